@@ -1,0 +1,251 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end of oracle/liboracle.so, the CPU restatement of the reference's
+MSM / NTT hot path (see oracle/ff.hpp, ec.hpp, msm.hpp, ntt.hpp for the
+reference file:line each function follows).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; nothing under sppark_amd/ does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BLS12_381, BN254 = 0, 1
+FIELD_BLS_FP, FIELD_BLS_FR, FIELD_BN_FP, FIELD_BN_FR = 0, 1, 2, 3
+NN, NR, RN, RR = 0, 1, 2, 3
+FORWARD, INVERSE = 0, 1
+STANDARD, COSET = 0, 1
+
+FP_BYTES = {BLS12_381: 48, BN254: 32}
+FR_MODULUS = {
+    BLS12_381: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+    BN254: int("30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", 16),
+}
+FP_MODULUS = {
+    BLS12_381: int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16),
+    BN254: int("30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47", 16),
+}
+GL64_P = 0xffffffff00000001
+BB31_P = 0x78000001
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref/ when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        vp, sz, ci, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
+        L.oracle_field_op.argtypes = [ci, ci, vp, vp, vp]
+        L.oracle_g1_generator.argtypes = [ci, vp, sz]
+        L.oracle_g1_gen_points.argtypes = [ci, vp, sz, sz, u64]
+        L.oracle_g1_mul.argtypes = [ci, vp, vp, sz, vp]
+        L.oracle_g1_on_curve.argtypes = [ci, vp, sz]
+        L.oracle_jac_to_affine.argtypes = [ci, vp, vp, sz]
+        L.oracle_xyzz_to_affine.argtypes = [ci, vp, vp, sz]
+        L.oracle_jac_add.argtypes = [ci, vp, vp, vp]
+        L.oracle_jac_dbl.argtypes = [ci, vp, vp]
+        L.oracle_jac_eq.argtypes = [ci, vp, vp]
+        L.oracle_msm.argtypes = [ci, ci, vp, vp, sz, sz, vp, ci, sz]
+        L.oracle_ntt_gl64.argtypes = [vp, ctypes.c_uint, ci, ci, ci]
+        L.oracle_ntt_bb31.argtypes = [vp, ctypes.c_uint, ci, ci, ci]
+        L.oracle_ntt_naive_gl64.argtypes = [vp, vp, ctypes.c_uint, ci]
+        L.oracle_ntt_naive_bb31.argtypes = [vp, vp, ctypes.c_uint, ci]
+        L.oracle_gl64_root.argtypes = [ctypes.c_uint]; L.oracle_gl64_root.restype = u64
+        L.oracle_bb31_root.argtypes = [ctypes.c_uint]; L.oracle_bb31_root.restype = ctypes.c_uint32
+        L.oracle_gl64_mul.argtypes = [u64, u64]; L.oracle_gl64_mul.restype = u64
+        L.oracle_bb31_mul.argtypes = [ctypes.c_uint32] * 2; L.oracle_bb31_mul.restype = ctypes.c_uint32
+        L.oracle_bb31_to_mont.argtypes = [ctypes.c_uint32]; L.oracle_bb31_to_mont.restype = ctypes.c_uint32
+        L.oracle_bb31_from_mont.argtypes = [ctypes.c_uint32]; L.oracle_bb31_from_mont.restype = ctypes.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ----------------------------------------------------------------- fields ----
+def int_to_limbs(x, nbytes):
+    return np.frombuffer(int(x).to_bytes(nbytes, "little"), dtype=np.uint64).copy()
+
+
+def limbs_to_int(a):
+    return int.from_bytes(np.ascontiguousarray(a).tobytes(), "little")
+
+
+def field_op(field, op, a, b=None):
+    nbytes = 48 if field == FIELD_BLS_FP else 32
+    out = np.zeros(nbytes // 8, dtype=np.uint64)
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    bp = _ptr(np.ascontiguousarray(b, dtype=np.uint64)) if b is not None else None
+    rc = lib().oracle_field_op(field, op, _ptr(out), _ptr(a), bp)
+    assert rc == 0
+    return out
+
+
+# --------------------------------------------------------------------- G1 ----
+def g1_generator(curve, stride=None):
+    stride = stride or 2 * FP_BYTES[curve]
+    out = np.zeros(stride, dtype=np.uint8)
+    lib().oracle_g1_generator(curve, _ptr(out), stride)
+    return out
+
+
+def g1_gen_points(curve, n, seed, stride=None):
+    """n points k_i*G (k_i from splitmix64(seed)) as an (n, stride) uint8 array."""
+    stride = stride or 2 * FP_BYTES[curve]
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lib().oracle_g1_gen_points(curve, _ptr(out), stride, n, seed)
+    return out
+
+
+def g1_mul(curve, point, k):
+    point = np.ascontiguousarray(point, dtype=np.uint8)
+    out = np.zeros_like(point)
+    kb = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    lib().oracle_g1_mul(curve, _ptr(out), _ptr(point), point.size, _ptr(kb))
+    return out
+
+
+def g1_on_curve(curve, point):
+    point = np.ascontiguousarray(point, dtype=np.uint8)
+    return bool(lib().oracle_g1_on_curve(curve, _ptr(point), point.size))
+
+
+def jac_to_affine(curve, jac, stride=None):
+    stride = stride or 2 * FP_BYTES[curve]
+    jac = np.ascontiguousarray(jac, dtype=np.uint8)
+    out = np.zeros(stride, dtype=np.uint8)
+    lib().oracle_jac_to_affine(curve, _ptr(out), _ptr(jac), stride)
+    return out
+
+
+def xyzz_to_affine(curve, p, stride=None):
+    stride = stride or 2 * FP_BYTES[curve]
+    p = np.ascontiguousarray(p, dtype=np.uint8)
+    out = np.zeros(stride, dtype=np.uint8)
+    lib().oracle_xyzz_to_affine(curve, _ptr(out), _ptr(p), stride)
+    return out
+
+
+def jac_add(curve, a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+    out = np.zeros_like(a)
+    lib().oracle_jac_add(curve, _ptr(out), _ptr(a), _ptr(b))
+    return out
+
+
+def jac_dbl(curve, a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    out = np.zeros_like(a)
+    lib().oracle_jac_dbl(curve, _ptr(out), _ptr(a))
+    return out
+
+
+def jac_eq(curve, a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8); b = np.ascontiguousarray(b, dtype=np.uint8)
+    return bool(lib().oracle_jac_eq(curve, _ptr(a), _ptr(b)))
+
+
+MSM_PIPPENGER_CPU, MSM_NAIVE, MSM_SIGNED = 0, 1, 2
+
+
+def msm(curve, points, scalars, algo=MSM_PIPPENGER_CPU, param=0, mont=False):
+    """points: (n, stride) uint8; scalars: (n, 32) uint8 LE.  Returns Jacobian bytes."""
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+    n = points.shape[0] if points.ndim == 2 else 0
+    stride = points.shape[1] if points.ndim == 2 else 2 * FP_BYTES[curve]
+    assert scalars.size == n * 32
+    out = np.zeros(3 * FP_BYTES[curve], dtype=np.uint8)
+    rc = lib().oracle_msm(curve, algo, _ptr(out), _ptr(points), stride, n, _ptr(scalars), int(mont), param)
+    assert rc == 0
+    return out
+
+
+def msm_affine(curve, points, scalars, **kw):
+    return jac_to_affine(curve, msm(curve, points, scalars, **kw))
+
+
+# -------------------------------------------------------------------- NTT ----
+def ntt_gl64(a, order=NN, direction=FORWARD, type=STANDARD):
+    a = np.array(a, dtype=np.uint64)
+    lg = int(a.size).bit_length() - 1
+    assert a.size == 1 << lg
+    lib().oracle_ntt_gl64(_ptr(a), lg, order, direction, type)
+    return a
+
+
+def ntt_bb31(a, order=NN, direction=FORWARD, type=STANDARD):
+    a = np.array(a, dtype=np.uint32)
+    lg = int(a.size).bit_length() - 1
+    assert a.size == 1 << lg
+    lib().oracle_ntt_bb31(_ptr(a), lg, order, direction, type)
+    return a
+
+
+def ntt_naive_gl64(a, inverse=False):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.zeros_like(a)
+    lib().oracle_ntt_naive_gl64(_ptr(out), _ptr(a), int(a.size).bit_length() - 1, int(inverse))
+    return out
+
+
+def ntt_naive_bb31(a, inverse=False):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.zeros_like(a)
+    lib().oracle_ntt_naive_bb31(_ptr(out), _ptr(a), int(a.size).bit_length() - 1, int(inverse))
+    return out
+
+
+# ------------------------------------------------------------- test inputs ---
+def random_scalars(curve, n, seed):
+    """n uniform scalars in [0, r) as an (n, 32) uint8 LE array (plain form)."""
+    rng = np.random.default_rng(seed)
+    r = FR_MODULUS[curve]
+    raw = rng.integers(0, 256, size=(n, 40), dtype=np.uint8)
+    out = np.zeros((n, 32), dtype=np.uint8)
+    for i in range(n):
+        out[i] = np.frombuffer((int.from_bytes(raw[i].tobytes(), "little") % r).to_bytes(32, "little"), dtype=np.uint8)
+    return out
+
+
+# ------------------------------------------------ the reference itself (_ref) -
+_REF = None
+
+
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_msm.so"))
+
+
+def ref_msm_affine(curve, points, scalars, nthreads=0, mont=False):
+    """The reference's own msm/pippenger.hpp (oracle/_ref/libref_msm.so); affine X|Y."""
+    global _REF
+    if _REF is None:
+        _REF = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_msm.so"))
+        _REF.ref_mult_pippenger.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
+    points = np.ascontiguousarray(points, dtype=np.uint8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+    out = np.zeros(2 * FP_BYTES[curve], dtype=np.uint8)
+    rc = _REF.ref_mult_pippenger(curve, _ptr(out), _ptr(points), points.shape[1], points.shape[0],
+                                 _ptr(scalars), int(mont), nthreads)
+    assert rc == 0
+    return out

@@ -1,0 +1,323 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Nothing under sppark_amd/ may include,
+// link or execute this file; only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg use it (as the checker, never as the product).
+//
+// CPU restatement of the reference's field layer for the MSM/NTT hot path.
+//
+//  * mont_t<P>   : N-bit Montgomery field on 64-bit limbs.  Restates the
+//                  semantics the reference gets from blst's blst_384_t /
+//                  blst_256_t (un-vendored dependency, blst v0.3.16 per
+//                  /root/reference/go.mod:5; call sites
+//                  ff/bls12-381.hpp:90-138, ff/alt_bn128.hpp:86-131) and that
+//                  the device class ff/mont_t.cuh:33-1217 implements with
+//                  32-bit limbs.  Algorithm here: schoolbook product followed
+//                  by word-serial Montgomery reduction (SOS form), chosen to
+//                  be *different* from the product's CIOS/FIPS device code so
+//                  that the two do not share bugs.  Residues mod p are unique,
+//                  so any correct implementation yields identical bytes.
+//  * gl64        : Goldilocks p = 2^64-2^32+1, canonical u64, non-Montgomery
+//                  (ff/gl64_t.cuh:39-587).
+//  * bb31        : BabyBear p = 0x78000001, Montgomery R = 2^32
+//                  (ff/mont32_t.cuh:19-425, ff/baby_bear.hpp:19).
+//
+// Constants (modulus, R^2, R, -1/p mod 2^64) are the reference's tables,
+// cited at each definition, and are re-derived from Python big-ints by
+// tests/test_oracle_fields.py.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+
+namespace oracle {
+
+typedef unsigned __int128 u128;
+
+// ---------------------------------------------------------------------------
+// Generic Montgomery field, P supplies: N (64-bit limbs), NBITS, MOD, RR, ONE, M0
+// ---------------------------------------------------------------------------
+template<class P> class mont_t {
+public:
+    static const size_t N = P::N;
+    static const size_t nbits = P::NBITS;
+    static const unsigned int degree = 1;
+    using mem_t = mont_t;
+    typedef unsigned char pow_t[(P::NBITS + 7) / 8];
+
+    uint64_t v[N];
+
+    mont_t() = default;
+
+    static const uint64_t* modulus() { return P::MOD; }
+
+    static mont_t from_limbs(const uint64_t* p)
+    {   mont_t r; for (size_t i = 0; i < N; i++) r.v[i] = p[i]; return r;   }
+
+    // one(or_zero): R mod p, or zero when the flag is set (ec/xyzz_t.hpp:24-26
+    // uses one(is_inf) to build ZZZ/ZZ of a point at infinity).
+    static mont_t one(bool or_zero = false)
+    {
+        mont_t r;
+        for (size_t i = 0; i < N; i++) r.v[i] = or_zero ? 0 : P::ONE[i];
+        return r;
+    }
+
+    bool is_zero() const
+    {   uint64_t acc = 0; for (size_t i = 0; i < N; i++) acc |= v[i]; return acc == 0;   }
+    void zero() { for (size_t i = 0; i < N; i++) v[i] = 0; }
+
+    friend bool operator==(const mont_t& a, const mont_t& b)
+    {   uint64_t acc = 0; for (size_t i = 0; i < N; i++) acc |= a.v[i] ^ b.v[i]; return acc == 0;   }
+    friend bool operator!=(const mont_t& a, const mont_t& b) { return !(a == b); }
+
+private:
+    // r = a - MOD if a >= MOD (carry = bit above the top limb)
+    static void final_sub(uint64_t r[], const uint64_t a[], uint64_t carry)
+    {
+        uint64_t t[N], borrow = 0;
+        for (size_t i = 0; i < N; i++) {
+            u128 d = (u128)a[i] - P::MOD[i] - borrow;
+            t[i] = (uint64_t)d;
+            borrow = (uint64_t)(d >> 64) & 1;
+        }
+        bool ge = carry || !borrow;
+        for (size_t i = 0; i < N; i++) r[i] = ge ? t[i] : a[i];
+    }
+
+public:
+    mont_t& operator+=(const mont_t& b)
+    {
+        uint64_t t[N], c = 0;
+        for (size_t i = 0; i < N; i++) {
+            u128 s = (u128)v[i] + b.v[i] + c;
+            t[i] = (uint64_t)s; c = (uint64_t)(s >> 64);
+        }
+        final_sub(v, t, c);
+        return *this;
+    }
+    mont_t& operator-=(const mont_t& b)
+    {
+        uint64_t borrow = 0;
+        for (size_t i = 0; i < N; i++) {
+            u128 d = (u128)v[i] - b.v[i] - borrow;
+            v[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1;
+        }
+        if (borrow) {
+            uint64_t c = 0;
+            for (size_t i = 0; i < N; i++) {
+                u128 s = (u128)v[i] + P::MOD[i] + c;
+                v[i] = (uint64_t)s; c = (uint64_t)(s >> 64);
+            }
+        }
+        return *this;
+    }
+    friend mont_t operator+(mont_t a, const mont_t& b) { return a += b; }
+    friend mont_t operator-(mont_t a, const mont_t& b) { return a -= b; }
+
+    // Montgomery product a*b/R mod p.
+    mont_t& operator*=(const mont_t& b)
+    {
+        uint64_t t[2*N + 1];
+        for (size_t i = 0; i < 2*N + 1; i++) t[i] = 0;
+        for (size_t i = 0; i < N; i++) {
+            uint64_t c = 0;
+            for (size_t j = 0; j < N; j++) {
+                u128 s = (u128)v[i] * b.v[j] + t[i+j] + c;
+                t[i+j] = (uint64_t)s; c = (uint64_t)(s >> 64);
+            }
+            t[i+N] = c;
+        }
+        for (size_t i = 0; i < N; i++) {
+            uint64_t m = t[i] * P::M0, c = 0;
+            for (size_t j = 0; j < N; j++) {
+                u128 s = (u128)m * P::MOD[j] + t[i+j] + c;
+                t[i+j] = (uint64_t)s; c = (uint64_t)(s >> 64);
+            }
+            for (size_t k = i + N; c != 0 && k < 2*N + 1; k++) {
+                u128 s = (u128)t[k] + c;
+                t[k] = (uint64_t)s; c = (uint64_t)(s >> 64);
+            }
+        }
+        final_sub(v, &t[N], t[2*N]);
+        return *this;
+    }
+    friend mont_t operator*(mont_t a, const mont_t& b) { return a *= b; }
+
+    // a^2 is spelled `a^2` in the reference templates (ec/xyzz_t.hpp:139).
+    friend mont_t operator^(mont_t a, int p)
+    {   if (p != 2) __builtin_trap(); a *= mont_t(a); return a;   }
+    mont_t& operator^=(int p)
+    {   if (p != 2) __builtin_trap(); mont_t t = *this; return *this *= t;   }
+
+    mont_t& operator<<=(unsigned l)
+    {   while (l--) { mont_t t = *this; *this += t; } return *this;   }
+    friend mont_t operator<<(mont_t a, unsigned l) { return a <<= l; }
+
+    mont_t& cneg(bool flag)
+    {
+        if (flag && !is_zero()) {
+            mont_t z; z.zero(); z -= *this; *this = z;
+        }
+        return *this;
+    }
+    friend mont_t czero(const mont_t& a, int set_z)
+    {   mont_t r = a; if (set_z) r.zero(); return r;   }
+
+    // to Montgomery form: a*RR/R ; from: a*1/R
+    mont_t& to()   { return *this *= from_limbs(P::RR); }
+    mont_t& from()
+    {   mont_t o; o.zero(); o.v[0] = 1; return *this *= o;   }
+
+    // from-Montgomery, little-endian bytes (msm/pippenger.hpp:236-241 calls
+    // scalar_t::to_scalar on Montgomery-form scalars).
+    void to_scalar(pow_t& out) const
+    {
+        mont_t t = *this; t.from();
+        for (size_t i = 0; i < sizeof(pow_t); i++)
+            out[i] = (unsigned char)(t.v[i/8] >> (8*(i%8)));
+    }
+
+    // Fermat inversion a^(p-2); 1/0 = 0.
+    mont_t reciprocal() const
+    {
+        uint64_t e[N]; uint64_t borrow = 2;
+        for (size_t i = 0; i < N; i++) {
+            u128 d = (u128)P::MOD[i] - borrow;
+            e[i] = (uint64_t)d; borrow = (uint64_t)(d >> 64) & 1;
+        }
+        mont_t r = one(), b = *this;
+        for (size_t i = 0; i < 64*N; i++) {
+            if ((e[i/64] >> (i%64)) & 1) r *= b;
+            b ^= 2;
+        }
+        return r;
+    }
+    friend mont_t operator/(int one_, const mont_t& a)
+    {   if (one_ != 1) __builtin_trap(); return a.reciprocal();   }
+};
+
+// ---------------------------------------------------------------------------
+// Parameter sets.  TO_LIMB values are the reference's tables.
+// ---------------------------------------------------------------------------
+struct bls12_381_fp_params {        // ff/bls12-381.hpp:100-116
+    static const size_t N = 6, NBITS = 381;
+    static constexpr uint64_t MOD[6] = {
+        0xb9feffffffffaaab, 0x1eabfffeb153ffff, 0x6730d2a0f6b0f624,
+        0x64774b84f38512bf, 0x4b1ba7b6434bacd7, 0x1a0111ea397fe69a };
+    static constexpr uint64_t RR[6] = {
+        0xf4df1f341c341746, 0x0a76e6a609d104f1, 0x8de5476c4c95b6d5,
+        0x67eb88a9939d83c0, 0x9a793e85b519952d, 0x11988fe592cae3aa };
+    static constexpr uint64_t ONE[6] = {
+        0x760900000002fffd, 0xebf4000bc40c0002, 0x5f48985753c758ba,
+        0x77ce585370525745, 0x5c071a97a256ec6d, 0x15f65ec3fa80e493 };
+    static const uint64_t M0 = 0x89f3fffcfffcfffd;
+};
+struct bls12_381_fr_params {        // ff/bls12-381.hpp:125-138
+    static const size_t N = 4, NBITS = 255;
+    static constexpr uint64_t MOD[4] = {
+        0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48 };
+    static constexpr uint64_t RR[4] = {
+        0xc999e990f3f29c6d, 0x2b6cedcb87925c23, 0x05d314967254398f, 0x0748d9d99f59ff11 };
+    static constexpr uint64_t ONE[4] = {
+        0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f };
+    static const uint64_t M0 = 0xfffffffeffffffff;
+};
+struct alt_bn128_fp_params {        // ff/alt_bn128.hpp:88-101
+    static const size_t N = 4, NBITS = 254;
+    static constexpr uint64_t MOD[4] = {
+        0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029 };
+    static constexpr uint64_t RR[4] = {
+        0xf32cfc5b538afa89, 0xb5e71911d44501fb, 0x47ab1eff0a417ff6, 0x06d89f71cab8351f };
+    static constexpr uint64_t ONE[4] = {
+        0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f };
+    static const uint64_t M0 = 0x87d20782e4866389;
+};
+struct alt_bn128_fr_params {        // ff/alt_bn128.hpp:111-124
+    static const size_t N = 4, NBITS = 254;
+    static constexpr uint64_t MOD[4] = {
+        0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029 };
+    static constexpr uint64_t RR[4] = {
+        0x1bb8e645ae216da7, 0x53fe3ab1e35c59e3, 0x8c49833d53bb8085, 0x0216d0b17f4e44a5 };
+    static constexpr uint64_t ONE[4] = {
+        0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f };
+    static const uint64_t M0 = 0xc2e1f593efffffff;
+};
+
+// ---------------------------------------------------------------------------
+// Goldilocks (ff/gl64_t.cuh:39-587): canonical residues in a u64.
+// ---------------------------------------------------------------------------
+struct gl64 {
+    static const uint64_t MOD = 0xffffffff00000001ULL;
+    uint64_t v;
+    gl64() = default;
+    explicit gl64(uint64_t x) : v(x % MOD) {}
+    static gl64 one() { return gl64(1); }
+    friend gl64 operator+(gl64 a, gl64 b)
+    {   u128 s = (u128)a.v + b.v; if (s >= MOD) s -= MOD; gl64 r; r.v = (uint64_t)s; return r;   }
+    friend gl64 operator-(gl64 a, gl64 b)
+    {   gl64 r; r.v = a.v >= b.v ? a.v - b.v : a.v + (MOD - b.v); return r;   }
+    friend gl64 operator*(gl64 a, gl64 b)
+    {   gl64 r; r.v = (uint64_t)(((u128)a.v * b.v) % MOD); return r;   }
+    gl64& operator*=(gl64 b) { return *this = *this * b; }
+    friend bool operator==(gl64 a, gl64 b) { return a.v == b.v; }
+    uint64_t raw() const { return v; }
+    static gl64 from_raw(uint64_t x) { gl64 r; r.v = x; return r; }
+    // reference NTT root tables, ntt/parameters/goldilocks.h:84-159 (default
+    // "canonical" generator branch): group_gen = 7, the 2^32-th root below;
+    // every other entry of forward_roots_of_unity[] is a repeated square of it.
+    static const unsigned TWO_ADICITY = 32;
+    static gl64 group_gen()   { return gl64(7); }
+    static gl64 top_root()    { return gl64(0x185629dcda58878cULL); }
+};
+
+// ---------------------------------------------------------------------------
+// BabyBear (ff/baby_bear.hpp:19; ff/mont32_t.cuh): Montgomery, R = 2^32.
+// Wire format = Montgomery residues (poc/ntt-cuda/tests/ntt.rs:50-53).
+// ---------------------------------------------------------------------------
+struct bb31 {
+    static const uint32_t MOD = 0x78000001u;
+    static const uint32_t M   = 0x77ffffffu;     // -1/MOD mod 2^32
+    static const uint32_t RR  = 0x45dddde3u;     // 2^64 mod MOD
+    static const uint32_t ONE = 0x0ffffffeu;     // 2^32 mod MOD
+    uint32_t v;                                  // Montgomery residue
+    bb31() = default;
+    static bb31 from_raw(uint32_t x) { bb31 r; r.v = x; return r; }
+    static bb31 from_canonical(uint32_t x)
+    {   bb31 r; r.v = (uint32_t)((((uint64_t)(x % MOD)) << 32) % MOD); return r;   }
+    uint32_t to_canonical() const
+    {   bb31 o; o.v = 1; return (*this * o).v;   }
+    static bb31 one() { return from_raw(ONE); }
+    uint32_t raw() const { return v; }
+    friend bb31 operator+(bb31 a, bb31 b)
+    {   uint64_t s = (uint64_t)a.v + b.v; if (s >= MOD) s -= MOD; return from_raw((uint32_t)s);   }
+    friend bb31 operator-(bb31 a, bb31 b)
+    {   return from_raw(a.v >= b.v ? a.v - b.v : a.v + (MOD - b.v));   }
+    friend bb31 operator*(bb31 a, bb31 b)
+    {
+        uint64_t t = (uint64_t)a.v * b.v;
+        uint32_t m = (uint32_t)t * M;
+        uint64_t u = (t + (uint64_t)m * MOD) >> 32;       // < 2*MOD
+        if (u >= MOD) u -= MOD;
+        return from_raw((uint32_t)u);
+    }
+    bb31& operator*=(bb31 b) { return *this = *this * b; }
+    friend bool operator==(bb31 a, bb31 b) { return a.v == b.v; }
+    // ntt/parameters/baby_bear.h:76-175 (default branch): group_gen = 3,
+    // forward_roots_of_unity[27] = 0x1ffffedc (Montgomery).
+    static const unsigned TWO_ADICITY = 27;
+    static bb31 group_gen()   { return from_canonical(3); }
+    static bb31 top_root()    { return from_raw(0x1ffffedcu); }
+};
+
+template<class F> static inline F fpow(F b, uint64_t e)
+{
+    F r = F::one();
+    while (e) { if (e & 1) r *= b; b *= b; e >>= 1; }
+    return r;
+}
+
+typedef mont_t<bls12_381_fp_params> bls12_381_fp;
+typedef mont_t<bls12_381_fr_params> bls12_381_fr;
+typedef mont_t<alt_bn128_fp_params> alt_bn128_fp;
+typedef mont_t<alt_bn128_fr_params> alt_bn128_fr;
+
+} // namespace oracle

@@ -1,0 +1,112 @@
+/*
+ * sppark_amd C ABI — the drop-in boundary.
+ *
+ * One shared object per field/curve, exactly as the reference builds one per
+ * -DFEATURE_* (rust/src/build.rs ccmd(), poc/{msm,ntt}-cuda/build.rs):
+ *
+ *   libsppark_bls12_381.so  mult_pippenger_inf, mult_pippenger          (BLS12-381 G1)
+ *   libsppark_bn254.so      mult_pippenger_inf, mult_pippenger          (alt_bn128 G1)
+ *   libsppark_gl64.so       compute_ntt                                 (Goldilocks)
+ *   libsppark_bb31.so       compute_ntt                                 (BabyBear)
+ *
+ * plus, in every library, the four symbols of util/all_gpus.cpp:65-86.
+ * Section 1 below declares exactly what the reference's Rust/Go callers bind;
+ * section 2 is this implementation's extension surface (contexts that keep
+ * scratch memory and inputs resident in HBM, stream selection, kernel timers,
+ * host-side point helpers).  Plain pointers and sizes only.
+ *
+ * All field elements are little-endian limbs in Montgomery form (R = 2^384 for
+ * the BLS12-381 base field, 2^256 for 256-bit fields, 2^32 for BabyBear), except
+ * Goldilocks (canonical u64) and MSM scalars (plain little-endian integers < r).
+ * Pointers may be HOST or DEVICE (HIP) pointers; the library detects which.
+ */
+#ifndef SPPARK_AMD_H
+#define SPPARK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* util/rusterror.h:18-36 — returned BY VALUE (RAX:RDX on SysV x86-64).
+ * code == 0: success; otherwise the negated HIP error code.  message is
+ * malloc'ed (strdup) or NULL; the caller frees it (Rust: libc free on drop,
+ * rust/src/lib.rs:9-23; Go: drop_error_message, go/sppark.go:51-60). */
+typedef struct { int code; char *message; } SppError;
+
+/* ------------------------------------------------------------------------ */
+/* 1. The reference's FFI surface                                            */
+/* ------------------------------------------------------------------------ */
+
+/* poc/msm-cuda/cuda/pippenger_inf.cu:29-34.  points: array of Affine_inf_t
+ * (X | Y | infinity-flag byte) with stride ffi_affine_sz (104 for arkworks
+ * BLS12-381 G1Affine, 72 for bn254); scalars: 32-byte integers < r, NOT in
+ * Montgomery form; out: Jacobian X|Y|Z (144 B / 96 B).  On error out = infinity. */
+SppError mult_pippenger_inf(void *out, const void *points, size_t npoints,
+                            const void *scalars, size_t ffi_affine_sz);
+
+/* poc/msm-cuda/cuda/pippenger.cu:20-25.  points: Affine_t (X | Y, infinity
+ * encoded as all-zero), stride 2*sizeof(fp); same scalars/out as above. */
+SppError mult_pippenger(void *out, const void *points, size_t npoints,
+                        const void *scalars);
+
+/* poc/ntt-cuda/cuda/ntt_api.cu:25-36.  In-place transform of 2^lg_domain_size
+ * elements.  order: NN=0 NR=1 RN=2 RR=3; direction: forward=0 inverse=1;
+ * type: standard=0 coset=1 (ntt/ntt.cuh:33-36).  lg_domain_size == 0 is a
+ * successful no-op (ntt/ntt.cuh:220-221). */
+SppError compute_ntt(size_t device_id, void *inout, uint32_t lg_domain_size,
+                     int ntt_order, int ntt_direction, int ntt_type);
+
+/* util/all_gpus.cpp:65-86 */
+bool  cuda_available(void);
+void  drop_gpu_ptr_t(void **ref);           /* gpu_ptr_t<void>& : one pointer to a ref-counted block */
+void *clone_gpu_ptr_t(void *const *ref);    /* returns gpu_ptr_t<void>::by_value                      */
+void  drop_error_message(char *msg);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Extension surface (device-resident inputs, reusable scratch, timers)   */
+/*    Counterpart of the reference's C++-only msm_t / NTT::Base_dev_ptr API  */
+/*    (msm/pippenger.cuh:351-388,582-610; ntt/ntt.cuh:344-350).              */
+/* ------------------------------------------------------------------------ */
+
+typedef struct sppark_msm_ctx sppark_msm_ctx;
+
+/* device_id indexes the filtered device list, -1 = current HIP device.
+ * stream: a hipStream_t to launch on, or NULL for a private stream. */
+SppError sppark_msm_create(sppark_msm_ctx **ctx, int device_id, void *stream);
+void     sppark_msm_destroy(sppark_msm_ctx *ctx);
+SppError sppark_msm_set_stream(sppark_msm_ctx *ctx, void *stream);
+/* wbits/L/F/K/nslabs = 0 keeps the automatic choice */
+SppError sppark_msm_tune(sppark_msm_ctx *ctx, unsigned wbits, unsigned L, unsigned F,
+                         unsigned K, unsigned nslabs);
+SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affine_sz,
+                            int host_points, int host_scalars);
+/* mont != 0: scalars are in Montgomery form (msm_t::invoke's `mont`). */
+SppError sppark_msm_invoke(sppark_msm_ctx *ctx, void *out, const void *points, size_t npoints,
+                           const void *scalars, int mont, size_t ffi_affine_sz);
+SppError sppark_msm_enable_timing(sppark_msm_ctx *ctx, int on);
+/* which: 0 digits+sort, 1 bucket accumulation kernel, 2 all device work (ms of the last invoke) */
+float    sppark_msm_kernel_ms(const sppark_msm_ctx *ctx, int which);
+size_t   sppark_msm_scratch_bytes(const sppark_msm_ctx *ctx);
+
+/* Host-side helpers on Jacobian points (no GPU needed): out = sum of n points;
+ * affine = (x, y) of a Jacobian point, infinity -> all-zero.  Used by the
+ * multi-GPU combine step and by callers that want affine results. */
+void sppark_g1_jacobian_sum(void *out, const void *points, size_t n);
+void sppark_g1_to_affine(void *out_xy, const void *jacobian);
+/* P_i = k_i * G for i < n on the DEVICE, k_i = splitmix64(seed) stream, 253-bit;
+ * out: affine, stride bytes apart (flag byte written when stride > 2*sizeof(fp)).
+ * out may be a host or device pointer.  Synthetic-input generator for benches. */
+SppError sppark_g1_generate(void *out, size_t stride, size_t n, uint64_t seed);
+
+/* NTT on a device- or host-resident buffer with an explicit stream. */
+SppError sppark_ntt(size_t device_id, void *inout, uint32_t lg_domain_size,
+                    int ntt_order, int ntt_direction, int ntt_type, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

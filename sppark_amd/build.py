@@ -1,0 +1,98 @@
+"""Build the sppark_amd C-ABI libraries for gfx950 with hipcc (cross-compiles
+without a GPU).  One shared object per FEATURE, as the reference builds one per
+-DFEATURE_* (rust/src/build.rs ccmd(); poc/*/build.rs).  Translation units are
+compiled in parallel; objects are cached under build/ keyed on source mtimes.
+
+    python -m sppark_amd.build [--force] [--only bls12_381,gl64]
+"""
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+         "-Wno-duplicate-decl-specifier"]
+
+MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
+           "msm/k_bucket1.hip", "msm/k_bucketN.hip", "api/devtest_api.hip"]
+NTT_TUS = ["api/ntt_api.hip"]
+
+TARGETS = {
+    "bls12_381": ("FEATURE_BLS12_381", MSM_TUS),
+    "bn254":     ("FEATURE_BN254", MSM_TUS),
+    "gl64":      ("FEATURE_GOLDILOCKS", NTT_TUS),
+    "bb31":      ("FEATURE_BABY_BEAR", NTT_TUS),
+}
+
+
+def lib_path(name):
+    return os.path.join(LIBDIR, "libsppark_%s.so" % name)
+
+
+def _sources_stamp():
+    h = hashlib.sha1()
+    for root, _, files in sorted(os.walk(CSRC)):
+        for f in sorted(files):
+            p = os.path.join(root, f)
+            h.update(p.encode()); h.update(str(os.stat(p).st_mtime_ns).encode())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def _compile(job):
+    src, obj, feature = job
+    t0 = time.time()
+    cmd = [HIPCC] + FLAGS + ["-D" + feature, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return src, feature, time.time() - t0, r.returncode, r.stderr
+
+
+def build(only=None, force=False, verbose=True, jobs=None):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = _sources_stamp()
+    names = [n for n in TARGETS if (only is None or n in only)]
+    names = [n for n in names if all(os.path.exists(os.path.join(CSRC, s)) for s in TARGETS[n][1])]
+    todo, links = [], {}
+    for n in names:
+        feature, tus = TARGETS[n]
+        stamp_file = lib_path(n) + ".stamp"
+        if not force and os.path.exists(lib_path(n)) and os.path.exists(stamp_file) \
+                and open(stamp_file).read() == stamp:
+            continue
+        objs = []
+        for s in tus:
+            obj = os.path.join(OBJDIR, "%s__%s.o" % (n, s.replace("/", "_")))
+            objs.append(obj)
+            todo.append((s, obj, feature))
+        links[n] = objs
+    if todo:
+        with cf.ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
+            for src, feature, dt, rc, err in ex.map(_compile, todo):
+                if verbose:
+                    print("[sppark_amd.build] %-24s %-20s %6.1fs" % (src, feature, dt), flush=True)
+                if rc != 0:
+                    raise RuntimeError("hipcc failed for %s (%s):\n%s" % (src, feature, err))
+    for n, objs in links.items():
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path(n)] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed for %s:\n%s" % (n, r.stderr))
+        open(lib_path(n) + ".stamp", "w").write(stamp)
+        if verbose:
+            print("[sppark_amd.build] linked", lib_path(n), flush=True)
+    return [lib_path(n) for n in names]
+
+
+if __name__ == "__main__":
+    only = None
+    if "--only" in sys.argv:
+        only = sys.argv[sys.argv.index("--only") + 1].split(",")
+    build(only=only, force="--force" in sys.argv)

@@ -1,0 +1,251 @@
+// Device test hooks and micro-benchmarks (exported as sppark_devtest_*).
+// They exist so that tests/ can check the DEVICE field / point arithmetic
+// element-by-element against the oracle, and so that DESIGN.md's instruction
+// costs are measured on the box rather than assumed.  Not part of the
+// reference's surface.
+#include "../msm/curve_select.hpp"
+#include "../util/runtime.hpp"
+#include <vector>
+
+using namespace sppark_amd;
+
+#define SPPARK_FFI extern "C" __attribute__((visibility("default")))
+
+template<class F>
+__global__ void k_field_op(u32* out, const u32* a, const u32* b, unsigned n, int op)
+{
+    constexpr int N = F::N;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x, y, r;
+    for (int k = 0; k < N; k++) { x.v[k] = a[(size_t)i * N + k]; y.v[k] = b[(size_t)i * N + k]; }
+    switch (op) {
+        case 0: r = x + y; break;
+        case 1: r = x - y; break;
+        case 2: r = x * y; break;
+        case 3: r = x.sqr(); break;
+        case 4: r = x.neg(); break;
+        case 5: r = x.from(); break;
+        case 6: r = x.to(); break;
+        default: r = x.dbl(); break;
+    }
+    for (int k = 0; k < N; k++) out[(size_t)i * N + k] = r.v[k];
+}
+
+// op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
+__global__ void k_xyzz_op(bucket_d* out, const bucket_d* a, const unsigned char* b, unsigned n, int op)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bucket_d p = bucket_d::load(&a[i]);
+    if (op == 0) {
+        p.add(bucket_d::load(reinterpret_cast<const bucket_d*>(b) + i));
+    } else if (op == 3) {
+        p.dbl();
+    } else {
+        affine_dev<fp_d> q = load_affine<fp_d, false>(b, i, 2 * sizeof(fp_d));
+        p.madd(q, op == 2);
+    }
+    p.store(&out[i]);
+}
+
+template<class Fn> static RustError guarded(Fn&& fn)
+{
+    try { fn(); return rust_ok(); }
+    catch (const hip_error& e) { (void)hipGetLastError(); return rust_err(e.code(), e.what()); }
+    catch (const std::exception& e) { return rust_err(-1, e.what()); }
+}
+
+template<class F>
+static void run_field_op(int op, void* out, const void* a, const void* b, size_t n)
+{
+    (void)select_gpu(-1);
+    size_t bytes = n * sizeof(F);
+    u32 *d_a, *d_b, *d_o;
+    HIP_OK(hipMalloc((void**)&d_a, bytes)); HIP_OK(hipMalloc((void**)&d_b, bytes)); HIP_OK(hipMalloc((void**)&d_o, bytes));
+    HIP_OK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_b, b ? b : a, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_field_op<F>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+}
+
+// field 0 = base field fp, 1 = scalar field fr
+SPPARK_FFI RustError sppark_devtest_field_op(int field, int op, void* out, const void* a, const void* b, size_t n)
+{
+    return guarded([&] {
+        if (field == 0) run_field_op<fp_d>(op, out, a, b, n);
+        else            run_field_op<fr_d>(op, out, a, b, n);
+    });
+}
+
+SPPARK_FFI RustError sppark_devtest_xyzz_op(int op, void* out, const void* a, const void* b, size_t n)
+{
+    return guarded([&] {
+        (void)select_gpu(-1);
+        size_t ab = n * sizeof(bucket_d), bb = n * (op == 0 ? sizeof(bucket_d) : 2 * sizeof(fp_d));
+        bucket_d *d_a, *d_o; unsigned char* d_b;
+        HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_o, ab)); HIP_OK(hipMalloc((void**)&d_b, bb ? bb : 16));
+        HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice));
+        if (op != 3) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_xyzz_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(out, d_o, ab, hipMemcpyDeviceToHost));
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+    });
+}
+
+// ---------------------------------------------------------------------------
+// micro-benchmarks: every wave runs |iters| iterations of a fixed instruction
+// block and reports its own s_memtime delta; the host also times the launch.
+// ---------------------------------------------------------------------------
+#define UB_REP8(x) x x x x x x x x
+
+__global__ void k_ub(int which, int iters, u64* clocks, u32* sink)
+{
+    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 977u;
+    u64 acc0 = a, acc1 = b, acc2 = a ^ b, acc3 = a + b, acc4 = 1, acc5 = 2, acc6 = 3, acc7 = 4;
+    u32 c0 = 0, c1 = 0;
+    double f0 = a, f1 = b, f2 = 1.0000001, f3 = 3;
+    u64 t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i++) {
+        switch (which) {
+        case 0:     // 8 independent v_mad_u64_u32
+            asm volatile(
+                "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\t"
+                "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\t"
+                "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\t"
+                "v_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7"
+                : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(acc5), "+v"(acc6), "+v"(acc7)
+                : "v"(a), "v"(b) : "vcc");
+            break;
+        case 1:     // 8 dependent v_mad_u64_u32
+            asm volatile(UB_REP8("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t") : "+v"(acc0) : "v"(a), "v"(b) : "vcc");
+            break;
+        case 2:     // 8 dependent mad + addc pairs (the mac96 primitive)
+            asm volatile(UB_REP8("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t")
+                         : "+v"(acc0), "+v"(c0) : "v"(a), "v"(b) : "vcc");
+            break;
+        case 3:     // 2 interleaved chains of mad + addc
+            asm volatile(
+                "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+                "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                "v_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc"
+                : "+v"(acc0), "+v"(c0), "+v"(acc1), "+v"(c1) : "v"(a), "v"(b) : "vcc");
+            break;
+        case 4:     // 8 dependent mad + addc pairs with an s_nop 0 after each pair
+            asm volatile(UB_REP8("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t")
+                         : "+v"(acc0), "+v"(c0) : "v"(a), "v"(b) : "vcc");
+            break;
+        case 5:     // 8 dependent v_mul_lo_u32
+            asm volatile(UB_REP8("v_mul_lo_u32 %0, %0, %1\n\t") : "+v"(c0) : "v"(a));
+            break;
+        case 6:     // 8 dependent v_mul_hi_u32
+            asm volatile(UB_REP8("v_mul_hi_u32 %0, %0, %1\n\t") : "+v"(c0) : "v"(a));
+            break;
+        case 7:     // 8 dependent v_mad_u32_u24
+            asm volatile(UB_REP8("v_mad_u32_u24 %0, %0, %1, %0\n\t") : "+v"(c0) : "v"(a));
+            break;
+        case 8:     // 8 dependent v_add_co / v_addc_co pairs (64-bit add)
+            asm volatile(UB_REP8("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc\n\t")
+                         : "+v"(c0), "+v"(c1) : "v"(a), "v"(b) : "vcc");
+            break;
+        case 9:     // 8 independent v_fma_f64 (4 chains x 2)
+            asm volatile(
+                "v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5\n\t"
+                "v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5"
+                : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(1.0000001), "v"(0.5));
+            break;
+        case 10:    // 8 dependent v_lshl_add_u64
+            asm volatile(UB_REP8("v_lshl_add_u64 %0, %0, 0, %1\n\t") : "+v"(acc0) : "v"(acc1));
+            break;
+        case 11:    // 8 dependent v_add_u32
+            asm volatile(UB_REP8("v_add_u32 %0, %0, %1\n\t") : "+v"(c0) : "v"(a));
+            break;
+        case 12:    // 8 independent v_mul_lo_u32
+            {
+                u32 m0 = (u32)acc0, m1 = (u32)acc1, m2 = (u32)acc2, m3 = (u32)acc3;
+                asm volatile(
+                    "v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4\n\t"
+                    "v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4"
+                    : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(a));
+                acc0 = m0; acc1 = m1; acc2 = m2; acc3 = m3;
+            }
+            break;
+        default: break;
+        }
+    }
+    u64 t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+    u64 s = acc0 ^ acc1 ^ acc2 ^ acc3 ^ acc4 ^ acc5 ^ acc6 ^ acc7 ^ c0 ^ c1 ^ (u64)(f0 + f1 + f2 + f3);
+    if (s == 0x123456789abcdefULL) sink[0] = (u32)s;
+}
+
+// returns elapsed ms; *cycles_per_iter = mean s_memtime delta per iteration over waves
+SPPARK_FFI RustError sppark_devtest_ubench(int which, int iters, unsigned blocks, unsigned threads,
+                                           float* ms, double* cycles_per_iter)
+{
+    return guarded([&] {
+        (void)select_gpu(-1);
+        size_t nw = (size_t)blocks * threads / 64;
+        u64* d_clk; u32* d_sink;
+        HIP_OK(hipMalloc((void**)&d_clk, nw * 8)); HIP_OK(hipMalloc((void**)&d_sink, 64));
+        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(threads), 0, 0, which, 16, d_clk, d_sink);   // warm-up
+        HIP_OK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_ub, dim3(blocks), dim3(threads), 0, 0, which, iters, d_clk, d_sink);
+        HIP_OK(hipEventRecord(e1, 0));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(ms, e0, e1));
+        std::vector<u64> clk(nw);
+        HIP_OK(hipMemcpy(clk.data(), d_clk, nw * 8, hipMemcpyDeviceToHost));
+        double sum = 0; for (auto c : clk) sum += (double)c;
+        *cycles_per_iter = sum / nw / iters;
+        (void)hipFree(d_clk); (void)hipFree(d_sink); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    });
+}
+
+// field-level throughput: x = x*y (op 0), x = x.sqr() (1), x = x+y (2), xyzz madd (3), xyzz add (4)
+__global__ void k_fieldbench(int op, int iters, u32* io)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    fp_d x, y;
+    for (int k = 0; k < fp_d::N; k++) { x.v[k] = io[k] ^ (i * 2654435761u >> 3); y.v[k] = io[k + fp_d::N] + i; }
+    x.v[fp_d::N - 1] &= 0x0fffffff; y.v[fp_d::N - 1] &= 0x0fffffff;
+    if (op <= 2) {
+        for (int it = 0; it < iters; it++) {
+            if (op == 0) x = x * y; else if (op == 1) x = x.sqr(); else x = x + y;
+        }
+        if (x.is_zero()) io[0] = 1;
+    } else {
+        bucket_d p; p.X = x; p.Y = y; p.ZZ = y; p.ZZZ = x;
+        affine_dev<fp_d> q; q.X = y; q.Y = x; q.inf = false;
+        bucket_d r = p; r.X = y;
+        for (int it = 0; it < iters; it++) {
+            if (op == 3) p.madd(q, it & 1); else p.add(r);
+        }
+        if (p.X.is_zero()) io[0] = 1;
+    }
+}
+
+SPPARK_FFI RustError sppark_devtest_fieldbench(int op, int iters, unsigned blocks, unsigned threads, float* ms)
+{
+    return guarded([&] {
+        (void)select_gpu(-1);
+        u32* d_io; HIP_OK(hipMalloc((void**)&d_io, 4096)); HIP_OK(hipMemset(d_io, 0x5a, 4096));
+        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_fieldbench, dim3(blocks), dim3(threads), 0, 0, op, 2, d_io);
+        HIP_OK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k_fieldbench, dim3(blocks), dim3(threads), 0, 0, op, iters, d_io);
+        HIP_OK(hipEventRecord(e1, 0));
+        HIP_OK(hipEventSynchronize(e1));
+        HIP_OK(hipEventElapsedTime(ms, e0, e1));
+        (void)hipFree(d_io); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    });
+}

@@ -1,0 +1,200 @@
+// C-ABI of the MSM library (one .so per curve, selected by -DFEATURE_*, as the
+// reference's poc/msm-cuda/build.rs does).  Declarations + reference
+// citations: include/sppark_amd.h.  No C++ exception crosses this boundary
+// (msm/pippenger.cuh:735-746).
+#include "../msm/curve_select.hpp"
+#include "../msm/msm_kernels.hpp"
+#include "../msm/msm_sort_kernels.hpp"
+
+// the big kernels are instantiated in their own translation units
+// (msm/k_accumulate.hip, k_reduce.hip, k_bucket1.hip, k_bucketN.hip)
+namespace sppark_amd {
+extern template __global__ void k_accumulate<fp_d, false>(bucket_d*, u32*, bucket_d*, const unsigned char*, unsigned,
+                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_accumulate<fp_d, true>(bucket_d*, u32*, bucket_d*, const unsigned char*, unsigned,
+                                                         const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_reduce_runs<fp_d>(bucket_d*, u32*, bucket_d*, const u32*, const bucket_d*,
+                                                    unsigned, unsigned, unsigned, int);
+extern template __global__ void k_bucket_level1<fp_d>(bucket_d*, bucket_d*, const bucket_d*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_levelN<fp_d>(bucket_d*, bucket_d*, const bucket_d*, const bucket_d*,
+                                                      unsigned, unsigned, unsigned, unsigned);
+}
+
+#include "../msm/msm_driver.hpp"
+#include "common_api.hpp"
+
+using namespace sppark_amd;
+
+typedef msm_t<curve_p::fp, curve_p::fr> msm_impl;
+typedef msm_impl::point_t point_t;
+typedef msm_impl::fp_h fp_h;
+
+struct sppark_msm_ctx { msm_impl impl; sppark_msm_ctx(int id, hipStream_t s) : impl(id, s) {} };
+
+static void store_point(void* out, const point_t& p) { memcpy(out, &p, sizeof(p)); }
+static void store_inf(void* out) { memset(out, 0, sizeof(point_t)); }
+
+template<class Fn> static RustError guarded(Fn&& fn)
+{
+    try { fn(); return rust_ok(); }
+    catch (const hip_error& e) { (void)hipGetLastError(); return rust_err(e.code(), e.what()); }
+    catch (const std::exception& e) { return rust_err(-1, e.what()); }
+    catch (...) { return rust_err(-1, "unknown exception"); }
+}
+
+static RustError one_shot(void* out, const void* points, size_t npoints, const void* scalars,
+                          bool mont, size_t ffi_sz)
+{
+    store_inf(out);
+    return guarded([&] {
+        msm_impl msm(-1);                               // select_gpu(-1): current device
+        point_t r;
+        msm.invoke(r, points, npoints, scalars, mont, ffi_sz);
+        store_point(out, r);
+    });
+}
+
+extern "C" {
+
+SPPARK_FFI RustError mult_pippenger_inf(void* out, const void* points, size_t npoints,
+                                        const void* scalars, size_t ffi_affine_sz)
+{   return one_shot(out, points, npoints, scalars, false, ffi_affine_sz);   }
+
+SPPARK_FFI RustError mult_pippenger(void* out, const void* points, size_t npoints, const void* scalars)
+{   return one_shot(out, points, npoints, scalars, false, 2 * sizeof(fp_d));   }
+
+SPPARK_FFI RustError sppark_msm_create(sppark_msm_ctx** ctx, int device_id, void* stream)
+{
+    *ctx = nullptr;
+    return guarded([&] { *ctx = new sppark_msm_ctx(device_id, (hipStream_t)stream); });
+}
+SPPARK_FFI void sppark_msm_destroy(sppark_msm_ctx* ctx) { delete ctx; }
+SPPARK_FFI RustError sppark_msm_set_stream(sppark_msm_ctx* ctx, void* stream)
+{   return guarded([&] { ctx->impl.set_stream((hipStream_t)stream); });   }
+SPPARK_FFI RustError sppark_msm_tune(sppark_msm_ctx* ctx, unsigned wbits, unsigned L, unsigned F,
+                                     unsigned K, unsigned nslabs)
+{
+    return guarded([&] {
+        if ((K & (K - 1)) || wbits > 16) HIP_OK(hipErrorInvalidValue);
+        ctx->impl.tune.wbits = wbits; ctx->impl.tune.L = L; ctx->impl.tune.F = F;
+        ctx->impl.tune.K = K; ctx->impl.tune.nslabs = nslabs;
+    });
+}
+SPPARK_FFI RustError sppark_msm_reserve(sppark_msm_ctx* ctx, size_t npoints, size_t ffi_affine_sz,
+                                        int host_points, int host_scalars)
+{   return guarded([&] { ctx->impl.reserve_for(npoints, ffi_affine_sz, host_points, host_scalars); });   }
+SPPARK_FFI RustError sppark_msm_invoke(sppark_msm_ctx* ctx, void* out, const void* points, size_t npoints,
+                                       const void* scalars, int mont, size_t ffi_affine_sz)
+{
+    store_inf(out);
+    return guarded([&] {
+        point_t r;
+        ctx->impl.invoke(r, points, npoints, scalars, mont != 0, ffi_affine_sz);
+        store_point(out, r);
+    });
+}
+SPPARK_FFI RustError sppark_msm_enable_timing(sppark_msm_ctx* ctx, int on)
+{   return guarded([&] { ctx->impl.enable_timing(on != 0); });   }
+SPPARK_FFI float sppark_msm_kernel_ms(const sppark_msm_ctx* ctx, int which) { return ctx->impl.kernel_ms(which); }
+SPPARK_FFI size_t sppark_msm_scratch_bytes(const sppark_msm_ctx* ctx) { return ctx->impl.scratch_bytes(); }
+
+// ---- host-side point helpers (no GPU work) --------------------------------
+SPPARK_FFI void sppark_g1_jacobian_sum(void* out, const void* points, size_t n)
+{
+    point_t acc; acc.set_inf();
+    for (size_t i = 0; i < n; i++) {
+        point_t p; memcpy(&p, (const char*)points + i * sizeof(point_t), sizeof(p));
+        acc.add(p);
+    }
+    store_point(out, acc);
+}
+SPPARK_FFI void sppark_g1_to_affine(void* out_xy, const void* jacobian)
+{
+    point_t p; memcpy(&p, jacobian, sizeof(p));
+    fp_h xy[2];
+    p.to_affine(xy[0], xy[1]);
+    memcpy(out_xy, xy, sizeof(xy));
+}
+
+} // extern "C"
+
+// ---- synthetic-input generator: P_i = k_i * G on the device ------------------
+__device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 j)
+{
+    u64 z = seed + (j + 1) * 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(64)
+void k_generate(xyzz_dev<fp_d>* out, unsigned n, u64 seed)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    affine_dev<fp_d> g;
+    #pragma unroll
+    for (int k = 0; k < fp_d::N / 2; k++) {
+        g.X.v[2*k] = (u32)curve_p::GX64[k]; g.X.v[2*k+1] = (u32)(curve_p::GX64[k] >> 32);
+        g.Y.v[2*k] = (u32)curve_p::GY64[k]; g.Y.v[2*k+1] = (u32)(curve_p::GY64[k] >> 32);
+    }
+    g.inf = false;
+    u64 kw[4];
+    for (int w = 0; w < 4; w++) kw[w] = splitmix64_at(seed, (u64)i * 4 + w);
+    kw[3] &= 0x1fffffffffffffffULL;                     // 253-bit
+    xyzz_dev<fp_d> acc; acc.set_inf();
+    for (int w = 3; w >= 0; w--) {
+        u64 word = kw[w];
+        for (int b = 63; b >= 0; b--) {
+            acc.dbl();
+            if ((word >> b) & 1) acc.madd(g, false);
+        }
+    }
+    acc.store(&out[i]);
+}
+
+SPPARK_FFI RustError sppark_g1_generate(void* out, size_t stride, size_t n, uint64_t seed)
+{
+    return guarded([&] {
+        if (n == 0) return;
+        (void)select_gpu(-1);
+        typedef xyzz_dev<fp_d> bucket_t;
+        bucket_t* d_pts;
+        HIP_OK(hipMalloc((void**)&d_pts, n * sizeof(bucket_t)));
+        hipLaunchKernelGGL(k_generate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_pts, (unsigned)n, seed);
+        std::vector<fp_h> c(4 * n);
+        hipError_t e = hipMemcpy(c.data(), d_pts, n * sizeof(bucket_t), hipMemcpyDeviceToHost);
+        (void)hipFree(d_pts);
+        HIP_OK(e);
+        // x = X/ZZ, y = Y/ZZZ with one shared inversion (Montgomery's trick)
+        std::vector<fp_h> pref(2 * n + 1);
+        pref[0] = fp_h::one();
+        for (size_t i = 0; i < n; i++) {
+            fp_h zzz = c[4*i+2], zz = c[4*i+3];
+            if (zzz.is_zero()) zzz = fp_h::one();
+            if (zz.is_zero())  zz  = fp_h::one();
+            pref[2*i+1] = pref[2*i] * zz;
+            pref[2*i+2] = pref[2*i+1] * zzz;
+        }
+        fp_h inv = pref[2*n].inverse();
+        const size_t fb = sizeof(fp_h);
+        std::vector<unsigned char> host(n * stride, 0);
+        for (size_t i = n; i--;) {
+            fp_h zzz = c[4*i+2], zz = c[4*i+3];
+            bool is_inf = zzz.is_zero() && zz.is_zero();
+            if (zzz.is_zero()) zzz = fp_h::one();
+            if (zz.is_zero())  zz  = fp_h::one();
+            fp_h izzz = inv * pref[2*i+1]; inv = inv * zzz;
+            fp_h izz  = inv * pref[2*i];   inv = inv * zz;
+            if (!is_inf) {
+                fp_h x = c[4*i] * izz, y = c[4*i+1] * izzz;
+                memcpy(&host[i * stride], &x, fb);
+                memcpy(&host[i * stride + fb], &y, fb);
+            } else if (stride > 2 * fb) {
+                host[i * stride + 2 * fb] = 1;
+            }
+        }
+        if (is_device_pointer(out)) HIP_OK(hipMemcpy(out, host.data(), host.size(), hipMemcpyHostToDevice));
+        else                        memcpy(out, host.data(), host.size());
+    });
+}

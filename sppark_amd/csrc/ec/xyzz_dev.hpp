@@ -1,0 +1,155 @@
+// Device-side point types for the MSM bucket pipeline (a4 = 0 curves).
+//
+//   affine_dev : X, Y  (+ in-register infinity flag).  Memory formats accepted:
+//                plain  X|Y, infinity = all-zero          (ec/affine_t.hpp:17-35)
+//                flagged X|Y|flag byte, stride = ffi size (ec/affine_t.hpp:64-122,
+//                the arkworks G1Affine layout poc/msm-cuda/src/lib.rs:52-58 passes)
+//   xyzz_dev   : X, Y, ZZZ, ZZ with x = X/ZZ, y = Y/ZZZ, infinity = (ZZZ = ZZ = 0);
+//                same member order and memory image as the reference's bucket
+//                type (ec/xyzz_t.hpp:17) so bucket dumps are interchangeable.
+//
+// Formulas: EFD madd-2008-s / mdbl-2008-s-1 (mixed) and add-2008-s /
+// dbl-2008-s-1 (full), the ones ec/xyzz_t.hpp:117-200,351-429 uses.  Control
+// flow is written for wave64: the generic-add path is the straight-line fast
+// path every lane normally takes; "same point" (doubling), "opposite point"
+// and "operand at infinity" are handled by wave-divergent side branches that
+// cost nothing unless some lane actually needs them.
+#pragma once
+#include "../ff/mont_dev.hpp"
+
+namespace sppark_amd {
+
+template<class F> struct affine_dev {
+    F X, Y;
+    bool inf;
+};
+
+// Load one affine point.  |stride| bytes between points; FLAGGED selects the
+// Affine_inf_t wire format.  Limbs are fetched as 8-byte words so that the
+// 104-byte arkworks stride (8-byte aligned only) is legal.
+template<class F, bool FLAGGED>
+SPPARK_DEVFN affine_dev<F> load_affine(const unsigned char* base, size_t idx, unsigned stride)
+{
+    constexpr int N = F::N;
+    const unsigned char* p = base + idx * (size_t)stride;
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+    affine_dev<F> a;
+    #pragma unroll
+    for (int i = 0; i < N / 2; i++) { uint2 w = q[i]; a.X.v[2*i] = w.x; a.X.v[2*i+1] = w.y; }
+    #pragma unroll
+    for (int i = 0; i < N / 2; i++) { uint2 w = q[N/2 + i]; a.Y.v[2*i] = w.x; a.Y.v[2*i+1] = w.y; }
+    if (FLAGGED) a.inf = (p[2 * N * 4] & 1) != 0;
+    else         a.inf = a.X.is_zero() & a.Y.is_zero();
+    return a;
+}
+
+template<class F> struct xyzz_dev {
+    F X, Y, ZZZ, ZZ;
+
+    SPPARK_DEVFN bool is_inf() const { return ZZZ.is_zero() & ZZ.is_zero(); }
+    SPPARK_DEVFN void set_inf()
+    {   X = F::zero(); Y = F::zero(); ZZZ = F::zero(); ZZ = F::zero();   }
+
+    // this = +/- affine point
+    SPPARK_DEVFN void set(const affine_dev<F>& p, bool negate)
+    {
+        if (p.inf) { set_inf(); return; }
+        X = p.X; Y = p.Y.cneg(negate); ZZZ = F::one(); ZZ = F::one();
+    }
+
+    // this += (negate ? -p : p), mixed addition 8M + 2S on the fast path.
+    SPPARK_DEVFN void madd(const affine_dev<F>& p, bool negate)
+    {
+        if (p.inf) return;
+        F y2 = p.Y.cneg(negate);
+        if (is_inf()) { X = p.X; Y = y2; ZZZ = F::one(); ZZ = F::one(); return; }
+
+        F Pd = p.X * ZZ - X;                    // U2 - X1
+        F Rd = y2 * ZZZ - Y;                    // S2 - Y1
+
+        if (!Pd.is_zero()) {                    // fast path
+            F PP  = Pd.sqr();
+            F PPP = Pd * PP;
+            F Q   = X * PP;
+            F X3  = Rd.sqr() - PPP - Q - Q;
+            F Y3  = Rd * (Q - X3) - Y * PPP;
+            ZZ  = ZZ * PP;
+            ZZZ = ZZZ * PPP;
+            X = X3; Y = Y3;
+        } else if (Rd.is_zero()) {              // same point: 2*p
+            F U = y2.dbl();
+            F V = U.sqr();
+            F W = U * V;
+            F S = p.X * V;
+            F M = p.X.sqr(); M = M + M + M;
+            F X3 = M.sqr() - S - S;
+            F Y3 = M * (S - X3) - W * y2;
+            X = X3; Y = Y3; ZZ = V; ZZZ = W;
+        } else {                                // p + (-p)
+            set_inf();
+        }
+    }
+
+    // this += q, full addition 12M + 2S on the fast path.
+    SPPARK_DEVFN void add(const xyzz_dev& q)
+    {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+
+        F U1 = X * q.ZZ;
+        F S1 = Y * q.ZZZ;
+        F Pd = q.X * ZZ - U1;
+        F Rd = q.Y * ZZZ - S1;
+
+        if (!Pd.is_zero()) {
+            F PP  = Pd.sqr();
+            F PPP = Pd * PP;
+            F Q   = U1 * PP;
+            F X3  = Rd.sqr() - PPP - Q - Q;
+            F Y3  = Rd * (Q - X3) - S1 * PPP;
+            ZZ  = ZZ * PP * q.ZZ;
+            ZZZ = ZZZ * PPP * q.ZZZ;
+            X = X3; Y = Y3;
+        } else if (Rd.is_zero()) {
+            dbl();
+        } else {
+            set_inf();
+        }
+    }
+
+    // this = 2*this (dbl-2008-s-1)
+    SPPARK_DEVFN void dbl()
+    {
+        if (is_inf()) return;
+        F U = Y.dbl();
+        F V = U.sqr();
+        F W = U * V;
+        F S = X * V;
+        F M = X.sqr(); M = M + M + M;
+        F X3 = M.sqr() - S - S;
+        F Y3 = M * (S - X3) - W * Y;
+        ZZ = ZZ * V; ZZZ = ZZZ * W;
+        X = X3; Y = Y3;
+    }
+
+    SPPARK_DEVFN void store(xyzz_dev* dst) const
+    {
+        constexpr int N = F::N;
+        uint4* d = reinterpret_cast<uint4*>(dst);
+        const u32* s = reinterpret_cast<const u32*>(this);
+        #pragma unroll
+        for (int i = 0; i < N; i++) d[i] = make_uint4(s[4*i], s[4*i+1], s[4*i+2], s[4*i+3]);
+    }
+    SPPARK_DEVFN static xyzz_dev load(const xyzz_dev* src)
+    {
+        constexpr int N = F::N;
+        xyzz_dev r;
+        const uint4* q = reinterpret_cast<const uint4*>(src);
+        u32* d = reinterpret_cast<u32*>(&r);
+        #pragma unroll
+        for (int i = 0; i < N; i++) { uint4 w = q[i]; d[4*i] = w.x; d[4*i+1] = w.y; d[4*i+2] = w.z; d[4*i+3] = w.w; }
+        return r;
+    }
+};
+
+} // namespace sppark_amd

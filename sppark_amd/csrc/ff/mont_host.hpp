@@ -1,0 +1,81 @@
+// Host-side Montgomery field (64-bit limbs, CIOS) used by the MSM driver for
+// the O(windows) tail of an MSM -- Horner over the per-window sums -- and by the
+// multi-GPU combine step.  The reference does this part on the host as well
+// (msm/pippenger.cuh:627-727 collect/integrate_row) with blst's field classes
+// (un-vendored); this is the product's own replacement for that dependency.
+// It is NOT a CPU fallback for the device kernels: nothing here can evaluate an
+// MSM or an NTT.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+
+namespace sppark_amd {
+
+template<class P> struct mont_host {
+    static constexpr int N = P::N64;
+    typedef unsigned __int128 u128;
+    uint64_t v[N];
+
+    static mont_host zero() { mont_host r; memset(r.v, 0, sizeof(r.v)); return r; }
+    static mont_host one()  { mont_host r; for (int i = 0; i < N; i++) r.v[i] = P::ONE64[i]; return r; }
+    bool is_zero() const { uint64_t a = 0; for (int i = 0; i < N; i++) a |= v[i]; return a == 0; }
+    friend bool operator==(const mont_host& a, const mont_host& b)
+    {   uint64_t x = 0; for (int i = 0; i < N; i++) x |= a.v[i] ^ b.v[i]; return x == 0;   }
+
+    static void cond_sub(uint64_t r[N], const uint64_t t[N], uint64_t top)
+    {
+        uint64_t u[N], bw = 0;
+        for (int i = 0; i < N; i++) {
+            u128 d = (u128)t[i] - P::MOD64[i] - bw;
+            u[i] = (uint64_t)d; bw = (uint64_t)(d >> 127);
+        }
+        bool ge = top | !bw;
+        for (int i = 0; i < N; i++) r[i] = ge ? u[i] : t[i];
+    }
+    friend mont_host operator+(const mont_host& a, const mont_host& b)
+    {
+        uint64_t t[N], c = 0; mont_host r;
+        for (int i = 0; i < N; i++) { u128 s = (u128)a.v[i] + b.v[i] + c; t[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        cond_sub(r.v, t, c);
+        return r;
+    }
+    friend mont_host operator-(const mont_host& a, const mont_host& b)
+    {
+        mont_host r; uint64_t bw = 0;
+        for (int i = 0; i < N; i++) { u128 d = (u128)a.v[i] - b.v[i] - bw; r.v[i] = (uint64_t)d; bw = (uint64_t)(d >> 127); }
+        uint64_t mask = 0 - bw, c = 0;
+        for (int i = 0; i < N; i++) { u128 s = (u128)r.v[i] + (P::MOD64[i] & mask) + c; r.v[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+        return r;
+    }
+    // coarsely integrated operand scanning
+    friend mont_host operator*(const mont_host& a, const mont_host& b)
+    {
+        uint64_t t[N + 2] = {0};
+        for (int i = 0; i < N; i++) {
+            uint64_t c = 0;
+            for (int j = 0; j < N; j++) { u128 s = (u128)a.v[j] * b.v[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+            u128 s = (u128)t[N] + c; t[N] = (uint64_t)s; t[N + 1] = (uint64_t)(s >> 64);
+            uint64_t m = t[0] * P::M0_64;
+            c = (uint64_t)(((u128)m * P::MOD64[0] + t[0]) >> 64);
+            for (int j = 1; j < N; j++) { u128 q = (u128)m * P::MOD64[j] + t[j] + c; t[j - 1] = (uint64_t)q; c = (uint64_t)(q >> 64); }
+            s = (u128)t[N] + c; t[N - 1] = (uint64_t)s; t[N] = t[N + 1] + (uint64_t)(s >> 64);
+        }
+        mont_host r; cond_sub(r.v, t, t[N]);
+        return r;
+    }
+    mont_host sqr() const { return *this * *this; }
+    mont_host dbl() const { return *this + *this; }
+    mont_host neg() const { return is_zero() ? *this : zero() - *this; }
+
+    mont_host inverse() const               // a^(p-2), 1/0 = 0
+    {
+        uint64_t e[N], bw = 2;
+        for (int i = 0; i < N; i++) { u128 d = (u128)P::MOD64[i] - bw; e[i] = (uint64_t)d; bw = (uint64_t)(d >> 127); }
+        mont_host r = one(), b = *this;
+        for (int i = 0; i < 64 * N; i++) { if ((e[i / 64] >> (i % 64)) & 1) r = r * b; b = b.sqr(); }
+        return r;
+    }
+};
+
+} // namespace sppark_amd

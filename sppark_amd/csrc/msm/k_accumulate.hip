@@ -1,0 +1,10 @@
+// Explicit instantiation of the hot MSM kernel (own translation unit so that
+// the library builds in parallel; see msm_kernels.hpp for the kernel itself).
+#include "curve_select.hpp"
+#include "msm_kernels.hpp"
+namespace sppark_amd {
+template __global__ void k_accumulate<fp_d, false>(bucket_d*, u32*, bucket_d*, const unsigned char*, unsigned,
+                                                   const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_accumulate<fp_d, true>(bucket_d*, u32*, bucket_d*, const unsigned char*, unsigned,
+                                                  const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+}

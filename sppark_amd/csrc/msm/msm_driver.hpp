@@ -1,0 +1,309 @@
+// Host driver of the MI355X MSM pipeline: plays the role of the reference's
+// msm_t (msm/pippenger.cuh:325-728) -- window choice, one device blob, kernel
+// sequence, error mapping -- re-planned for a 288 GB / 256-CU part:
+//
+//  * no batching: the whole point/scalar vector is resident (the reference
+//    streams 2^24-point strides through a 3-stream pipeline, :454-557, to stay
+//    inside a few GB);
+//  * no cooperative launches or device-global work counters (:157-223): kernel
+//    boundaries are the only grid-wide synchronisation;
+//  * the host part is O(windows): it receives one XYZZ sum per window and runs
+//    the Horner recombination (the reference integrates 256 partial sums per
+//    window on a host thread pool, :627-727).
+//
+// Inputs may be host or device pointers (cf. is_device_ptr, util/gpu_t.cuh:385-395,
+// and the preloaded-points constructor :351-388): device pointers are used in
+// place, host pointers are staged with one H2D copy each.
+#pragma once
+#include "msm_kernels.hpp"
+#include "../ec/jacobian_host.hpp"
+#include "../util/runtime.hpp"
+#include <algorithm>
+#include <vector>
+
+namespace sppark_amd {
+
+struct msm_plan {
+    unsigned n, wbits, nwins, NB;       // NB = 2^(wbits-1) buckets per window
+    unsigned L, chunks_per_win;         // accumulate run length
+    unsigned nslabs, slab_sz;           // hist/scatter point slabs
+    unsigned F;                         // reduce_runs fan-in
+    unsigned K;                         // bucket-reduction chunk
+};
+
+struct msm_tunables {                   // 0 = automatic
+    unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0;
+};
+
+static inline unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
+
+static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm_tunables& t)
+{
+    msm_plan p;
+    p.n = (unsigned)npoints;
+    unsigned lg = lg2_floor(npoints ? npoints : 1);
+    // window: LDS must hold 2^(wbits-1) u32 counters (<= 128 KB of the 160 KB)
+    p.wbits = t.wbits ? t.wbits : std::min(16u, std::max(6u, lg > 4 ? lg - 4 : 0u));
+    p.wbits = std::min(16u, std::max(2u, p.wbits));
+    p.nwins = (scalar_bits - 1) / p.wbits + 1;      // as pippenger.cuh:365
+    p.NB = 1u << (p.wbits - 1);
+    size_t entries = (size_t)p.n * p.nwins;
+    unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(64, std::max<size_t>(4, entries / 262144));
+    p.L = L;
+    p.chunks_per_win = (p.n + L - 1) / L;
+    p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
+    p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
+    p.F = t.F ? t.F : 32;
+    p.K = t.K ? t.K : 8;
+    p.K = std::min(p.K, p.NB);
+    return p;
+}
+
+template<class FPp, class FRp>
+class msm_t {
+public:
+    typedef mont_dev<FPp> fp_d;
+    typedef mont_dev<FRp> fr_d;
+    typedef mont_host<FPp> fp_h;
+    typedef xyzz_dev<fp_d> bucket_t;
+    typedef jacobian_host<fp_h> point_t;
+    static constexpr size_t FP_BYTES = sizeof(fp_d);
+    static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
+
+private:
+    const gpu_info* gpu;
+    hipStream_t stream;
+    bool own_stream;
+    unsigned char* blob = nullptr;
+    size_t blob_sz = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_ms[3] = {0, 0, 0};       // [0] digits+sort, [1] accumulate, [2] whole device part
+    bool timing = false;
+
+    struct layout {
+        size_t points, scalars, digits, sorted, H, tot, off, buckets;
+        size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, total;
+    };
+
+    static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+    layout make_layout(const msm_plan& p, size_t pts_bytes, size_t sc_bytes) const
+    {
+        layout l; size_t o = 0;
+        auto take = [&](size_t sz) { size_t r = o; o += align_up(sz); return r; };
+        l.points  = take(pts_bytes);
+        l.scalars = take(sc_bytes);
+        l.digits  = take((size_t)p.nwins * p.n * 4);
+        l.sorted  = take((size_t)p.nwins * p.n * 4);
+        l.H       = take((size_t)p.nwins * p.nslabs * p.NB * 4);
+        l.tot     = take((size_t)p.nwins * p.NB * 4);
+        l.off     = take((size_t)p.nwins * (p.NB + 1) * 4);
+        l.buckets = take((size_t)p.nwins * p.NB * sizeof(bucket_t));
+        size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win;
+        size_t nrecB = 2 * ((nrecA + p.F - 1) / p.F);
+        l.keyA = take(nrecA * 4); l.ptA = take(nrecA * sizeof(bucket_t));
+        l.keyB = take(nrecB * 4); l.ptB = take(nrecB * sizeof(bucket_t));
+        size_t n1 = (size_t)p.nwins * (p.NB / p.K);
+        size_t n2 = n1;
+        l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
+        l.A2 = take(n2 * sizeof(bucket_t)); l.W2 = take(n2 * sizeof(bucket_t));
+        l.total = o;
+        return l;
+    }
+
+    void reserve(size_t sz)
+    {
+        if (sz <= blob_sz) return;
+        if (blob) { HIP_OK(hipFree(blob)); blob = nullptr; blob_sz = 0; }
+        HIP_OK(hipMalloc((void**)&blob, sz));
+        blob_sz = sz;
+    }
+
+public:
+    msm_tunables tune;
+
+    explicit msm_t(int device_id = -1, hipStream_t s = nullptr)
+        : gpu(&select_gpu(device_id)), stream(s), own_stream(false)
+    {
+        if (stream == nullptr) {
+            HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            own_stream = true;
+        }
+    }
+    ~msm_t()
+    {
+        (void)hipStreamSynchronize(stream);
+        if (blob) (void)hipFree(blob);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (own_stream) (void)hipStreamDestroy(stream);
+    }
+    msm_t(const msm_t&) = delete;
+    msm_t& operator=(const msm_t&) = delete;
+
+    void set_stream(hipStream_t s)
+    {
+        if (own_stream) { (void)hipStreamDestroy(stream); own_stream = false; }
+        stream = s;
+    }
+    void enable_timing(bool on)
+    {
+        timing = on;
+        if (on) for (auto& e : ev) if (!e) HIP_OK(hipEventCreate(&e));
+    }
+    float kernel_ms(int which) const { return which >= 0 && which < 3 ? last_ms[which] : -1.f; }
+    size_t scratch_bytes() const { return blob_sz; }
+
+    // Size the blob for |npoints| ahead of time (so a timed invoke does not allocate).
+    void reserve_for(size_t npoints, size_t ffi_affine_sz, bool host_points, bool host_scalars)
+    {
+        msm_plan p = make_plan(npoints, FRp::NBITS, tune);
+        layout l = make_layout(p, host_points ? npoints * ffi_affine_sz : 0,
+                                  host_scalars ? npoints * SCALAR_BYTES : 0);
+        reserve(l.total);
+    }
+
+    // out: Jacobian X|Y|Z (Montgomery).  points: stride ffi_affine_sz, flagged
+    // format iff ffi_affine_sz > 2*FP_BYTES.  scalars: SCALAR_BYTES each.
+    void invoke(point_t& out, const void* points, size_t npoints, const void* scalars,
+                bool mont, size_t ffi_affine_sz)
+    {
+        out.set_inf();
+        if (npoints == 0) return;
+        if (npoints > (1u << 31)) HIP_OK(hipErrorInvalidValue);
+        HIP_OK(hipSetDevice(gpu->hip_id));
+
+        const bool flagged = ffi_affine_sz > 2 * FP_BYTES;
+        const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);
+        const msm_plan p = make_plan(npoints, FRp::NBITS, tune);
+        const layout l = make_layout(p, pts_dev ? 0 : npoints * ffi_affine_sz,
+                                        sc_dev ? 0 : npoints * SCALAR_BYTES);
+        reserve(l.total);
+
+        const unsigned char* d_points = (const unsigned char*)points;
+        const u32* d_scalars = (const u32*)scalars;
+        if (!pts_dev) {
+            HIP_OK(hipMemcpyAsync(blob + l.points, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, stream));
+            d_points = blob + l.points;
+        }
+        if (!sc_dev) {
+            HIP_OK(hipMemcpyAsync(blob + l.scalars, scalars, npoints * SCALAR_BYTES, hipMemcpyHostToDevice, stream));
+            d_scalars = (const u32*)(blob + l.scalars);
+        }
+
+        u32* digits = (u32*)(blob + l.digits);
+        u32* sorted = (u32*)(blob + l.sorted);
+        u32* H = (u32*)(blob + l.H);
+        u32* tot = (u32*)(blob + l.tot);
+        u32* off = (u32*)(blob + l.off);
+        bucket_t* buckets = (bucket_t*)(blob + l.buckets);
+
+        if (timing) HIP_OK(hipEventRecord(ev[0], stream));
+
+        // ---- digits + counting sort -------------------------------------
+        {
+            unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, stream,
+                               digits, d_scalars, p.n, p.nwins, p.wbits, (int)mont);
+            HIP_OK(hipGetLastError());
+        }
+        {
+            size_t lds = (size_t)p.NB * 4;
+            if (lds > 65536) {
+                HIP_OK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIP_OK(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            hipLaunchKernelGGL(k_hist, dim3(p.nslabs, p.nwins), dim3(1024), lds, stream,
+                               H, digits, p.n, p.nslabs, p.slab_sz, p.NB);
+            HIP_OK(hipGetLastError());
+            size_t nb_total = (size_t)p.nwins * p.NB;
+            hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((nb_total + 255) / 256)), dim3(256), 0, stream,
+                               H, tot, p.nslabs, p.NB, p.nwins);
+            HIP_OK(hipGetLastError());
+            hipLaunchKernelGGL(k_scan_buckets, dim3(p.nwins), dim3(1024), 0, stream, off, tot, p.NB);
+            HIP_OK(hipGetLastError());
+            hipLaunchKernelGGL(k_scatter, dim3(p.nslabs, p.nwins), dim3(1024), lds, stream,
+                               sorted, digits, H, off, p.n, p.nslabs, p.slab_sz, p.NB);
+            HIP_OK(hipGetLastError());
+        }
+        HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
+
+        if (timing) HIP_OK(hipEventRecord(ev[1], stream));
+
+        // ---- bucket accumulation: level 0 + segmented tree ------------------
+        u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
+        u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
+        {
+            dim3 grid((p.chunks_per_win + 255) / 256, p.nwins);
+            if (flagged)
+                hipLaunchKernelGGL((k_accumulate<fp_d, true>), grid, dim3(256), 0, stream,
+                                   buckets, keyA, ptA, d_points, (unsigned)ffi_affine_sz, sorted, off,
+                                   p.n, p.NB, p.L, p.chunks_per_win);
+            else
+                hipLaunchKernelGGL((k_accumulate<fp_d, false>), grid, dim3(256), 0, stream,
+                                   buckets, keyA, ptA, d_points, (unsigned)ffi_affine_sz, sorted, off,
+                                   p.n, p.NB, p.L, p.chunks_per_win);
+            HIP_OK(hipGetLastError());
+        }
+        if (timing) HIP_OK(hipEventRecord(ev[2], stream));
+        {
+            size_t nrec = (size_t)2 * p.nwins * p.chunks_per_win;
+            u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
+            for (;;) {
+                unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
+                int last = nthreads == 1;
+                hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
+                                   buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last);
+                HIP_OK(hipGetLastError());
+                if (last) break;
+                nrec = (size_t)2 * nthreads;
+                std::swap(ik, ok); std::swap(ip, op);
+            }
+        }
+
+        // ---- per-window weighted bucket sums --------------------------------
+        bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
+        bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
+        bucket_t* result;
+        {
+            unsigned nitems = p.NB / p.K;
+            size_t nthr = (size_t)p.nwins * nitems;
+            hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                               A1, W1, buckets, p.NB, p.K, p.nwins);
+            HIP_OK(hipGetLastError());
+            unsigned lgG = lg2_floor(p.K);
+            bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
+            while (nitems > 1) {
+                unsigned K = std::min(p.K, nitems);
+                nthr = (size_t)p.nwins * (nitems / K);
+                hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                   oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                HIP_OK(hipGetLastError());
+                nitems /= K; lgG += lg2_floor(K);
+                std::swap(ia, oa); std::swap(iw, ow);
+            }
+            result = iw;
+        }
+        if (timing) HIP_OK(hipEventRecord(ev[3], stream));
+
+        // ---- device -> host: one XYZZ per window; Horner on the host --------
+        std::vector<bucket_t> sums(p.nwins);
+        HIP_OK(hipMemcpyAsync(sums.data(), result, p.nwins * sizeof(bucket_t), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+
+        if (timing) {
+            HIP_OK(hipEventElapsedTime(&last_ms[0], ev[0], ev[1]));
+            HIP_OK(hipEventElapsedTime(&last_ms[1], ev[1], ev[2]));
+            HIP_OK(hipEventElapsedTime(&last_ms[2], ev[0], ev[3]));
+        }
+
+        for (unsigned w = p.nwins; w--;) {
+            fp_h c[4];
+            memcpy(c, &sums[w], sizeof(c));
+            point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
+            out.add(s);
+            if (w) for (unsigned k = 0; k < p.wbits; k++) out.dbl();
+        }
+    }
+};
+
+} // namespace sppark_amd

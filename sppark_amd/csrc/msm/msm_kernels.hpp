@@ -1,0 +1,284 @@
+// MI355X Pippenger MSM kernels (bucket method with signed windows).
+//
+// Same mathematical pipeline as the reference's GPU path
+// (msm/pippenger.cuh:72-296 breakdown/accumulate/integrate, msm/sort.cuh,
+// msm/batch_addition.cuh) but laid out for CDNA4 rather than translated:
+//
+//   breakdown     scalars -> signed digits, one u32 per (window, point)
+//   hist          per (window, point-slab) bucket histogram built ENTIRELY in
+//                 LDS (2^(c-1) counters = 128 KB at c = 16 fit the 160 KB LDS),
+//                 stored with plain coalesced writes -- no global atomics
+//   scan_*        slab-exclusive and bucket-exclusive prefix sums
+//   scatter       counting-sort scatter with LDS cursors (ds_add_rtn), output
+//                 = point indices grouped by bucket, sign in bit 31
+//   accumulate    the hot kernel: every lane walks a FIXED-length run of the
+//                 grouped index list (so all 64 lanes of a wave do the same
+//                 number of mixed additions no matter how skewed the scalars
+//                 are), gathers the affine points, keeps the running XYZZ sum
+//                 in registers and flushes at bucket boundaries
+//   reduce_runs   the same walk over the (key, partial sum) records the
+//                 previous level left at its chunk boundaries, until one
+//                 record is left: a segmented tree reduction whose cost is
+//                 independent of the bucket-size distribution
+//   bucket_*      per-window weighted bucket sum  sum_b (b+1)*B_b  by chunked
+//                 running sums, log-depth
+//
+// The reference instead assigns one thread per bucket with dynamic work
+// stealing through a device-global atomic counter and a cooperative grid sync
+// (pippenger.cuh:157-223), sized for 32-lane warps and <= 100 SMs (sort.cuh:312).
+#pragma once
+#include "../ec/xyzz_dev.hpp"
+
+namespace sppark_amd {
+
+static constexpr u32 KEY_NONE = 0xffffffffu;
+
+// ---------------------------------------------------------------------------
+// Every kernel is a thin __global__ wrapper around a per-work-item body
+// (SPPARK_DEVFN = __device__ in the shipped build).  The bodies are also what
+// the host-emulation test harness (tests/emu/, -DSPPARK_HOST_EMULATION) calls.
+// ---------------------------------------------------------------------------
+
+// Digit recoding (any recoding with the same sum is valid; only the group
+// element is observable -- SURVEY Appendix A.6):
+//   s > (r-1)/2  ->  s = r - s, all signs flipped   (cf. pippenger.cuh:96-99)
+//   d_w = bits [w*c, w*c+c) + carry;  d_w > 2^(c-1)  ->  d_w -= 2^c, carry = 1
+// so |d_w| <= 2^(c-1) and bucket index = |d_w| - 1  (cf. sort.cuh:92).
+// Output word: bit31 = sign, low bits = |digit|, 0 = no contribution.
+// |limb(k)| returns 32-bit limb k of the reduced magnitude (k <= N, limb N = 0).
+template<class LimbFn>
+SPPARK_DEVFN void recode_digits(u32* digits, size_t n, size_t i, LimbFn limb, bool flip,
+                                unsigned nwins, unsigned wbits)
+{
+    const u32 half = 1u << (wbits - 1), full = 1u << wbits, mask = full - 1;
+    u32 carry = 0;
+    for (unsigned w = 0, bit = 0; w < nwins; w++, bit += wbits) {
+        const unsigned li = bit >> 5, sh = bit & 31;
+        u64 two = limb(li) | ((u64)limb(li + 1) << 32);
+        u32 d = ((u32)(two >> sh) & mask) + carry;
+        bool minus = d > half;
+        carry = minus;
+        d = minus ? full - d : d;
+        digits[(size_t)w * n + i] = d ? (d | ((u32)(minus != flip) << 31)) : 0;
+    }
+}
+
+// load scalar i, leave Montgomery form if asked, fold into [0, (r-1)/2]
+template<class FR>
+SPPARK_DEVFN FR load_scalar_abs(const u32* scalars, size_t i, int mont, bool& flip)
+{
+    constexpr int N = FR::N;
+    FR s;
+    const uint4* src = reinterpret_cast<const uint4*>(scalars + i * N);
+    #pragma unroll
+    for (int k = 0; k < N / 4; k++) {
+        uint4 q = src[k];
+        s.v[4*k] = q.x; s.v[4*k+1] = q.y; s.v[4*k+2] = q.z; s.v[4*k+3] = q.w;
+    }
+    if (mont) s = s.from();
+    FR neg = FR::modulus_minus(s);                      // r - s
+    u32 bw = 0;
+    #pragma unroll
+    for (int k = 0; k < N; k++) (void)__builtin_subc(neg.v[k], s.v[k], bw, &bw);
+    flip = bw != 0;                                     // r - s < s  <=>  s > (r-1)/2
+    return FR::select(flip, neg, s);
+}
+
+template<class FR>
+__global__ __launch_bounds__(256)
+void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
+                 unsigned n, unsigned nwins, unsigned wbits, int mont)
+{
+    constexpr int N = FR::N;
+    __shared__ u32 limbs[N + 2][256];                   // transposed: dynamic limb index without scratch
+    const unsigned tid = threadIdx.x;
+    for (unsigned i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        bool flip;
+        FR s = load_scalar_abs<FR>(scalars, i, mont, flip);
+        #pragma unroll
+        for (int k = 0; k < N; k++) limbs[k][tid] = s.v[k];
+        limbs[N][tid] = 0; limbs[N + 1][tid] = 0;
+        recode_digits(digits, n, i, [&](unsigned k) { return limbs[k][tid]; }, flip, nwins, wbits);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// accumulate (level 0).  Work item (chunk, window) owns entries
+// [chunk*L, chunk*L + L) of window w's grouped list.  Runs that touch the
+// chunk's ends are handed to the next level as (key, sum) records (slot 0 =
+// first run, slot 1 = last run); runs strictly inside are complete buckets and
+// are stored straight into buckets[key].
+// ---------------------------------------------------------------------------
+template<class FP, bool FLAGGED>
+SPPARK_DEVFN void accumulate_chunk(xyzz_dev<FP>* buckets, u32* rec_key, xyzz_dev<FP>* rec_pt,
+                                   const unsigned char* points, unsigned stride,
+                                   const u32* sorted, const u32* off,
+                                   unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win,
+                                   unsigned chunk, unsigned w)
+{
+    if (chunk >= chunks_per_win) return;
+    const size_t rec0 = ((size_t)w * chunks_per_win + chunk) * 2;
+    const u32* o = off + (size_t)w * (NB + 1);
+    const unsigned total = o[NB];
+    unsigned p = chunk * L;
+    if (p >= total) { rec_key[rec0] = KEY_NONE; rec_key[rec0 + 1] = KEY_NONE; return; }
+    const unsigned end = total < p + L ? total : p + L;
+
+    // bucket holding position p: o[b] <= p < o[b+1]
+    unsigned lo = 0, hi = NB;                       // invariant o[lo] <= p < o[hi]
+    while (hi - lo > 1) {
+        unsigned mid = (lo + hi) >> 1;
+        if (o[mid] <= p) lo = mid; else hi = mid;
+    }
+    unsigned b = lo, next = o[b + 1];
+
+    const u32* src = sorted + (size_t)w * n;
+    xyzz_dev<FP> acc;
+    bool first_run = true;
+    u32 slot0_key = KEY_NONE;
+
+    u32 e = src[p];
+    affine_dev<FP> pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);
+    acc.set(pt, e >> 31);
+    for (p++; p < end; p++) {
+        e = src[p];
+        pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);
+        if (p == next) {                            // bucket boundary: flush
+            const u32 key = w * NB + b;
+            if (first_run) { acc.store(&rec_pt[rec0]); slot0_key = key; first_run = false; }
+            else           acc.store(&buckets[key]);
+            do { b++; next = o[b + 1]; } while (p == next);
+            acc.set(pt, e >> 31);
+        } else {
+            acc.madd(pt, e >> 31);
+        }
+    }
+    const u32 key = w * NB + b;
+    if (first_run) { acc.store(&rec_pt[rec0]); rec_key[rec0] = key; rec_key[rec0 + 1] = KEY_NONE; }
+    else           { acc.store(&rec_pt[rec0 + 1]); rec_key[rec0] = slot0_key; rec_key[rec0 + 1] = key; }
+}
+
+template<class FP, bool FLAGGED>
+__global__ __launch_bounds__(256)
+void k_accumulate(xyzz_dev<FP>* __restrict__ buckets,
+                  u32* __restrict__ rec_key, xyzz_dev<FP>* __restrict__ rec_pt,
+                  const unsigned char* __restrict__ points, unsigned stride,
+                  const u32* __restrict__ sorted, const u32* __restrict__ off,
+                  unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win)
+{
+    accumulate_chunk<FP, FLAGGED>(buckets, rec_key, rec_pt, points, stride, sorted, off, n, NB, L,
+                                  chunks_per_win, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------
+// reduce_runs (levels >= 1): same walk over F consecutive records.
+// |last| = this is the final level (single work item): every run is complete.
+// ---------------------------------------------------------------------------
+template<class FP>
+SPPARK_DEVFN void reduce_runs_chunk(xyzz_dev<FP>* buckets, u32* out_key, xyzz_dev<FP>* out_pt,
+                                    const u32* in_key, const xyzz_dev<FP>* in_pt,
+                                    unsigned nrec, unsigned F, unsigned nthreads, int last, unsigned t)
+{
+    if (t >= nthreads) return;
+    const unsigned lo = t * F, hi = nrec < lo + F ? nrec : lo + F;
+    const size_t rec0 = (size_t)t * 2;
+
+    xyzz_dev<FP> acc;
+    u32 cur = KEY_NONE, slot0_key = KEY_NONE;
+    bool first_run = true;
+
+    for (unsigned r = lo; r < hi; r++) {
+        const u32 k = in_key[r];
+        if (k == KEY_NONE) continue;
+        if (k == cur) {
+            acc.add(xyzz_dev<FP>::load(&in_pt[r]));
+        } else {
+            if (cur != KEY_NONE) {
+                if (first_run && !last) { acc.store(&out_pt[rec0]); slot0_key = cur; }
+                else                    acc.store(&buckets[cur]);
+                first_run = false;
+            }
+            cur = k;
+            acc = xyzz_dev<FP>::load(&in_pt[r]);
+        }
+    }
+    if (last) {
+        if (cur != KEY_NONE) acc.store(&buckets[cur]);
+        return;
+    }
+    if (cur == KEY_NONE)      { out_key[rec0] = KEY_NONE; out_key[rec0 + 1] = KEY_NONE; }
+    else if (first_run)       { acc.store(&out_pt[rec0]); out_key[rec0] = cur; out_key[rec0 + 1] = KEY_NONE; }
+    else                      { acc.store(&out_pt[rec0 + 1]); out_key[rec0] = slot0_key; out_key[rec0 + 1] = cur; }
+}
+
+template<class FP>
+__global__ __launch_bounds__(256)
+void k_reduce_runs(xyzz_dev<FP>* __restrict__ buckets,
+                   u32* __restrict__ out_key, xyzz_dev<FP>* __restrict__ out_pt,
+                   const u32* __restrict__ in_key, const xyzz_dev<FP>* __restrict__ in_pt,
+                   unsigned nrec, unsigned F, unsigned nthreads, int last)
+{
+    reduce_runs_chunk<FP>(buckets, out_key, out_pt, in_key, in_pt, nrec, F, nthreads, last,
+                          blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// bucket reduction, level 1: work item = (window, chunk of K buckets)
+//   A[u]  = sum_j B[uK+j]          Wt[u] = sum_j (j+1) * B[uK+j]
+// (running-sum trick of msm/pippenger.hpp:40-56 / pippenger.cuh:225-296)
+// ---------------------------------------------------------------------------
+template<class FP>
+SPPARK_DEVFN void bucket_level1_item(xyzz_dev<FP>* A, xyzz_dev<FP>* Wt, const xyzz_dev<FP>* buckets,
+                                     unsigned NB, unsigned K, unsigned nwins, size_t id)
+{
+    const unsigned nchunks = NB / K;
+    if (id >= (size_t)nwins * nchunks) return;
+    const unsigned w = id / nchunks, u = id % nchunks;
+    const xyzz_dev<FP>* row = buckets + (size_t)w * NB + (size_t)u * K;
+    xyzz_dev<FP> acc = xyzz_dev<FP>::load(&row[K - 1]), ret = acc;
+    for (unsigned j = K - 1; j--;) {
+        acc.add(xyzz_dev<FP>::load(&row[j]));
+        ret.add(acc);
+    }
+    acc.store(&A[id]); ret.store(&Wt[id]);
+}
+
+template<class FP>
+__global__ __launch_bounds__(256)
+void k_bucket_level1(xyzz_dev<FP>* __restrict__ A, xyzz_dev<FP>* __restrict__ Wt,
+                     const xyzz_dev<FP>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins)
+{   bucket_level1_item<FP>(A, Wt, buckets, NB, K, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+
+// level >= 2: chunk u of K items (A_j, Wt_j), each item spanning 2^lgG buckets:
+//   A'[u] = sum_j A_j      Wt'[u] = sum_j Wt_j + 2^lgG * sum_j j*A_j
+template<class FP>
+SPPARK_DEVFN void bucket_levelN_item(xyzz_dev<FP>* A2, xyzz_dev<FP>* Wt2,
+                                     const xyzz_dev<FP>* A1, const xyzz_dev<FP>* Wt1,
+                                     unsigned nitems, unsigned K, unsigned lgG, unsigned nwins, size_t id)
+{
+    const unsigned nchunks = nitems / K;
+    if (id >= (size_t)nwins * nchunks) return;
+    const unsigned w = id / nchunks, u = id % nchunks;
+    const size_t base = (size_t)w * nitems + (size_t)u * K;
+    xyzz_dev<FP> acc, r, sw;
+    acc.set_inf(); r.set_inf();
+    sw = xyzz_dev<FP>::load(&Wt1[base]);
+    for (unsigned j = K - 1; j >= 1; j--) {
+        acc.add(xyzz_dev<FP>::load(&A1[base + j]));
+        r.add(acc);
+        sw.add(xyzz_dev<FP>::load(&Wt1[base + j]));
+    }
+    acc.add(xyzz_dev<FP>::load(&A1[base]));
+    for (unsigned k = 0; k < lgG; k++) r.dbl();
+    sw.add(r);
+    acc.store(&A2[id]); sw.store(&Wt2[id]);
+}
+
+template<class FP>
+__global__ __launch_bounds__(256)
+void k_bucket_levelN(xyzz_dev<FP>* __restrict__ A2, xyzz_dev<FP>* __restrict__ Wt2,
+                     const xyzz_dev<FP>* __restrict__ A1, const xyzz_dev<FP>* __restrict__ Wt1,
+                     unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)
+{   bucket_levelN_item<FP>(A2, Wt2, A1, Wt1, nitems, K, lgG, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+
+} // namespace sppark_amd

@@ -1,0 +1,177 @@
+// HOST EMULATION TEST HARNESS (tests only; never linked into the product).
+//
+// Compiles the product's per-work-item kernel bodies (sppark_amd/csrc/msm/
+// msm_kernels.hpp, ec/xyzz_dev.hpp, ff/mont_dev.hpp) for the host CPU with
+// -DSPPARK_HOST_EMULATION and runs the MSM pipeline by looping over the work
+// items the GPU grid would cover, in the order msm_driver.hpp launches them.
+// Purpose: exercise digit recoding, chunk walking / flush logic, record levels
+// and the bucket-sum levels in the GPU-less build container before spending
+// GPU minutes.  Results are compared with the oracle by tests/test_emulation.py.
+#define SPPARK_HOST_EMULATION 1
+#include "../../sppark_amd/csrc/msm/curve_select.hpp"
+#include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
+#include "../../sppark_amd/csrc/ec/jacobian_host.hpp"
+#include <vector>
+#include <algorithm>
+#include <cstring>
+
+using namespace sppark_amd;
+
+// plan/tunables only (no HIP runtime needed)
+struct msm_plan { unsigned n, wbits, nwins, NB, L, chunks_per_win, nslabs, slab_sz, F, K; };
+
+static unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
+
+extern "C" int emu_field_op(int field, int op, void* out, const void* a, const void* b, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (field == 0) {
+            fp_d x, y, r; memcpy(&x, (const char*)a + i * sizeof(x), sizeof(x)); memcpy(&y, (const char*)b + i * sizeof(y), sizeof(y));
+            switch (op) { case 0: r = x + y; break; case 1: r = x - y; break; case 2: r = x * y; break; case 3: r = x.sqr(); break;
+                          case 4: r = x.neg(); break; case 5: r = x.from(); break; case 6: r = x.to(); break; default: r = x.dbl(); }
+            memcpy((char*)out + i * sizeof(r), &r, sizeof(r));
+        } else {
+            fr_d x, y, r; memcpy(&x, (const char*)a + i * sizeof(x), sizeof(x)); memcpy(&y, (const char*)b + i * sizeof(y), sizeof(y));
+            switch (op) { case 0: r = x + y; break; case 1: r = x - y; break; case 2: r = x * y; break; case 3: r = x.sqr(); break;
+                          case 4: r = x.neg(); break; case 5: r = x.from(); break; case 6: r = x.to(); break; default: r = x.dbl(); }
+            memcpy((char*)out + i * sizeof(r), &r, sizeof(r));
+        }
+    }
+    return 0;
+}
+
+// op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
+extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size_t n)
+{
+    const bucket_d* pa = (const bucket_d*)a; bucket_d* po = (bucket_d*)out;
+    for (size_t i = 0; i < n; i++) {
+        bucket_d p = bucket_d::load(&pa[i]);
+        if (op == 0) p.add(bucket_d::load((const bucket_d*)b + i));
+        else if (op == 3) p.dbl();
+        else { affine_dev<fp_d> q = load_affine<fp_d, false>((const unsigned char*)b, i, 2 * sizeof(fp_d)); p.madd(q, op == 2); }
+        p.store(&po[i]);
+    }
+    return 0;
+}
+
+extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
+                       const unsigned char* scalars, int mont,
+                       unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs)
+{
+    typedef mont_host<curve_p::fp> fp_h;
+    typedef jacobian_host<fp_h> point_t;
+    point_t out; out.set_inf();
+    if (npoints == 0) { memcpy(out_jac, &out, sizeof(out)); return 0; }
+
+    msm_plan p;
+    p.n = (unsigned)npoints;
+    unsigned lg = lg2_floor(npoints);
+    p.wbits = wbits ? wbits : std::min(16u, std::max(6u, lg > 4 ? lg - 4 : 0u));
+    p.nwins = (curve_p::fr::NBITS - 1) / p.wbits + 1;
+    p.NB = 1u << (p.wbits - 1);
+    size_t entries = (size_t)p.n * p.nwins;
+    p.L = L ? L : (unsigned)std::min<size_t>(64, std::max<size_t>(4, entries / 262144));
+    p.chunks_per_win = (p.n + p.L - 1) / p.L;
+    p.nslabs = nslabs ? nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
+    p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
+    p.F = F ? F : 32;
+    p.K = std::min(K ? K : 8u, p.NB);
+    const bool flagged = stride > 2 * sizeof(fp_d);
+
+    // ---- breakdown (k_breakdown) ----
+    std::vector<u32> digits((size_t)p.nwins * p.n), sorted((size_t)p.nwins * p.n);
+    std::vector<u32> sc32((size_t)p.n * fr_d::N + 8);
+    memcpy(sc32.data(), scalars, (size_t)p.n * sizeof(fr_d));
+    for (unsigned i = 0; i < p.n; i++) {
+        bool flip;
+        fr_d s = load_scalar_abs<fr_d>(sc32.data(), i, mont, flip);
+        u32 limbs[fr_d::N + 2] = {0};
+        for (int k = 0; k < fr_d::N; k++) limbs[k] = s.v[k];
+        recode_digits(digits.data(), p.n, i, [&](unsigned k) { return limbs[k]; }, flip, p.nwins, p.wbits);
+    }
+
+    // ---- hist / scan / scatter (translation of msm_sort_kernels.hpp) ----
+    std::vector<u32> H((size_t)p.nwins * p.nslabs * p.NB, 0), tot((size_t)p.nwins * p.NB), off((size_t)p.nwins * (p.NB + 1));
+    for (unsigned w = 0; w < p.nwins; w++)
+        for (unsigned slab = 0; slab < p.nslabs; slab++) {
+            unsigned lo = slab * p.slab_sz, hi = std::min(p.n, lo + p.slab_sz);
+            u32* cnt = &H[((size_t)w * p.nslabs + slab) * p.NB];
+            for (unsigned i = lo; i < hi; i++) { u32 d = digits[(size_t)w * p.n + i]; if (d) cnt[(d & 0x7fffffffu) - 1]++; }
+        }
+    for (size_t id = 0; id < (size_t)p.nwins * p.NB; id++) {
+        unsigned w = id / p.NB, b = id % p.NB; u32 run = 0;
+        for (unsigned s = 0; s < p.nslabs; s++) { u32* q = &H[((size_t)w * p.nslabs + s) * p.NB + b]; u32 t = *q; *q = run; run += t; }
+        tot[id] = run;
+    }
+    for (unsigned w = 0; w < p.nwins; w++) {
+        u32 run = 0;
+        for (unsigned b = 0; b < p.NB; b++) { off[(size_t)w * (p.NB + 1) + b] = run; run += tot[(size_t)w * p.NB + b]; }
+        off[(size_t)w * (p.NB + 1) + p.NB] = run;
+    }
+    for (unsigned w = 0; w < p.nwins; w++)
+        for (unsigned slab = 0; slab < p.nslabs; slab++) {
+            std::vector<u32> cur(p.NB);
+            for (unsigned b = 0; b < p.NB; b++) cur[b] = H[((size_t)w * p.nslabs + slab) * p.NB + b] + off[(size_t)w * (p.NB + 1) + b];
+            unsigned lo = slab * p.slab_sz, hi = std::min(p.n, lo + p.slab_sz);
+            // reverse order inside the slab: any order within a bucket must work
+            for (unsigned i = hi; i-- > lo;) {
+                u32 d = digits[(size_t)w * p.n + i];
+                if (d) sorted[(size_t)w * p.n + cur[(d & 0x7fffffffu) - 1]++] = i | (d & 0x80000000u);
+            }
+        }
+
+    // ---- accumulate + record levels ----
+    std::vector<bucket_d> buckets((size_t)p.nwins * p.NB);
+    memset(buckets.data(), 0, buckets.size() * sizeof(bucket_d));
+    size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win, nrecB = 2 * ((nrecA + p.F - 1) / p.F);
+    std::vector<u32> keyA(nrecA), keyB(nrecB);
+    std::vector<bucket_d> ptA(nrecA), ptB(nrecB);
+    // the device gather may read up to the padded stride; copy points into an 8-byte aligned buffer
+    std::vector<uint64_t> pts_al((npoints * stride + 15) / 8);
+    memcpy(pts_al.data(), points, npoints * stride);
+    const unsigned char* pts = (const unsigned char*)pts_al.data();
+    for (unsigned w = 0; w < p.nwins; w++)
+        for (unsigned chunk = 0; chunk < ((p.chunks_per_win + 255) / 256) * 256; chunk++) {
+            if (flagged) accumulate_chunk<fp_d, true>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
+                                                      sorted.data(), off.data(), p.n, p.NB, p.L, p.chunks_per_win, chunk, w);
+            else         accumulate_chunk<fp_d, false>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
+                                                       sorted.data(), off.data(), p.n, p.NB, p.L, p.chunks_per_win, chunk, w);
+        }
+    {
+        size_t nrec = nrecA;
+        u32 *ik = keyA.data(), *ok = keyB.data(); bucket_d *ip = ptA.data(), *op = ptB.data();
+        for (;;) {
+            unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
+            int last = nthreads == 1;
+            for (unsigned t = 0; t < ((nthreads + 255) / 256) * 256; t++)
+                reduce_runs_chunk<fp_d>(buckets.data(), ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last, t);
+            if (last) break;
+            nrec = (size_t)2 * nthreads;
+            std::swap(ik, ok); std::swap(ip, op);
+        }
+    }
+
+    // ---- bucket sums ----
+    size_t n1 = (size_t)p.nwins * (p.NB / p.K);
+    std::vector<bucket_d> A1(n1), W1(n1), A2(n1), W2(n1);
+    unsigned nitems = p.NB / p.K;
+    for (size_t id = 0; id < n1; id++) bucket_level1_item<fp_d>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id);
+    unsigned lgG = lg2_floor(p.K);
+    bucket_d *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
+    while (nitems > 1) {
+        unsigned Kc = std::min(p.K, nitems);
+        size_t nthr = (size_t)p.nwins * (nitems / Kc);
+        for (size_t id = 0; id < nthr; id++) bucket_levelN_item<fp_d>(oa, ow, ia, iw, nitems, Kc, lgG, p.nwins, id);
+        nitems /= Kc; lgG += lg2_floor(Kc);
+        std::swap(ia, oa); std::swap(iw, ow);
+    }
+    for (unsigned w = p.nwins; w--;) {
+        fp_h c[4];
+        memcpy(c, &iw[w], sizeof(c));
+        point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
+        out.add(s);
+        if (w) for (unsigned k = 0; k < p.wbits; k++) out.dbl();
+    }
+    memcpy(out_jac, &out, sizeof(out));
+    return 0;
+}

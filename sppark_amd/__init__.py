@@ -1,0 +1,12 @@
+"""sppark_amd — MI355X-native MSM + NTT primitives behind sppark's C ABI.
+
+Host-side mirror of the reference's Rust/Go wrappers (poc/msm-cuda/src/lib.rs,
+poc/ntt-cuda/src/lib.rs, rust/src/lib.rs) over the C-ABI libraries in
+sppark_amd/lib (declared in include/sppark_amd.h).  All compute happens in the
+HIP libraries; importing this package without them built raises at first use.
+"""
+from .ffi import SpparkError, load, lib_path, cuda_available                      # noqa: F401
+from .msm import (multi_scalar_mult, multi_scalar_mult_arkworks, MsmContext,      # noqa: F401
+                  jacobian_sum, to_affine, generate_points)
+from .ntt import (NTT, iNTT, coset_NTT, coset_iNTT, compute_ntt,                  # noqa: F401
+                  NTTInputOutputOrder, NTTDirection, NTTType)

@@ -53,7 +53,7 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.chunks_per_win = (p.n + L - 1) / L;
     p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
-    p.F = t.F ? t.F : 32;
+    p.F = std::max(4u, t.F ? t.F : 32u);       // fan-in < 3 would never shrink the record list
     p.K = t.K ? t.K : 8;
     p.K = std::min(p.K, p.NB);
     return p;

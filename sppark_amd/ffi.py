@@ -1,0 +1,123 @@
+"""ctypes binding of the sppark_amd C ABI (include/sppark_amd.h).
+
+What a maintainer of the reference's callers would write:
+  * Rust  `#[repr(C)] struct Error { code: i32, str: Option<NonNull<c_char>> }`
+    returned by value (rust/src/lib.rs:9-23)               -> class _Error below
+  * Go    dlopen the library next to the executable and dlsym each entry point
+    (go/sppark.go:83-96,165-214)                           -> load() below
+Errors surface as SpparkError (the Rust wrappers `panic!(String::from(err))`,
+poc/msm-cuda/src/lib.rs:76-78).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+CURVES = ("bls12_381", "bn254")
+NTT_FIELDS = ("gl64", "bb31")
+
+
+class _Error(ctypes.Structure):                 # util/rusterror.h:18-36
+    _fields_ = [("code", ctypes.c_int), ("message", ctypes.c_void_p)]
+
+
+class SpparkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("sppark error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+def lib_path(name):
+    return os.path.join(_HERE, "lib", "libsppark_%s.so" % name)
+
+
+def load(name):
+    """dlopen libsppark_<name>.so and declare its entry points.  Fails loudly
+    when the HIP library has not been built -- there is no fallback."""
+    if name in _LIBS:
+        return _LIBS[name]
+    path = lib_path(name)
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s is missing: build the HIP libraries first (python -m sppark_amd.build)" % path)
+    L = ctypes.CDLL(path)
+    vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
+    L.cuda_available.restype = ctypes.c_bool
+    L.drop_error_message.argtypes = [vp]
+    L.drop_gpu_ptr_t.argtypes = [ctypes.POINTER(vp)]
+    L.clone_gpu_ptr_t.argtypes = [ctypes.POINTER(vp)]
+    L.clone_gpu_ptr_t.restype = vp
+    if name in CURVES:
+        L.mult_pippenger_inf.argtypes = [vp, vp, sz, vp, sz]
+        L.mult_pippenger_inf.restype = _Error
+        L.mult_pippenger.argtypes = [vp, vp, sz, vp]
+        L.mult_pippenger.restype = _Error
+        L.sppark_msm_create.argtypes = [ctypes.POINTER(vp), ci, vp]
+        L.sppark_msm_create.restype = _Error
+        L.sppark_msm_destroy.argtypes = [vp]
+        L.sppark_msm_set_stream.argtypes = [vp, vp]
+        L.sppark_msm_set_stream.restype = _Error
+        L.sppark_msm_tune.argtypes = [vp, cu, cu, cu, cu, cu]
+        L.sppark_msm_tune.restype = _Error
+        L.sppark_msm_reserve.argtypes = [vp, sz, sz, ci, ci]
+        L.sppark_msm_reserve.restype = _Error
+        L.sppark_msm_invoke.argtypes = [vp, vp, vp, sz, vp, ci, sz]
+        L.sppark_msm_invoke.restype = _Error
+        L.sppark_msm_enable_timing.argtypes = [vp, ci]
+        L.sppark_msm_enable_timing.restype = _Error
+        L.sppark_msm_kernel_ms.argtypes = [vp, ci]
+        L.sppark_msm_kernel_ms.restype = ctypes.c_float
+        L.sppark_msm_scratch_bytes.argtypes = [vp]
+        L.sppark_msm_scratch_bytes.restype = sz
+        L.sppark_g1_jacobian_sum.argtypes = [vp, vp, sz]
+        L.sppark_g1_to_affine.argtypes = [vp, vp]
+        L.sppark_g1_generate.argtypes = [vp, sz, sz, ctypes.c_uint64]
+        L.sppark_g1_generate.restype = _Error
+        L.sppark_devtest_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
+        L.sppark_devtest_field_op.restype = _Error
+        L.sppark_devtest_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_xyzz_op.restype = _Error
+        L.sppark_devtest_ubench.argtypes = [ci, ci, cu, cu, ctypes.POINTER(ctypes.c_float),
+                                            ctypes.POINTER(ctypes.c_double)]
+        L.sppark_devtest_ubench.restype = _Error
+        L.sppark_devtest_fieldbench.argtypes = [ci, ci, cu, cu, ctypes.POINTER(ctypes.c_float)]
+        L.sppark_devtest_fieldbench.restype = _Error
+    if name in NTT_FIELDS:
+        L.compute_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci]
+        L.compute_ntt.restype = _Error
+        L.sppark_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci, vp]
+        L.sppark_ntt.restype = _Error
+    _LIBS[name] = L
+    return L
+
+
+def check(L, err):
+    """Raise SpparkError for a non-zero code; take ownership of the message."""
+    if err.code != 0:
+        msg = ""
+        if err.message:
+            msg = ctypes.string_at(err.message).decode(errors="replace")
+            L.drop_error_message(err.message)
+        raise SpparkError(err.code, msg)
+
+
+def cuda_available(name="bls12_381"):
+    """util/all_gpus.cpp:65-66 via go/sppark.go:475-477 IsCudaAvailable()."""
+    return bool(load(name).cuda_available())
+
+
+def as_pointer(x):
+    """(address, keepalive) of a numpy array, torch tensor (host or device) or int."""
+    if isinstance(x, int):
+        return x, None
+    if hasattr(x, "data_ptr"):                      # torch tensor
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr(), x
+    if hasattr(x, "ctypes"):                        # numpy
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data, x
+    raise TypeError("unsupported buffer type %r" % type(x))

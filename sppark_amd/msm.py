@@ -1,0 +1,138 @@
+"""MSM host API: mirror of poc/msm-cuda/src/lib.rs:18-119 (multi_scalar_mult,
+multi_scalar_mult_arkworks) plus a context object playing the role of the
+reference's C++-only msm_t (msm/pippenger.cuh:325-728): scratch memory reused
+across calls, device-resident inputs, stream selection and kernel timers.
+"""
+import ctypes
+
+import numpy as np
+
+from . import ffi
+
+FP_BYTES = {"bls12_381": 48, "bn254": 32}
+
+
+def _nbytes(x):
+    if hasattr(x, "nbytes"):
+        return int(x.nbytes)
+    return int(x.numel() * x.element_size())
+
+
+def _npoints(points, stride):
+    total = _nbytes(points)
+    if total % stride:
+        raise ValueError("points buffer is not a multiple of the %d-byte stride" % stride)
+    return total // stride
+
+
+def multi_scalar_mult_arkworks(points, scalars, curve="bls12_381", ffi_affine_sz=None):
+    """mult_pippenger_inf (poc/msm-cuda/src/lib.rs:46-82).
+
+    points : buffer of Affine_inf_t records (X | Y | infinity flag), stride
+             ffi_affine_sz (default: 2*sizeof(fp) + 8, the arkworks layout)
+    scalars: n 32-byte little-endian integers < r (not Montgomery)
+    returns the Jacobian result X|Y|Z as a uint8 array (144 B / 96 B).
+    Buffers may be numpy arrays or torch tensors (host or device).
+    """
+    L = ffi.load(curve)
+    fb = FP_BYTES[curve]
+    stride = ffi_affine_sz or (2 * fb + 8)
+    n = _npoints(points, stride)
+    if _nbytes(scalars) != 32 * n:
+        raise ValueError("length mismatch")                 # lib.rs:61-63
+    pp, _k1 = ffi.as_pointer(points)
+    sp, _k2 = ffi.as_pointer(scalars)
+    out = np.zeros(3 * fb, dtype=np.uint8)
+    ffi.check(L, L.mult_pippenger_inf(out.ctypes.data, pp, n, sp, stride))
+    return out
+
+
+def multi_scalar_mult(points, scalars, curve="bls12_381"):
+    """mult_pippenger (poc/msm-cuda/src/lib.rs:18-44): plain X|Y affine points,
+    infinity encoded as all-zero."""
+    L = ffi.load(curve)
+    fb = FP_BYTES[curve]
+    n = _npoints(points, 2 * fb)
+    if _nbytes(scalars) != 32 * n:
+        raise ValueError("length mismatch")
+    pp, _k1 = ffi.as_pointer(points)
+    sp, _k2 = ffi.as_pointer(scalars)
+    out = np.zeros(3 * fb, dtype=np.uint8)
+    ffi.check(L, L.mult_pippenger(out.ctypes.data, pp, n, sp))
+    return out
+
+
+class MsmContext:
+    """Reusable MSM context (cf. msm_t, msm/pippenger.cuh:325-388,582-610)."""
+
+    def __init__(self, curve="bls12_381", device_id=-1, stream=None):
+        self.curve = curve
+        self.L = ffi.load(curve)
+        self.fb = FP_BYTES[curve]
+        h = ctypes.c_void_p()
+        ffi.check(self.L, self.L.sppark_msm_create(ctypes.byref(h), device_id, stream))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.sppark_msm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_stream(self, stream):
+        ffi.check(self.L, self.L.sppark_msm_set_stream(self.h, stream))
+
+    def tune(self, wbits=0, L=0, F=0, K=0, nslabs=0):
+        ffi.check(self.L, self.L.sppark_msm_tune(self.h, wbits, L, F, K, nslabs))
+
+    def reserve(self, npoints, ffi_affine_sz, host_points=False, host_scalars=False):
+        ffi.check(self.L, self.L.sppark_msm_reserve(self.h, npoints, ffi_affine_sz,
+                                                    int(host_points), int(host_scalars)))
+
+    def enable_timing(self, on=True):
+        ffi.check(self.L, self.L.sppark_msm_enable_timing(self.h, int(on)))
+
+    def kernel_ms(self, which):
+        return float(self.L.sppark_msm_kernel_ms(self.h, which))
+
+    def scratch_bytes(self):
+        return int(self.L.sppark_msm_scratch_bytes(self.h))
+
+    def invoke(self, points, scalars, npoints=None, mont=False, ffi_affine_sz=None):
+        stride = ffi_affine_sz or 2 * self.fb
+        n = npoints if npoints is not None else _npoints(points, stride)
+        pp, _k1 = ffi.as_pointer(points)
+        sp, _k2 = ffi.as_pointer(scalars)
+        out = np.zeros(3 * self.fb, dtype=np.uint8)
+        ffi.check(self.L, self.L.sppark_msm_invoke(self.h, out.ctypes.data, pp, n, sp, int(mont), stride))
+        return out
+
+
+def jacobian_sum(points, curve="bls12_381"):
+    """Sum of Jacobian points (host arithmetic; the multi-GPU combine step)."""
+    L = ffi.load(curve)
+    pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 3 * FP_BYTES[curve])
+    out = np.zeros(3 * FP_BYTES[curve], dtype=np.uint8)
+    L.sppark_g1_jacobian_sum(out.ctypes.data, pts.ctypes.data, pts.shape[0])
+    return out
+
+
+def to_affine(jacobian, curve="bls12_381"):
+    """(x | y) of a Jacobian point, infinity -> all-zero (what the reference's
+    tests obtain from arkworks' into_affine(), poc/msm-cuda/tests/msm.rs:26-38)."""
+    L = ffi.load(curve)
+    j = np.ascontiguousarray(jacobian, dtype=np.uint8)
+    out = np.zeros(2 * FP_BYTES[curve], dtype=np.uint8)
+    L.sppark_g1_to_affine(out.ctypes.data, j.ctypes.data)
+    return out
+
+
+def generate_points(out, n, seed, stride, curve="bls12_381"):
+    """Fill |out| (numpy array or torch tensor, host or device) with n points
+    k_i*G computed on the GPU (synthetic inputs in the shape of
+    poc/msm-cuda/src/util.rs:11-38)."""
+    L = ffi.load(curve)
+    p, _k = ffi.as_pointer(out)
+    ffi.check(L, L.sppark_g1_generate(p, stride, n, seed))
+    return out

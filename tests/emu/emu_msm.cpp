@@ -74,7 +74,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     p.chunks_per_win = (p.n + p.L - 1) / p.L;
     p.nslabs = nslabs ? nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
-    p.F = F ? F : 32;
+    p.F = std::max(4u, F ? F : 32u);
     p.K = std::min(K ? K : 8u, p.NB);
     const bool flagged = stride > 2 * sizeof(fp_d);
 

@@ -1,0 +1,114 @@
+"""Generate tests/golden/*.json.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+MSM expectations come from the REFERENCE's own msm/pippenger.hpp compiled in
+place (oracle/_ref/libref_msm.so, see oracle/ref_shim.cpp), 1-thread and
+8-thread paths required to agree.  NTT expectations come from an independent
+definition-level Python big-int DFT written here (the reference has no CPU NTT),
+applied through the order/direction/coset semantics of ntt/ntt.cuh:161-213.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle as O          # noqa: E402
+import recipe               # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def hexs(a):
+    return np.ascontiguousarray(a).tobytes().hex()
+
+
+def make_msm():
+    assert O.ref_available(), "oracle/_ref not built (needs /root/reference)"
+    cases = []
+    for curve, cname in ((O.BLS12_381, "bls12_381"), (O.BN254, "bn254")):
+        for n, flagged in ((1, False), (2, False), (4, True), (31, False), (32, True), (33, False),
+                           (1000, True), (1024, False), (65536 if curve == O.BLS12_381 else 4096, False)):
+            seed = 0x5eed5eed0001 + n
+            pts, sc = recipe.msm_inputs(curve, n, seed, ndistinct=2048 if n > 4096 else 64, flagged=flagged)
+            e1 = O.ref_msm_affine(curve, pts, sc, nthreads=0)
+            e8 = O.ref_msm_affine(curve, pts, sc, nthreads=8)
+            assert (e1 == e8).all()
+            case = {"curve": cname, "n": n, "seed": seed, "flagged": flagged,
+                    "ndistinct": 2048 if n > 4096 else 64, "expect_affine": hexs(e1)}
+            if n <= 33:
+                case["points"] = hexs(pts); case["scalars"] = hexs(sc)
+            cases.append(case)
+    # KAT of SURVEY Appendix A.4: sum_{i=1..4} i*(i*G) = 30*G
+    G = O.g1_generator(O.BLS12_381)
+    pts = np.stack([O.g1_mul(O.BLS12_381, G, i) for i in range(1, 5)])
+    sc = np.stack([np.frombuffer(int(i).to_bytes(32, "little"), dtype=np.uint8) for i in range(1, 5)])
+    e = O.ref_msm_affine(O.BLS12_381, pts, sc, nthreads=0)
+    cases.append({"curve": "bls12_381", "n": 4, "kat": "30G", "points": hexs(pts), "scalars": hexs(sc),
+                  "flagged": False, "expect_affine": hexs(e)})
+    json.dump(cases, open(os.path.join(HERE, "msm_golden.json"), "w"), indent=0)
+    print("msm cases:", len(cases))
+
+
+# ---- independent big-int NTT (definition level) -----------------------------
+def bitrev(i, lg):
+    return int(format(i, "0%db" % lg)[::-1], 2) if lg else 0
+
+
+def py_ntt(a, lg, order, direction, typ, p, top_root, two_adicity, gen):
+    n = 1 << lg
+    w = pow(top_root, 1 << (two_adicity - lg), p)
+    g = gen
+    if direction == 1:
+        w = pow(w, p - 2, p); g = pow(g, p - 2, p)
+    a = list(a)
+    B = [bitrev(i, lg) for i in range(n)]
+    # SURVEY Appendix A.8 table
+    if order == O.RN:
+        a = [a[B[i]] for i in range(n)]                      # input is bit-reversed
+    if typ == 1 and direction == 0:
+        a = [a[j] * pow(g, B[j] if order == O.RR else j, p) % p for j in range(n)]
+    X = [sum(a[j] * pow(w, j * k, p) for j in range(n)) % p for k in range(n)]
+    if direction == 1:
+        ninv = pow(n, p - 2, p)
+        X = [x * ninv % p for x in X]
+    if typ == 1 and direction == 1:
+        X = [X[j] * pow(g, B[j] if order == O.RR else j, p) % p for j in range(n)]
+    if order == O.NR:
+        X = [X[B[i]] for i in range(n)]                      # output bit-reversed
+    return X
+
+
+def make_ntt():
+    cases = []
+    R = 1 << 32
+    for field in ("gl64", "bb31"):
+        for lg in (1, 3, 5):
+            x = recipe.ntt_input(field, lg, 0x5eed5eed0002 + lg)
+            for order in range(4):
+                for direction in range(2):
+                    for typ in range(2):
+                        if field == "gl64":
+                            y = py_ntt([int(v) for v in x], lg, order, direction, typ, O.GL64_P,
+                                       0x185629dcda58878c, 32, 7)
+                            out = np.array(y, dtype=np.uint64)
+                        else:
+                            p = O.BB31_P
+                            rinv = pow(R, p - 2, p)
+                            top = 0x1ffffedc * rinv % p                  # Montgomery -> canonical
+                            xc = [int(v) * rinv % p for v in x]
+                            y = py_ntt(xc, lg, order, direction, typ, p, top, 27, 3)
+                            out = np.array([v * R % p for v in y], dtype=np.uint32)
+                        cases.append({"field": field, "lg": lg, "order": order, "direction": direction,
+                                      "type": typ, "input": hexs(x), "expect": hexs(out)})
+    json.dump(cases, open(os.path.join(HERE, "ntt_golden.json"), "w"), indent=0)
+    print("ntt cases:", len(cases))
+
+
+if __name__ == "__main__":
+    make_msm()
+    make_ntt()

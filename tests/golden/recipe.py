@@ -1,0 +1,45 @@
+"""Deterministic input recipes shared by make_golden.py and the tests.
+
+MSM inputs mirror poc/msm-cuda/src/util.rs:11-38 (2^k distinct points replicated
+cyclically, index 3 forced to infinity, uniform scalars) but seeded."""
+import numpy as np
+
+import oracle as O
+
+
+def msm_inputs(curve, n, seed, ndistinct=64, flagged=False, edge=True):
+    fb = O.FP_BYTES[curve]
+    stride = 2 * fb + 8 if flagged else 2 * fb
+    base = O.g1_gen_points(curve, min(ndistinct, max(n, 1)), seed)
+    pts = np.zeros((n, stride), dtype=np.uint8)
+    if n:
+        pts[:, :2 * fb] = base[np.arange(n) % base.shape[0]]
+    sc = O.random_scalars(curve, n, seed ^ 0x5ca1a5)
+    r = O.FR_MODULUS[curve]
+    if edge and n > 3:
+        pts[3] = 0                                  # infinity at index 3 (util.rs:24)
+        if flagged:
+            pts[3, 2 * fb] = 1
+            pts[3, :8] = 0xa5                       # garbage coordinates under the flag
+    if edge and n > 12:
+        sc[5] = 0                                                               # zero scalar
+        sc[6] = np.frombuffer((r - 1).to_bytes(32, "little"), dtype=np.uint8)  # r - 1
+        sc[7] = sc[8]; pts[7] = pts[8]                                          # same point & scalar (doubling)
+        sc[9] = np.frombuffer(((r + 1) // 2).to_bytes(32, "little"), dtype=np.uint8)
+        sc[10] = np.frombuffer(((r - 1) // 2).to_bytes(32, "little"), dtype=np.uint8)
+        sc[11] = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
+        # P and -P with the same scalar cancel
+        p = O.FP_MODULUS[curve]
+        y = int.from_bytes(pts[1, fb:2 * fb].tobytes(), "little")
+        pts[12] = pts[1]
+        pts[12, fb:2 * fb] = np.frombuffer(((p - y) % p).to_bytes(fb, "little"), dtype=np.uint8)
+        sc[12] = sc[1]
+    return pts, sc
+
+
+def ntt_input(field, lg, seed):
+    rng = np.random.default_rng(seed)
+    n = 1 << lg
+    if field == "gl64":
+        return (rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)) % np.uint64(O.GL64_P)
+    return (rng.integers(0, 1 << 32, size=n, dtype=np.uint64) % O.BB31_P).astype(np.uint32)

@@ -1,0 +1,92 @@
+"""CPU: the C-ABI libraries load without a GPU, export every symbol that
+include/sppark_amd.h declares, honour the by-value {int, char*} error protocol
+and FAIL LOUDLY (no CPU fallback) when no device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import have_gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "sppark_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(\w+)\s*\([^;{}]*\)\s*;", hdr)) - {"defined"})
+
+
+def test_header_symbols_exported(libs):
+    syms = declared_symbols()
+    assert "mult_pippenger_inf" in syms and "compute_ntt" in syms and "cuda_available" in syms
+    common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message"}
+    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1")}
+    ntt_only = {"compute_ntt", "sppark_ntt"}
+    assert set(syms) == common | msm_only | ntt_only
+    for name, path in libs.items():
+        L = ctypes.CDLL(path)
+        want = common | (msm_only if name in ("bls12_381", "bn254") else ntt_only)
+        for s in want:
+            assert hasattr(L, s), (name, s)
+
+
+def test_symbols_resolve_like_go_dlsym(libs):
+    """go/sppark.go:83-96 resolves every registered name with dlsym on a handle
+    opened next to the executable."""
+    h = ctypes.CDLL(libs["bls12_381"], mode=ctypes.RTLD_LOCAL)
+    for s in ("mult_pippenger_inf", "mult_pippenger", "cuda_available", "drop_error_message"):
+        assert ctypes.cast(getattr(h, s), ctypes.c_void_p).value
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device behaviour")
+def test_no_device_fails_loudly(libs):
+    import sppark_amd
+    from sppark_amd import ffi
+    assert sppark_amd.cuda_available() is False
+    pts = np.zeros((4, 104), dtype=np.uint8)
+    sc = np.zeros((4, 32), dtype=np.uint8)
+    with pytest.raises(ffi.SpparkError) as e:
+        sppark_amd.multi_scalar_mult_arkworks(pts, sc)
+    assert e.value.code != 0 and e.value.message              # negated HIP error + text
+    with pytest.raises(ffi.SpparkError):
+        sppark_amd.NTT(0, np.zeros(8, dtype=np.uint64), sppark_amd.NTTInputOutputOrder.NN)
+
+
+def test_error_out_is_infinity_and_message_owned(libs):
+    """on error `out` is set to infinity (msm/pippenger.cuh:740) and the message
+    is a malloc'ed string the caller frees (drop_error_message)."""
+    if have_gpu():
+        pytest.skip("needs the no-device error path")
+    from sppark_amd import ffi
+    L = ffi.load("bls12_381")
+    out = np.full(144, 0xff, dtype=np.uint8)
+    err = L.mult_pippenger_inf(out.ctypes.data, 0, 4, 0, 104)
+    assert err.code != 0
+    assert (out == 0).all()
+    assert ctypes.string_at(err.message)
+    L.drop_error_message(err.message)
+
+
+def test_host_point_helpers(libs, oracle):
+    """sppark_g1_jacobian_sum / sppark_g1_to_affine are host arithmetic (the
+    multi-GPU combine step) and must agree with the oracle."""
+    import sppark_amd
+    O = oracle
+    for curve, name in ((O.BLS12_381, "bls12_381"), (O.BN254, "bn254")):
+        fb = O.FP_BYTES[curve]
+        pts = O.g1_gen_points(curve, 6, 42)
+        jac = np.zeros((6, 3 * fb), dtype=np.uint8)
+        one = O.field_op(O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP, 4, O.int_to_limbs(1, fb)).view(np.uint8)
+        jac[:, :2 * fb] = pts; jac[:, 2 * fb:] = one
+        jac[4] = 0                                              # infinity
+        jac[5] = jac[0]                                         # forces the doubling branch
+        s = sppark_amd.jacobian_sum(jac, name)
+        acc = np.zeros(3 * fb, dtype=np.uint8)
+        for j in jac:
+            acc = O.jac_add(curve, acc, j)
+        assert O.jac_eq(curve, s, acc)
+        assert (sppark_amd.to_affine(s, name) == O.jac_to_affine(curve, acc)).all()
+        assert (sppark_amd.to_affine(np.zeros(3 * fb, dtype=np.uint8), name) == 0).all()

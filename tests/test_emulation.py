@@ -1,0 +1,109 @@
+"""CPU: run the product's per-work-item kernel bodies on the host
+(tests/emu/emu_msm.cpp, built with -DSPPARK_HOST_EMULATION) and compare with the
+oracle.  This checks the device field/point arithmetic at C++ level, the digit
+recoding, the fixed-run accumulate / record-tree logic and the bucket-sum levels
+in the GPU-less container; the real kernels are checked on the GPU by
+tests/test_msm_gpu.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import recipe
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _emu(feature):
+    so = os.path.join(EMU, "libemu_%s.so" % feature)
+    src = os.path.join(EMU, "emu_msm.cpp")
+    csrc = os.path.join(os.path.dirname(HERE), "sppark_amd", "csrc")
+    newest = max(os.stat(os.path.join(r, f)).st_mtime for r, _, fs in os.walk(csrc) for f in fs)
+    newest = max(newest, os.stat(src).st_mtime)
+    if not os.path.exists(so) or os.stat(so).st_mtime < newest:
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               "-DFEATURE_" + feature, "-o", so, src])
+    L = ctypes.CDLL(so)
+    vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
+    L.emu_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
+    L.emu_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
+    L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu]
+    return L
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_device_field_code_on_host(oracle, curve):
+    O = oracle
+    L = _emu("BLS12_381" if curve == 0 else "BN254")
+    rng = np.random.default_rng(curve)
+    for which, p, nb, ofield in ((0, O.FP_MODULUS[curve], O.FP_BYTES[curve], O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP),
+                                 (1, O.FR_MODULUS[curve], 32, O.FIELD_BLS_FR if curve == 0 else O.FIELD_BN_FR)):
+        n = 96
+        va = [int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(n)]
+        vb = [int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(n)]
+        va[:5] = [0, 1, p - 1, p - 1, 0]; vb[:5] = [0, p - 1, p - 1, 1, 5]
+        a = np.frombuffer(b"".join(v.to_bytes(nb, "little") for v in va), dtype=np.uint8).copy()
+        b = np.frombuffer(b"".join(v.to_bytes(nb, "little") for v in vb), dtype=np.uint8).copy()
+        for op, oop in ((0, 0), (1, 1), (2, 2), (3, 7), (4, 6), (5, 5), (6, 4)):
+            out = np.zeros_like(a)
+            L.emu_field_op(which, op, P(out), P(a), P(b), n)
+            for i in range(n):
+                e = O.field_op(ofield, oop, a[i * nb:(i + 1) * nb].view(np.uint64), b[i * nb:(i + 1) * nb].view(np.uint64))
+                assert (e.view(np.uint8) == out[i * nb:(i + 1) * nb]).all(), (curve, which, op, i)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_msm_pipeline_on_host(oracle, curve):
+    O = oracle
+    L = _emu("BLS12_381" if curve == 0 else "BN254")
+    fb = O.FP_BYTES[curve]
+    # (n, wbits, L, F, K, nslabs, flagged): automatic plan and adversarial tunables
+    for n, wb, LL, F, K, ns, flagged in ((1, 0, 0, 0, 0, 0, False), (2, 0, 0, 0, 0, 0, True), (33, 0, 0, 0, 0, 0, False),
+                                         (1000, 0, 0, 0, 0, 0, True), (1000, 7, 4, 4, 2, 3, False),
+                                         (700, 9, 16, 8, 4, 2, True), (2048, 10, 8, 32, 8, 1, False),
+                                         (300, 2, 4, 4, 2, 1, False), (300, 16, 64, 32, 8, 1, False)):
+        pts, sc = recipe.msm_inputs(curve, n, 1234 + n + wb, flagged=flagged)
+        out = np.zeros(3 * fb, dtype=np.uint8)
+        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns)
+        assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
+
+
+def test_msm_skewed_scalars_on_host(oracle):
+    """all-equal scalars / tiny scalars / 50% zeros: one bucket holds everything,
+    the record tree must still reduce it (SURVEY 8(d) skew cases)."""
+    O = oracle
+    L = _emu("BLS12_381")
+    n = 1500
+    pts, sc = recipe.msm_inputs(0, n, 77, edge=False)
+    cases = []
+    s_eq = sc.copy(); s_eq[:] = sc[0]; cases.append(s_eq)
+    s_small = np.zeros_like(sc); s_small[:, 0] = sc[:, 0] & 3; cases.append(s_small)
+    s_half = sc.copy(); s_half[::2] = 0; cases.append(s_half)
+    same_pts = pts.copy(); same_pts[:] = pts[0]
+    for s in cases:
+        for p in (pts, same_pts):
+            out = np.zeros(144, dtype=np.uint8)
+            L.emu_msm(P(out), P(p), 96, n, P(s), 0, 8, 8, 4, 4, 2)
+            assert (O.jac_to_affine(0, out) == O.msm_affine(0, p, s, algo=0, param=4)).all()
+
+
+def test_msm_montgomery_scalars_on_host(oracle):
+    O = oracle
+    L = _emu("BN254")
+    pts, sc = recipe.msm_inputs(1, 200, 5)
+    mont = np.zeros_like(sc)
+    for i in range(200):
+        mont[i] = O.field_op(O.FIELD_BN_FR, 4, sc[i].view(np.uint64)).view(np.uint8)
+    out = np.zeros(96, dtype=np.uint8)
+    L.emu_msm(P(out), P(pts), 64, 200, P(mont), 1, 0, 0, 0, 0, 0)
+    assert (O.jac_to_affine(1, out) == O.msm_affine(1, pts, sc)).all()

@@ -1,0 +1,251 @@
+"""GPU parity tests for the MSM hot path, through the C ABI (ctypes).
+
+Bit-exactness is defined on the affine normalisation of the Jacobian result
+(what poc/msm-cuda/tests/msm.rs:26-38 compares)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import recipe
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CURVES = [(0, "bls12_381"), (1, "bn254")]
+
+
+def P(a):
+    return a.ctypes.data
+
+
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_device_field_ops(oracle, libs, curve, name):
+    """k_field_op on the GPU vs the oracle, element by element."""
+    from sppark_amd import ffi
+    O = oracle
+    L = ffi.load(name)
+    rng = np.random.default_rng(curve + 10)
+    for which, p, nb, ofield in ((0, O.FP_MODULUS[curve], O.FP_BYTES[curve], O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP),
+                                 (1, O.FR_MODULUS[curve], 32, O.FIELD_BLS_FR if curve == 0 else O.FIELD_BN_FR)):
+        n = 512
+        va = [int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(n)]
+        vb = [int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(n)]
+        va[:5] = [0, 1, p - 1, p - 1, 0]; vb[:5] = [0, p - 1, p - 1, 1, 5]
+        a = np.frombuffer(b"".join(v.to_bytes(nb, "little") for v in va), dtype=np.uint8).copy()
+        b = np.frombuffer(b"".join(v.to_bytes(nb, "little") for v in vb), dtype=np.uint8).copy()
+        for op, oop in ((0, 0), (1, 1), (2, 2), (3, 7), (4, 6), (5, 5), (6, 4)):
+            out = np.zeros_like(a)
+            ffi.check(L, L.sppark_devtest_field_op(which, op, P(out), P(a), P(b), n))
+            for i in range(n):
+                e = O.field_op(ofield, oop, a[i * nb:(i + 1) * nb].view(np.uint64), b[i * nb:(i + 1) * nb].view(np.uint64))
+                assert (e.view(np.uint8) == out[i * nb:(i + 1) * nb]).all(), (name, which, op, i)
+
+
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_device_point_ops(oracle, libs, curve, name):
+    """xyzz add / mixed add / mixed sub / double on the GPU vs the oracle (affine compare),
+    including equal, opposite and infinite operands."""
+    from sppark_amd import ffi
+    O = oracle
+    L = ffi.load(name)
+    fb = O.FP_BYTES[curve]
+    n = 64
+    A = O.g1_gen_points(curve, n, 1); B = O.g1_gen_points(curve, n, 2)
+    B[0] = A[0]                                              # equal -> doubling branch
+    pmod = O.FP_MODULUS[curve]
+    y = int.from_bytes(A[1, fb:].tobytes(), "little")
+    B[1] = A[1]; B[1, fb:] = np.frombuffer(((pmod - y) % pmod).to_bytes(fb, "little"), dtype=np.uint8)   # opposite
+    B[2] = 0                                                 # infinity operand
+    one = O.field_op(O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP, 4, O.int_to_limbs(1, fb)).view(np.uint8)
+
+    def to_xyzz(aff):
+        x = np.zeros((aff.shape[0], 4 * fb), dtype=np.uint8)
+        x[:, :2 * fb] = aff; x[:, 2 * fb:3 * fb] = one; x[:, 3 * fb:] = one
+        inf = (aff == 0).all(axis=1)
+        x[inf] = 0
+        return x
+
+    def to_jac(aff):
+        j = np.zeros((aff.shape[0], 3 * fb), dtype=np.uint8)
+        j[:, :2 * fb] = aff; j[:, 2 * fb:] = one
+        j[(aff == 0).all(axis=1)] = 0
+        return j
+
+    xa, xb = to_xyzz(A), to_xyzz(B)
+    xa[3] = 0                                                # accumulator at infinity
+    A3 = A.copy(); A3[3] = 0
+    ja, jb = to_jac(A3), to_jac(B)
+    negB = B.copy()
+    for i in range(n):
+        yy = int.from_bytes(B[i, fb:].tobytes(), "little")
+        negB[i, fb:] = np.frombuffer(((pmod - yy) % pmod).to_bytes(fb, "little"), dtype=np.uint8)
+    negB[2] = 0
+    jnb = to_jac(negB)
+    for op, operand in ((0, xb), (1, B), (2, B), (3, None)):
+        out = np.zeros_like(xa)
+        ffi.check(L, L.sppark_devtest_xyzz_op(op, P(out), P(xa), P(operand) if operand is not None else 0, n))
+        for i in range(n):
+            if op in (0, 1):
+                e = O.jac_add(curve, ja[i], jb[i])
+            elif op == 2:
+                e = O.jac_add(curve, ja[i], jnb[i])
+            else:
+                e = O.jac_dbl(curve, ja[i])
+            assert (O.xyzz_to_affine(curve, out[i]) == O.jac_to_affine(curve, e)).all(), (name, op, i)
+
+
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_generate_points_matches_oracle(oracle, libs, curve, name):
+    """sppark_g1_generate (device double-and-add + host batch normalisation)."""
+    import sppark_amd
+    O = oracle
+    fb = O.FP_BYTES[curve]
+    out = np.zeros((33, 2 * fb), dtype=np.uint8)
+    sppark_amd.generate_points(out, 33, 0xabcdef, 2 * fb, name)
+    assert (out == O.g1_gen_points(curve, 33, 0xabcdef)).all()
+    flagged = np.zeros((5, 2 * fb + 8), dtype=np.uint8)
+    sppark_amd.generate_points(flagged, 5, 7, 2 * fb + 8, name)
+    assert (flagged[:, :2 * fb] == O.g1_gen_points(curve, 5, 7)).all() and (flagged[:, 2 * fb:] == 0).all()
+
+
+def test_msm_golden_vectors(oracle, libs):
+    """Golden vectors produced by the reference's own msm/pippenger.hpp."""
+    import sppark_amd
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "msm_golden.json"))):
+        curve = O.BLS12_381 if c["curve"] == "bls12_381" else O.BN254
+        fb = O.FP_BYTES[curve]
+        stride = 2 * fb + 8 if c["flagged"] else 2 * fb
+        if "points" in c:
+            pts = np.frombuffer(bytes.fromhex(c["points"]), dtype=np.uint8).reshape(c["n"], stride).copy()
+            sc = np.frombuffer(bytes.fromhex(c["scalars"]), dtype=np.uint8).reshape(c["n"], 32).copy()
+        else:
+            pts, sc = recipe.msm_inputs(curve, c["n"], c["seed"], c["ndistinct"], c["flagged"])
+        exp = np.frombuffer(bytes.fromhex(c["expect_affine"]), dtype=np.uint8)
+        if c["flagged"]:
+            out = sppark_amd.multi_scalar_mult_arkworks(pts, sc, c["curve"])
+        else:
+            out = sppark_amd.multi_scalar_mult(pts, sc, c["curve"])
+        assert (sppark_amd.to_affine(out, c["curve"]) == exp).all(), (c["curve"], c["n"])
+        assert (O.jac_to_affine(curve, out) == exp).all()
+
+
+@pytest.mark.parametrize("curve,name", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 1000, 4097, 1 << 15])
+def test_msm_vs_oracle(oracle, libs, curve, name, n):
+    """Reference test shape (poc/msm-cuda/tests/msm.rs:19-39, TEST_NPOW=15) +
+    ragged sizes, both wire formats."""
+    import sppark_amd
+    O = oracle
+    for flagged in (False, True):
+        pts, sc = recipe.msm_inputs(curve, n, 31337 + n, ndistinct=2048, flagged=flagged)
+        exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
+        f = sppark_amd.multi_scalar_mult_arkworks if flagged else sppark_amd.multi_scalar_mult
+        out = f(pts, sc, name)
+        assert (sppark_amd.to_affine(out, name) == exp).all(), (name, n, flagged)
+
+
+def test_msm_empty_and_all_infinity(oracle, libs):
+    import sppark_amd
+    out = sppark_amd.multi_scalar_mult(np.zeros((0, 96), dtype=np.uint8), np.zeros((0, 32), dtype=np.uint8))
+    assert (out == 0).all()
+    pts = np.zeros((100, 96), dtype=np.uint8)
+    sc = oracle.random_scalars(0, 100, 3)
+    assert (sppark_amd.to_affine(sppark_amd.multi_scalar_mult(pts, sc)) == 0).all()
+    pts2, _ = recipe.msm_inputs(0, 100, 9)
+    assert (sppark_amd.to_affine(sppark_amd.multi_scalar_mult(pts2, np.zeros((100, 32), dtype=np.uint8))) == 0).all()
+
+
+@pytest.mark.parametrize("tune", [dict(wbits=7, L=4, F=4, K=2, nslabs=3), dict(wbits=12, L=16, F=8, K=4, nslabs=2),
+                                  dict(wbits=16, L=64, F=32, K=8, nslabs=1), dict(wbits=2, L=4, F=4, K=2, nslabs=1)])
+def test_msm_tunables(oracle, libs, tune):
+    """every plan parameter away from its default must give the same group element"""
+    import sppark_amd
+    O = oracle
+    ctx = sppark_amd.MsmContext("bls12_381")
+    ctx.tune(**tune)
+    pts, sc = recipe.msm_inputs(0, 3000, 17, ndistinct=128)
+    out = ctx.invoke(pts, sc)
+    assert (sppark_amd.to_affine(out) == O.msm_affine(0, pts, sc, algo=0, param=8)).all()
+    ctx.close()
+
+
+def test_msm_skewed_scalars(oracle, libs):
+    """SURVEY 8(d) skew cases: all scalars equal, 50% zeros, 16-bit scalars,
+    all points equal."""
+    import sppark_amd
+    O = oracle
+    n = 20000
+    pts, sc = recipe.msm_inputs(0, n, 5, ndistinct=512, edge=False)
+    s_eq = sc.copy(); s_eq[:] = sc[0]
+    s_half = sc.copy(); s_half[::2] = 0
+    s_16 = np.zeros_like(sc); s_16[:, :2] = sc[:, :2]
+    same = pts.copy(); same[:] = pts[0]
+    for p, s in ((pts, s_eq), (pts, s_half), (pts, s_16), (same, sc), (same, s_eq)):
+        out = sppark_amd.multi_scalar_mult(p, s)
+        assert (sppark_amd.to_affine(out) == O.msm_affine(0, p, s, algo=0, param=8)).all()
+
+
+def test_msm_montgomery_scalars_and_device_pointers(oracle, libs):
+    import torch
+    import sppark_amd
+    O = oracle
+    n = 5000
+    pts, sc = recipe.msm_inputs(1, n, 8, ndistinct=256, flagged=True)
+    exp = O.msm_affine(1, pts, sc, algo=0, param=8)
+    mont = np.zeros_like(sc)
+    for i in range(n):
+        mont[i] = O.field_op(O.FIELD_BN_FR, 4, sc[i].view(np.uint64)).view(np.uint8)
+    ctx = sppark_amd.MsmContext("bn254")
+    assert (sppark_amd.to_affine(ctx.invoke(pts, mont, mont=True, ffi_affine_sz=72), "bn254") == exp).all()
+    d_pts = torch.from_numpy(pts).cuda(); d_sc = torch.from_numpy(sc).cuda()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert (sppark_amd.to_affine(ctx.invoke(d_pts, d_sc, ffi_affine_sz=72), "bn254") == exp).all()
+    assert (sppark_amd.to_affine(ctx.invoke(d_pts, sc, ffi_affine_sz=72), "bn254") == exp).all()
+    ctx.close()
+
+
+def test_msm_large_linearity(oracle, libs):
+    """2^20 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b mod r) and the 2^16
+    prefix equals the oracle -- size-independent properties at a size the
+    oracle cannot check directly in seconds."""
+    import torch
+    import sppark_amd
+    O = oracle
+    n = 1 << 20
+    r = O.FR_MODULUS[0]
+    base = np.zeros((2048, 96), dtype=np.uint8)
+    sppark_amd.generate_points(base, 2048, 0x5eed5eed0001, 96)
+    pts = base[np.arange(n) % 2048].copy()
+    pts[3] = 0
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); a[:, 31] &= 0x3f
+    b = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); b[:, 31] &= 0x3f
+    a64 = a.view(np.uint64).reshape(n, 4); b64 = b.view(np.uint64).reshape(n, 4)
+    s = np.zeros_like(a64); carry = np.zeros(n, dtype=np.uint64)
+    for k in range(4):                                       # a + b < 2^255 < 2r: one conditional subtraction
+        t = a64[:, k] + b64[:, k]; c1 = t < a64[:, k]
+        t2 = t + carry; c2 = t2 < t
+        s[:, k] = t2; carry = (c1 | c2).astype(np.uint64)
+    s_int_hi = s[:, 3]
+    r64 = np.frombuffer(r.to_bytes(32, "little"), dtype=np.uint64)
+    ge = np.zeros(n, dtype=bool); decided = np.zeros(n, dtype=bool)
+    for k in (3, 2, 1, 0):
+        gt = (s[:, k] > r64[k]) & ~decided; lt = (s[:, k] < r64[k]) & ~decided
+        ge |= gt; decided |= gt | lt
+    ge |= ~decided
+    borrow = np.zeros(n, dtype=np.uint64)
+    for k in range(4):
+        sub = np.where(ge, r64[k], np.uint64(0))
+        t = s[:, k] - sub; b1 = s[:, k] < sub
+        t2 = t - borrow; b2 = t < borrow
+        s[:, k] = t2; borrow = (b1 | b2).astype(np.uint64)
+    sc_sum = s.view(np.uint8).reshape(n, 32)
+    ctx = sppark_amd.MsmContext("bls12_381")
+    d_pts = torch.from_numpy(pts).cuda()
+    ra = ctx.invoke(d_pts, a); rb = ctx.invoke(d_pts, b); rs = ctx.invoke(d_pts, sc_sum)
+    assert (sppark_amd.to_affine(sppark_amd.jacobian_sum(np.stack([ra, rb]))) == sppark_amd.to_affine(rs)).all()
+    m = 1 << 16
+    assert (sppark_amd.to_affine(ctx.invoke(pts[:m], a[:m])) == O.msm_affine(0, pts[:m], a[:m], algo=0, param=8)).all()
+    ctx.close()

@@ -1,0 +1,155 @@
+"""CPU: pin the oracle (oracle/) against Python big-ints, the KATs of SURVEY
+Appendix A, the golden vectors and -- when built -- the reference itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import recipe
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rand_field(rng, p, nbytes, n):
+    vals = [int.from_bytes(rng.bytes(nbytes + 8), "little") % p for _ in range(n)]
+    vals[:4] = [0, 1, p - 1, p - 2]
+    return vals
+
+
+@pytest.mark.parametrize("field", [0, 1, 2, 3])
+def test_field_ops_vs_python(oracle, field):
+    O = oracle
+    p = {0: O.FP_MODULUS[0], 1: O.FR_MODULUS[0], 2: O.FP_MODULUS[1], 3: O.FR_MODULUS[1]}[field]
+    nb = 48 if field == 0 else 32
+    R = 1 << (8 * nb)
+    rinv = pow(R, p - 2, p)
+    rng = np.random.default_rng(field)
+    a, b = _rand_field(rng, p, nb, 64), _rand_field(rng, p, nb, 64)[::-1]
+    for x, y in zip(a, b):
+        lx, ly = O.int_to_limbs(x, nb), O.int_to_limbs(y, nb)
+        assert O.limbs_to_int(O.field_op(field, 0, lx, ly)) == (x + y) % p
+        assert O.limbs_to_int(O.field_op(field, 1, lx, ly)) == (x - y) % p
+        assert O.limbs_to_int(O.field_op(field, 2, lx, ly)) == x * y * rinv % p
+        assert O.limbs_to_int(O.field_op(field, 7, lx)) == x * x * rinv % p
+        assert O.limbs_to_int(O.field_op(field, 4, lx)) == x * R % p
+        assert O.limbs_to_int(O.field_op(field, 5, lx)) == x * rinv % p
+        assert O.limbs_to_int(O.field_op(field, 6, lx)) == (-x) % p
+        inv = O.limbs_to_int(O.field_op(field, 3, lx))                  # Montgomery inverse
+        assert (x * inv * rinv * rinv) % p == (1 if x else 0)
+
+
+def test_reference_constants(oracle):
+    """R, R^2, -1/p of the parameter tables (ff/bls12-381.hpp, ff/alt_bn128.hpp)."""
+    O = oracle
+    for field, p, nb in ((0, O.FP_MODULUS[0], 48), (1, O.FR_MODULUS[0], 32), (2, O.FP_MODULUS[1], 32), (3, O.FR_MODULUS[1], 32)):
+        one = O.limbs_to_int(O.field_op(field, 4, O.int_to_limbs(1, nb)))
+        assert one == (1 << (8 * nb)) % p
+    assert 0x1ffffedc * pow(1 << 32, O.BB31_P - 2, O.BB31_P) % O.BB31_P == 137
+    assert pow(7, (O.GL64_P - 1) >> 32, O.GL64_P) == 0x185629dcda58878c
+    assert O.lib().oracle_gl64_root(24) == 0x86cdcc31c307e171
+    assert O.lib().oracle_gl64_root(1) == O.GL64_P - 1
+
+
+def test_msm_kat_30G(oracle):
+    """SURVEY Appendix A.4."""
+    O = oracle
+    G = O.g1_generator(O.BLS12_381)
+    pts = np.stack([O.g1_mul(O.BLS12_381, G, i) for i in range(1, 5)])
+    sc = np.stack([np.frombuffer(int(i).to_bytes(32, "little"), dtype=np.uint8) for i in range(1, 5)])
+    x_limbs = [0x81d35a7c0d45fea7, 0x1d72ddc201bd6796, 0x26fca92118a3cb77, 0x412b51bb870f2a3a, 0x67640ebd91ea6ce3, 0x13d09f545c6c9d60]
+    for algo, param in ((0, 0), (0, 8), (1, 0), (2, 10), (2, 16)):
+        a = O.msm_affine(O.BLS12_381, pts, sc, algo=algo, param=param)
+        assert list(a[:48].view(np.uint64)) == x_limbs
+    xc = O.limbs_to_int(O.field_op(O.FIELD_BLS_FP, 5, a[:48].view(np.uint64)))
+    assert xc == int("0d84464b3966ec5bede84aa487facfca7823af383715078da03b387cc2f5d5597cdd7d025aa07db00a38b953bdeb6e3f", 16)
+    assert O.g1_on_curve(O.BLS12_381, a)
+
+
+def test_msm_golden(oracle):
+    """Every MSM golden vector (expectations produced by the reference's own
+    msm/pippenger.hpp, tests/golden/make_golden.py) through all three oracle
+    evaluators."""
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "msm_golden.json"))):
+        curve = O.BLS12_381 if c["curve"] == "bls12_381" else O.BN254
+        fb = O.FP_BYTES[curve]
+        stride = 2 * fb + 8 if c["flagged"] else 2 * fb
+        if "points" in c:
+            pts = np.frombuffer(bytes.fromhex(c["points"]), dtype=np.uint8).reshape(c["n"], stride)
+            sc = np.frombuffer(bytes.fromhex(c["scalars"]), dtype=np.uint8).reshape(c["n"], 32)
+        else:
+            pts, sc = recipe.msm_inputs(curve, c["n"], c["seed"], c["ndistinct"], c["flagged"])
+        exp = np.frombuffer(bytes.fromhex(c["expect_affine"]), dtype=np.uint8)
+        algos = [(0, 0), (0, 4), (2, 9)] + ([(1, 0)] if c["n"] <= 1024 else [])
+        if c["n"] > 4096:
+            algos = [(0, 8)]
+        for algo, param in algos:
+            got = O.msm_affine(curve, pts, sc, algo=algo, param=param)
+            assert (got[:2 * fb] == exp).all(), (c["curve"], c["n"], algo)
+
+
+def test_msm_vs_reference_build(oracle):
+    """Restatement == the reference's own template, on fresh random inputs."""
+    O = oracle
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    for curve in (O.BLS12_381, O.BN254):
+        for n, thr in ((5, 0), (100, 0), (100, 3), (777, 8)):
+            pts, sc = recipe.msm_inputs(curve, n, 99 + n)
+            assert (O.ref_msm_affine(curve, pts, sc, thr) == O.msm_affine(curve, pts, sc, algo=0, param=thr)).all()
+        pts, sc = recipe.msm_inputs(curve, 64, 5)
+        mont = np.zeros_like(sc)
+        fld = O.FIELD_BLS_FR if curve == O.BLS12_381 else O.FIELD_BN_FR
+        for i in range(64):
+            mont[i] = O.field_op(fld, 4, sc[i].view(np.uint64)).view(np.uint8)
+        assert (O.ref_msm_affine(curve, pts, mont, 0, mont=True) == O.msm_affine(curve, pts, sc)).all()
+        assert (O.msm_affine(curve, pts, mont, mont=True) == O.msm_affine(curve, pts, sc)).all()
+
+
+def test_msm_empty(oracle):
+    O = oracle
+    out = O.msm(O.BLS12_381, np.zeros((0, 96), dtype=np.uint8), np.zeros((0, 32), dtype=np.uint8))
+    assert (out[96:] == 0).all()
+
+
+def test_ntt_golden(oracle):
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "ntt_golden.json"))):
+        dt = np.uint64 if c["field"] == "gl64" else np.uint32
+        x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt)
+        e = np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)
+        f = O.ntt_gl64 if c["field"] == "gl64" else O.ntt_bb31
+        assert (f(x, c["order"], c["direction"], c["type"]) == e).all(), c
+
+
+def test_ntt_kat_survey_a3(oracle):
+    O = oracle
+    x = np.arange(1, 9, dtype=np.uint64)
+    nn = [0x24, 0xfffc03ff03fffbfd, 0xfffbfffefffffffd, 0x0004040003fffbfc,
+          0xfffffffefffffffd, 0xfffbfbfefc0003fd, 0x0003fffffffffffc, 0x0003fbfffc0003fc]
+    assert list(O.ntt_gl64(x, O.NN)) == nn
+    assert list(O.ntt_naive_gl64(x)) == nn
+    assert list(O.ntt_gl64(x, O.NR)) == [nn[int(format(i, "03b")[::-1], 2)] for i in range(8)]
+    assert int(O.ntt_gl64(x, O.NN, O.FORWARD, O.COSET)[0]) == 0x72d77c
+
+
+@pytest.mark.parametrize("field", ["gl64", "bb31"])
+def test_ntt_properties(oracle, field):
+    """The reference's own test shapes (poc/ntt-cuda/tests/ntt.rs:9-78):
+    NN == RR, iNTT(NTT(v)) == v in NN/RR, iNTT_RN(NTT_NR(v)) == v."""
+    O = oracle
+    f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+    naive = O.ntt_naive_gl64 if field == "gl64" else O.ntt_naive_bb31
+    for lg in range(1, 11):
+        v = recipe.ntt_input(field, lg, lg)
+        nn = f(v, O.NN)
+        assert (nn == f(v, O.RR)).all()
+        if lg <= 8:
+            assert (nn == naive(v)).all()
+        assert (f(nn, O.NN, O.INVERSE) == v).all()
+        assert (f(f(v, O.RR), O.RR, O.INVERSE) == v).all()
+        assert (f(f(v, O.NR), O.RN, O.INVERSE) == v).all()
+        for order in (O.NN, O.RR):
+            assert (f(f(v, order, O.FORWARD, O.COSET), order, O.INVERSE, O.COSET) == v).all()
+        assert (f(f(v, O.NR, O.FORWARD, O.COSET), O.RN, O.INVERSE, O.COSET) == v).all()

@@ -1,7 +1,7 @@
 """Build the sppark_amd C-ABI libraries for gfx950 with hipcc (cross-compiles
 without a GPU).  One shared object per FEATURE, as the reference builds one per
 -DFEATURE_* (rust/src/build.rs ccmd(); poc/*/build.rs).  Translation units are
-compiled in parallel; objects are cached under build/ keyed on source mtimes.
+compiled in parallel; libraries are rebuilt only when the contents of csrc/ change.
 
     python -m sppark_amd.build [--force] [--only bls12_381,gl64]
 """
@@ -41,7 +41,7 @@ def _sources_stamp():
     for root, _, files in sorted(os.walk(CSRC)):
         for f in sorted(files):
             p = os.path.join(root, f)
-            h.update(p.encode()); h.update(str(os.stat(p).st_mtime_ns).encode())
+            h.update(os.path.relpath(p, CSRC).encode()); h.update(open(p, 'rb').read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]
 

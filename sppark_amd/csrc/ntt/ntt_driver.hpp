@@ -1,0 +1,117 @@
+// Host driver of the NTT: the role of the reference's NTT class + NTTParameters
+// (ntt/ntt.cuh:31-366, ntt/parameters.cuh:222-337): order/direction/type
+// dispatch, per-(device, size, direction) twiddle tables built once on the
+// device and kept for the life of the process, kernel sequence on one stream.
+#pragma once
+#include "ntt_kernels.hpp"
+#include "../util/runtime.hpp"
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace sppark_amd {
+
+enum { NTT_NN = 0, NTT_NR = 1, NTT_RN = 2, NTT_RR = 3 };       // ntt/ntt.cuh:33
+enum { NTT_FORWARD = 0, NTT_INVERSE = 1 };                     // ntt/ntt.cuh:34
+enum { NTT_STANDARD = 0, NTT_COSET = 1 };                      // ntt/ntt.cuh:35
+
+// ---- host-side constants (parameter setup only; no transform code here) ------
+template<class F> struct host_field;
+template<> struct host_field<gl64_dev> {
+    typedef unsigned __int128 u128;
+    static u64 mul(u64 a, u64 b) { return (u64)(((u128)a * b) % gl64_dev::MOD); }
+    static u64 pow(u64 b, u64 e) { u64 r = 1; while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; } return r; }
+    static u64 inv(u64 a) { return pow(a, gl64_dev::MOD - 2); }
+    static u64 top_root() { return gl64_dev::TOP_ROOT; }
+    static u64 gen() { return gl64_dev::GROUP_GEN; }
+    static u64 two_pow(unsigned lg) { return pow(2, lg); }
+    static gl64_dev wire(u64 canonical) { gl64_dev r; r.v = canonical; return r; }
+};
+template<> struct host_field<bb31_dev> {                        // canonical arithmetic, converted at the end
+    static constexpr u64 P = bb31_dev::MOD;
+    static u64 mul(u64 a, u64 b) { return a * b % P; }
+    static u64 pow(u64 b, u64 e) { u64 r = 1; while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; } return r; }
+    static u64 inv(u64 a) { return pow(a, P - 2); }
+    static u64 top_root() { return mul(bb31_dev::TOP_ROOT, inv((1ULL << 32) % P)); }   // out of Montgomery form
+    static u64 gen() { return 3; }
+    static u64 two_pow(unsigned lg) { return pow(2, lg); }
+    static bb31_dev wire(u64 canonical) { bb31_dev r; r.v = (u32)((canonical << 32) % P); return r; }
+};
+
+template<class F>
+class ntt_engine {
+    struct table_set { F *lo, *hi, *glo, *ghi; unsigned h; F scale; };
+    std::map<std::tuple<int, unsigned, int>, table_set> cache;     // (hip device, lg, inverse)
+    std::mutex mtx;
+
+    static constexpr unsigned LG_LINE = sizeof(F) == 8 ? 4 : 5;     // elements per 128-byte line
+    static constexpr unsigned LG_TILE = sizeof(F) == 8 ? 12 : 13;   // 32 KB LDS tile
+
+    const table_set& tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        auto key = std::make_tuple(hip_dev, lg, inverse);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+        typedef host_field<F> H;
+        table_set t;
+        t.h = lg < 12 ? lg : 12;
+        size_t nlo = (size_t)1 << t.h, nhi = (size_t)1 << (lg - t.h);
+        HIP_OK(hipMalloc((void**)&t.lo, 2 * (nlo + nhi) * sizeof(F)));
+        t.hi = t.lo + nlo; t.glo = t.hi + nhi; t.ghi = t.glo + nlo;
+        u64 w = H::top_root();
+        for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = H::mul(w, w);
+        u64 g = H::gen();
+        if (inverse) { w = H::inv(w); g = H::inv(g); }
+        t.scale = H::wire(H::inv(H::two_pow(lg)));
+        unsigned grid = (unsigned)((std::max(nlo, nhi) + 255) / 256);
+        hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.lo, t.hi, H::wire(w), lg, t.h);
+        hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.glo, t.ghi, H::wire(g), lg, t.h);
+        HIP_OK(hipGetLastError());
+        return cache.emplace(key, t).first->second;
+    }
+
+public:
+    static ntt_engine& instance() { static ntt_engine e; return e; }
+
+    // in-place transform of a DEVICE buffer of 2^lg elements on |stream|
+    void run(const gpu_info& gpu, F* d, unsigned lg, int order, int direction, int type, hipStream_t stream)
+    {
+        if (lg == 0) return;                                        // ntt/ntt.cuh:220-221
+        if (lg > F::TWO_ADICITY || order < 0 || order > 3) HIP_OK(hipErrorInvalidValue);
+        const int inverse = direction == NTT_INVERSE;
+        const table_set& ts = tables(gpu.hip_id, lg, inverse, stream);
+        ntt_tables<F> T{ts.lo, ts.hi, lg, ts.h, ts.scale}, G{ts.glo, ts.ghi, lg, ts.h, ts.scale};
+        const size_t n = (size_t)1 << lg;
+        const unsigned egrid = (unsigned)((n + 255) / 256);
+
+        bool bitrev, gs;
+        switch (order) {
+            case NTT_NN: hipLaunchKernelGGL(k_bitrev<F>, dim3(egrid), dim3(256), 0, stream, d, lg);
+                         bitrev = true;  gs = false; break;
+            case NTT_NR: bitrev = false; gs = true;  break;
+            case NTT_RN: bitrev = true;  gs = false; break;
+            default:     bitrev = true;  gs = true;  break;
+        }
+        if (!inverse && type == NTT_COSET)
+            hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
+
+        ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE);
+        for (unsigned i = 0; i < pl.npass; i++) {
+            ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
+            P.apply_scale = inverse && i == pl.npass - 1;
+            size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
+            unsigned tiles = (unsigned)(n / tile_elems);
+            size_t lds = (tile_elems + ((size_t)1 << (P.S - 1))) * sizeof(F);
+            if (gs) hipLaunchKernelGGL((k_ntt_pass<F, true>), dim3(tiles), dim3(256), lds, stream, d, T, P);
+            else    hipLaunchKernelGGL((k_ntt_pass<F, false>), dim3(tiles), dim3(256), lds, stream, d, T, P);
+        }
+        if (inverse && type == NTT_COSET)
+            hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)!bitrev);
+        if (order == NTT_RR)
+            hipLaunchKernelGGL(k_bitrev<F>, dim3(egrid), dim3(256), 0, stream, d, lg);
+        HIP_OK(hipGetLastError());
+    }
+};
+
+} // namespace sppark_amd

@@ -1,0 +1,74 @@
+// HOST EMULATION TEST HARNESS for the NTT kernels (tests only; see emu_msm.cpp).
+// Runs the phase functions of sppark_amd/csrc/ntt/ntt_kernels.hpp for every
+// (tile, thread) the GPU grid would cover, in the driver's launch order.
+#define SPPARK_HOST_EMULATION 1
+#include "../../sppark_amd/csrc/ntt/ntt_kernels.hpp"
+#include <vector>
+#include <cstring>
+using namespace sppark_amd;
+
+#if defined(FEATURE_GOLDILOCKS)
+typedef gl64_dev F;
+static const unsigned LG_LINE = 4, LG_TILE = 12;
+#else
+typedef bb31_dev F;
+static const unsigned LG_LINE = 5, LG_TILE = 13;
+#endif
+
+static F finv(F a) { return field_pow(a, (u64)F::MOD - 2); }
+
+extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
+{
+    if (lg == 0) return 0;
+    F* d = (F*)inout;
+    const size_t n = (size_t)1 << lg;
+    const int inverse = direction == 1;
+    unsigned h = lg < 12 ? lg : 12;
+    std::vector<F> lo(1u << h), hi((size_t)1 << (lg - h)), glo(1u << h), ghi((size_t)1 << (lg - h));
+    F w = F::top_root();
+    for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = w * w;
+    F g = F::group_gen();
+    if (inverse) { w = finv(w); g = finv(g); }
+    for (size_t k = 0; k < std::max(lo.size(), hi.size()); k++) {
+        table_item(lo.data(), hi.data(), w, lg, h, k);
+        table_item(glo.data(), ghi.data(), g, lg, h, k);
+    }
+    F two = F::one() + F::one();
+    ntt_tables<F> T{lo.data(), hi.data(), lg, h, finv(field_pow(two, lg))}, G{glo.data(), ghi.data(), lg, h, F::one()};
+
+    bool bitrev, gs;
+    switch (order) {
+        case 0: for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i); bitrev = true; gs = false; break;
+        case 1: bitrev = false; gs = true; break;
+        case 2: bitrev = true; gs = false; break;
+        default: bitrev = true; gs = true; break;
+    }
+    if (!inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)bitrev, i);
+
+    ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE);
+    for (unsigned i = 0; i < pl.npass; i++) {
+        ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
+        P.apply_scale = inverse && i == pl.npass - 1;
+        size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
+        std::vector<F> tile(tile_elems), inner((size_t)1 << (P.S - 1));
+        for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {
+            for (unsigned tid = 0; tid < nt; tid++) ntt_phase_inner_table(inner.data(), T, P.S, tid, nt);
+            for (unsigned tid = 0; tid < nt; tid++) {
+                if (gs) ntt_phase_load<F, true>(tile.data(), d, T, P, tile_id, tid, nt);
+                else    ntt_phase_load<F, false>(tile.data(), d, T, P, tile_id, tid, nt);
+            }
+            for (unsigned t = 0; t < P.S; t++)
+                for (unsigned tid = 0; tid < nt; tid++) {
+                    if (gs) ntt_phase_stage<F, true>(tile.data(), inner.data(), P, t, tid, nt);
+                    else    ntt_phase_stage<F, false>(tile.data(), inner.data(), P, t, tid, nt);
+                }
+            for (unsigned tid = 0; tid < nt; tid++) {
+                if (gs) ntt_phase_store<F, true>(d, tile.data(), T, P, tile_id, tid, nt);
+                else    ntt_phase_store<F, false>(d, tile.data(), T, P, tile_id, tid, nt);
+            }
+        }
+    }
+    if (inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)!bitrev, i);
+    if (order == 3) for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i);
+    return 0;
+}

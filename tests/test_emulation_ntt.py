@@ -1,0 +1,44 @@
+"""CPU: NTT kernel phase functions run on the host (tests/emu/emu_ntt.cpp) vs the oracle."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import recipe
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _emu(feature):
+    so = os.path.join(HERE, "emu", "libemu_ntt_%s.so" % feature)
+    src = os.path.join(HERE, "emu", "emu_ntt.cpp")
+    csrc = os.path.join(os.path.dirname(HERE), "sppark_amd", "csrc")
+    newest = max([os.stat(src).st_mtime] + [os.stat(os.path.join(r, f)).st_mtime for r, _, fs in os.walk(csrc) for f in fs])
+    if not os.path.exists(so) or os.stat(so).st_mtime < newest:
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
+                               "-DFEATURE_" + feature, "-o", so, src])
+    L = ctypes.CDLL(so)
+    L.emu_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+    return L
+
+
+@pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR")])
+def test_ntt_kernels_on_host(oracle, field, feature):
+    O = oracle
+    L = _emu(feature)
+    f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+    for lg in list(range(1, 15)) + [16]:
+        x = recipe.ntt_input(field, lg, 100 + lg)
+        for order in range(4):
+            for direction in range(2):
+                for typ in range(2):
+                    if lg > 13 and (typ == 1 or order in (0, 3)):
+                        continue
+                    y = x.copy()
+                    L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 10 else 256)
+                    assert (y == f(x, order, direction, typ)).all(), (field, lg, order, direction, typ)

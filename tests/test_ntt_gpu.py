@@ -1,0 +1,107 @@
+"""GPU parity tests for the NTT hot path, through the C ABI.  Outputs are unique
+bit patterns (canonical u64 / Montgomery u32 < p), so equality is exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import recipe
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIELDS = ["gl64", "bb31"]
+
+
+def _oracle_fn(O, field):
+    return O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+
+
+def test_ntt_golden_vectors(oracle, libs):
+    """vectors from the independent big-int DFT in tests/golden/make_golden.py"""
+    import sppark_amd
+    for c in json.load(open(os.path.join(HERE, "golden", "ntt_golden.json"))):
+        dt = np.uint64 if c["field"] == "gl64" else np.uint32
+        x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt).copy()
+        e = np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)
+        sppark_amd.compute_ntt(0, x, c["order"], c["direction"], c["type"], c["field"])
+        assert (x == e).all(), c
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ntt_vs_oracle_all_modes(oracle, libs, field):
+    import sppark_amd
+    O = oracle
+    f = _oracle_fn(O, field)
+    for lg in list(range(1, 15)) + [16, 18, 20]:
+        x = recipe.ntt_input(field, lg, 7 + lg)
+        for order in range(4):
+            for direction in range(2):
+                for typ in range(2):
+                    if lg > 16 and (typ == 1 or direction == 1) and order != 1:
+                        continue
+                    y = x.copy()
+                    sppark_amd.compute_ntt(0, y, order, direction, typ, field)
+                    assert (y == f(x, order, direction, typ)).all(), (field, lg, order, direction, typ)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ntt_reference_test_shapes(oracle, libs, field):
+    """poc/ntt-cuda/tests/ntt.rs:9-78 and goldilocks_test.go:11-32:
+    NTT_NN == NTT_RR; iNTT(NTT(v)) == v in NN and RR; iNTT_RN(NTT_NR(v)) == v."""
+    import sppark_amd
+    from sppark_amd import NTTInputOutputOrder as Ord
+    top = 24 if field == "gl64" else 24
+    for lg in list(range(1, 21)) + [22, top]:
+        v = recipe.ntt_input(field, lg, lg)
+        nn = sppark_amd.NTT(0, v.copy(), Ord.NN, field)
+        rr = sppark_amd.NTT(0, v.copy(), Ord.RR, field)
+        assert (nn == rr).all(), lg
+        assert (sppark_amd.iNTT(0, nn.copy(), Ord.NN, field) == v).all(), lg
+        assert (sppark_amd.iNTT(0, rr.copy(), Ord.RR, field) == v).all(), lg
+        nr = sppark_amd.NTT(0, v.copy(), Ord.NR, field)
+        assert (sppark_amd.iNTT(0, nr, Ord.RN, field) == v).all(), lg
+        c = sppark_amd.coset_NTT(0, v.copy(), Ord.NN, field)
+        assert (sppark_amd.coset_iNTT(0, c, Ord.NN, field) == v).all(), lg
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ntt_linearity_full_size(libs, field):
+    """2^24 (BASELINE size): NTT(a) + NTT(b) == NTT(a + b), on device buffers."""
+    import torch
+    import sppark_amd
+    from sppark_amd import NTTInputOutputOrder as Ord
+    lg = 24
+    p = 0xffffffff00000001 if field == "gl64" else 0x78000001
+    a = recipe.ntt_input(field, lg, 1); b = recipe.ntt_input(field, lg, 2)
+    if field == "gl64":
+        s = a + b
+        s = np.where(s < a, s + np.uint64(0xffffffff), s)             # wrapped: + 2^64 mod p
+        s = np.where(s >= np.uint64(p), s - np.uint64(p), s)
+    else:
+        s = ((a.astype(np.uint64) + b) % p).astype(np.uint32)
+    def ntt_dev(x):
+        t = torch.from_numpy(x.view(np.int64 if field == "gl64" else np.int32)).cuda()
+        sppark_amd.NTT(0, t, Ord.NR, field, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return t.cpu().numpy().view(x.dtype)
+    A, B, S = ntt_dev(a), ntt_dev(b), ntt_dev(s)
+    if field == "gl64":
+        t = A + B
+        t = np.where(t < A, t + np.uint64(0xffffffff), t)
+        t = np.where(t >= np.uint64(p), t - np.uint64(p), t)
+    else:
+        t = ((A.astype(np.uint64) + B) % p).astype(np.uint32)
+    assert (t == S).all()
+
+
+def test_ntt_lg0_noop_and_errors(libs):
+    import sppark_amd
+    from sppark_amd import ffi
+    x = np.array([5], dtype=np.uint64)
+    sppark_amd.NTT(0, x, sppark_amd.NTTInputOutputOrder.NN)
+    assert x[0] == 5
+    with pytest.raises(ValueError):
+        sppark_amd.NTT(0, np.zeros(3, dtype=np.uint64), sppark_amd.NTTInputOutputOrder.NN)
+    with pytest.raises(ffi.SpparkError):                     # bad device id -> error, not a crash
+        sppark_amd.NTT(99, np.zeros(8, dtype=np.uint64), sppark_amd.NTTInputOutputOrder.NN)

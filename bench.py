@@ -132,9 +132,16 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import oracle as O                                      # cpu_baseline leg only
         cores = len(os.sched_getaffinity(0))
-        m = 1 << min(args.lg, 18 if cores >= 16 else 16)
+        # size the sample for ~15 s of CPU work from a 2^16 probe (config 1 of BASELINE.json)
+        hp = pts[:1 << 16].cpu().numpy(); hs = sc[:1 << 16].cpu().numpy()
+        t1 = time.perf_counter()
+        O.msm_affine(O.BLS12_381, hp, hs, algo=0, param=cores)
+        probe = time.perf_counter() - t1
+        lgm = 16
+        while lgm < min(args.lg, 24) and probe * (1 << (lgm + 1 - 16)) * 0.6 < 15.0:
+            lgm += 1
+        m = 1 << lgm
         hp = pts[:m].cpu().numpy(); hs = sc[:m].cpu().numpy()
-        O.msm_affine(O.BLS12_381, hp[:4096], hs[:4096], algo=0, param=cores)      # warm-up
         t1 = time.perf_counter()
         ref = O.msm_affine(O.BLS12_381, hp, hs, algo=0, param=cores)
         dt = time.perf_counter() - t1

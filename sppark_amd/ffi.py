@@ -38,6 +38,13 @@ def load(name):
     when the HIP library has not been built -- there is no fallback."""
     if name in _LIBS:
         return _LIBS[name]
+    # torch wheels bundle their own HIP runtime; if /opt/rocm's copy gets loaded
+    # first (as a dependency of our library) torch later reports no GPU.  Import
+    # torch first so that one runtime serves both.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path(name)
     if not os.path.exists(path):
         raise FileNotFoundError(

@@ -51,3 +51,42 @@ SPPARK_FFI RustError compute_ntt(size_t device_id, void* inout, uint32_t lg_doma
 SPPARK_FFI RustError sppark_ntt(size_t device_id, void* inout, uint32_t lg_domain_size,
                                 int ntt_order, int ntt_direction, int ntt_type, void* stream)
 {   return guarded([&] { ntt_any(device_id, inout, lg_domain_size, ntt_order, ntt_direction, ntt_type, (hipStream_t)stream); });   }
+
+// ---- device test hook: element-wise field ops (tests/test_ntt_gpu.py) -----------
+// op 0: a+b  1: a-b  2: a*b  3: a*2^k (gl64 only; k = b's low byte mod 192)
+__global__ void k_small_field_op(fr_t* out, const fr_t* a, const fr_t* b, unsigned n, int op)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fr_t x = a[i], y = b[i], r;
+    if (op == 0) r = x + y;
+    else if (op == 1) r = x - y;
+    else if (op == 2) r = x * y;
+    else if (op == 4) { r = x; for (int k = 0; k < 12; k++) r = r * r; }
+    else if (op == 5) r = field_pow(x, (u64)(y.v & 0xffff));
+    else if (op == 6) { r = x; if (i & 1) { for (unsigned k = 0; k < (i & 15); k++) r = r * r + y; } }
+    else {
+#if defined(FEATURE_GOLDILOCKS)
+        r = gl64_dev::mul_pow2(x, (unsigned)(y.v & 0xff) % 192);
+#else
+        r = x;
+#endif
+    }
+    out[i] = r;
+}
+
+SPPARK_FFI RustError sppark_devtest_small_field_op(int op, void* out, const void* a, const void* b, size_t n)
+{
+    return guarded([&] {
+        (void)select_gpu(-1);
+        size_t bytes = n * sizeof(fr_t);
+        fr_t *d_a, *d_b, *d_o;
+        HIP_OK(hipMalloc((void**)&d_a, bytes)); HIP_OK(hipMalloc((void**)&d_b, bytes)); HIP_OK(hipMalloc((void**)&d_o, bytes));
+        HIP_OK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_small_field_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost));
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+    });
+}

@@ -16,6 +16,10 @@
 #pragma once
 #include "mont_dev.hpp"     // SPPARK_DEVFN, u32/u64
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SPPARK_GL64_PLAIN_C)
+# define SPPARK_GL64_ASM 1
+#endif
+
 namespace sppark_amd {
 
 struct gl64_dev {
@@ -31,42 +35,132 @@ struct gl64_dev {
     SPPARK_DEVFN static gl64_dev top_root() { return from_raw(TOP_ROOT); }
     SPPARK_DEVFN static gl64_dev group_gen() { return from_raw(GROUP_GEN); }
 
+    // Carry-generating VALU ops are the expensive ones on gfx950 (v_add_co/v_addc_co
+    // issue at half the rate of plain 32-bit ops, and hipcc's u64 compare+select
+    // lowering adds v_cmp_*_u64 + v_cndmask + s_nop on top), so the modular
+    // corrections are written as explicit carry chains:
+    //   a + b: both corrections ("sum wrapped 2^64" and "sum >= p") are the same
+    //          operation, + (2^32 - 1) mod 2^64, needed iff either carry is set.
+    //   a - b: on borrow, - (2^32 - 1).
     SPPARK_DEVFN friend gl64_dev operator+(gl64_dev a, gl64_dev b)
     {
+#if defined(SPPARK_GL64_ASM)
+        u32 a0 = (u32)a.v, a1 = (u32)(a.v >> 32), b0 = (u32)b.v, b1 = (u32)(b.v >> 32);
+        u32 lo, hi, ulo, uhi;
+        u64 c1, c2;
+        // gfx940+ needs two wait states between a VALU that writes an SGPR pair
+        // (carry-out) and a VALU that reads it; independent instructions are
+        // placed in those slots where possible, s_nop otherwise.
+        asm("v_add_co_u32 %0, %4, %6, %8\n\t"
+            "v_add_co_u32 %2, %5, -1, %0\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %1, %4, %7, %9, %4\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %3, %5, 0, %1, %5\n\t"
+            "s_nop 1\n\t"
+            "s_or_b64 %4, %4, %5\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %0, %0, %2, %4\n\t"
+            "v_cndmask_b32 %1, %1, %3, %4"
+            : "=&v"(lo), "=&v"(hi), "=&v"(ulo), "=&v"(uhi), "=&s"(c1), "=&s"(c2)
+            : "v"(a0), "v"(a1), "v"(b0), "v"(b1) : "scc");      // s_or_b64 writes SCC
+        return from_raw(((u64)hi << 32) | lo);
+#else
         u64 s = a.v + b.v;
         u64 c = s < a.v;                        // wrapped: s + 2^64 = s + (2^32-1) mod p
         s += (0 - c) & 0xffffffffULL;           // cannot wrap again: a,b < p
         s -= (s >= MOD) ? MOD : 0;
         return from_raw(s);
+#endif
     }
     SPPARK_DEVFN friend gl64_dev operator-(gl64_dev a, gl64_dev b)
     {
+#if defined(SPPARK_GL64_ASM)
+        u32 a0 = (u32)a.v, a1 = (u32)(a.v >> 32), b0 = (u32)b.v, b1 = (u32)(b.v >> 32);
+        u32 lo, hi, t;
+        asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+            "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+            : "=&v"(lo), "=&v"(hi), "=&v"(t)
+            : "v"(a0), "v"(a1), "v"(b0), "v"(b1) : "vcc");
+        return from_raw(((u64)hi << 32) | lo);
+#else
         u64 d = a.v - b.v;
         u64 bw = a.v < b.v;
         d -= (0 - bw) & 0xffffffffULL;          // - 2^64 = -(2^32-1) mod p ; a,b canonical => no second wrap
         return from_raw(d);
-    }
-    SPPARK_DEVFN static u64 mulhi(u64 a, u64 b)
-    {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return __umul64hi(a, b);
-#else
-        return (u64)(((unsigned __int128)a * b) >> 64);
 #endif
     }
     SPPARK_DEVFN friend gl64_dev operator*(gl64_dev a, gl64_dev b)
     {
-        u64 lo = a.v * b.v, hi = mulhi(a.v, b.v);
-        u64 hl = hi & 0xffffffffULL, hh = hi >> 32;
-        // x = lo + hl*2^64 + hh*2^96  =  lo - hh + hl*(2^32-1)   (mod p)
-        u64 t = lo - hh;
-        t -= (0 - (u64)(lo < hh)) & 0xffffffffULL;
-        u64 m = (hl << 32) - hl;
-        u64 s = t + m;
-        s += (0 - (u64)(s < t)) & 0xffffffffULL;
-        s -= (s >= MOD) ? MOD : 0;
-        return from_raw(s);
+        // 64x64 -> 128 as exactly four v_mad_u64_u32 (schoolbook on 32-bit halves; each
+        // partial product absorbs a 32-bit carry-in without overflowing 64 bits)
+        const u32 a0 = (u32)a.v, a1 = (u32)(a.v >> 32), b0 = (u32)b.v, b1 = (u32)(b.v >> 32);
+        const u64 p00 = (u64)a0 * b0;
+        const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+        const u64 p10 = (u64)a1 * b0 + (u32)p01;
+        const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+        const u32 w0 = (u32)p00, w1 = (u32)p10, w2 = (u32)p11, w3 = (u32)(p11 >> 32);
+        // x = w0 + w1*2^32 + w2*2^64 + w3*2^96 = (w1:w0) - w3 + w2*(2^32-1)   (mod p)
+        gl64_dev t = canon(((u64)w1 << 32) | w0) - from_raw(w3);
+        return t + from_raw(((u64)w2 << 32) - w2);
     }
+    // x >= p ? x - p : x      (x - p = x + 2^32 - 1 mod 2^64, and x >= p iff that addition carries)
+    SPPARK_DEVFN static gl64_dev canon(u64 x)
+    {
+#if defined(SPPARK_GL64_ASM)
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32), u0, u1;
+        asm("v_add_co_u32 %0, vcc, -1, %2\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %3, vcc\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %0, %2, %0, vcc\n\t"
+            "v_cndmask_b32 %1, %3, %1, vcc"
+            : "=&v"(u0), "=&v"(u1) : "v"(x0), "v"(x1) : "vcc");
+        return from_raw(((u64)u1 << 32) | u0);
+#else
+        return from_raw(x >= MOD ? x - MOD : x);
+#endif
+    }
+
+    // lo + hi*2^64 (mod p), canonical
+    SPPARK_DEVFN static gl64_dev reduce_u96(u64 lo, u32 hi)
+    {   return canon(lo) + from_raw(((u64)hi << 32) - hi);   }
+    // x * 2^e, e in [0, 192): 2 has order 192 in this field (2^96 = -1) and every
+    // root of unity of order <= 64 is a power of two -- w_64 = 2^39 in the
+    // reference's table (ntt/parameters/goldilocks.h:86-93: 0x8000000000 = 2^39).
+    // With e known at compile time (unrolled butterflies) this is a handful of
+    // shifts/adds instead of a 64x64 product.
+    SPPARK_DEVFN static gl64_dev mul_pow2(gl64_dev x, unsigned e)
+    {
+        const bool neg = e >= 96;
+        if (neg) e -= 96;
+        const unsigned q = e >> 5, sh = e & 31;
+        const u32 x0 = (u32)x.v, x1 = (u32)(x.v >> 32);
+        const u32 y0 = x0 << sh;
+        const u32 y1 = sh ? (x1 << sh) | (x0 >> (32 - sh)) : x1;
+        const u32 y2 = sh ? x1 >> (32 - sh) : 0;
+        gl64_dev r;
+        if (q == 0)      r = reduce_u96(((u64)y1 << 32) | y0, y2);
+        else if (q == 1) r = reduce_u96((u64)y0 << 32, y1) - from_raw(y2);
+        else             r = reduce_u96(0, y0) - from_raw(y1) - from_raw((u64)y2 << 32);
+        return neg ? from_raw(0) - r : r;
+    }
+    // x * w_{2^R}^k with the reference's root convention; INV selects w^-1
+    template<bool INV>
+    SPPARK_DEVFN static gl64_dev mul_root(gl64_dev x, unsigned R, unsigned k, const gl64_dev*)
+    {
+        const unsigned ER[7] = {0, 96, 48, 120, 156, 78, 39};       // w_{2^R} = 2^ER[R]
+        unsigned e = (ER[R] * k) % 192;
+        if (INV) e = (192 - e) % 192;
+        return e ? mul_pow2(x, e) : x;
+    }
+    static constexpr bool SHIFT_ROOTS = true;
 };
 
 struct bb31_dev {
@@ -93,6 +187,11 @@ struct bb31_dev {
         u32 r = (u32)u; r -= (r >= MOD) ? MOD : 0;
         return from_raw(r);
     }
+    // x * w_{2^R}^k from the per-(size, direction) table inner[(1 << R) + k]
+    template<bool INV>
+    SPPARK_DEVFN static bb31_dev mul_root(bb31_dev x, unsigned R, unsigned k, const bb31_dev* inner)
+    {   return k ? x * inner[(1u << R) + k] : x;   }
+    static constexpr bool SHIFT_ROOTS = false;
 };
 
 template<class F> SPPARK_DEVFN F field_pow(F b, u64 e)

@@ -40,7 +40,7 @@ template<> struct host_field<bb31_dev> {                        // canonical ari
 
 template<class F>
 class ntt_engine {
-    struct table_set { F *lo, *hi, *glo, *ghi; unsigned h; F scale; };
+    struct table_set { F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale; };
     std::map<std::tuple<int, unsigned, int>, table_set> cache;     // (hip device, lg, inverse)
     std::mutex mtx;
 
@@ -57,16 +57,16 @@ class ntt_engine {
         table_set t;
         t.h = lg < 12 ? lg : 12;
         size_t nlo = (size_t)1 << t.h, nhi = (size_t)1 << (lg - t.h);
-        HIP_OK(hipMalloc((void**)&t.lo, 2 * (nlo + nhi) * sizeof(F)));
-        t.hi = t.lo + nlo; t.glo = t.hi + nhi; t.ghi = t.glo + nlo;
+        HIP_OK(hipMalloc((void**)&t.lo, (2 * (nlo + nhi) + 512) * sizeof(F)));
+        t.hi = t.lo + nlo; t.glo = t.hi + nhi; t.ghi = t.glo + nlo; t.inner = t.ghi + nhi;
         u64 w = H::top_root();
         for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = H::mul(w, w);
         u64 g = H::gen();
         if (inverse) { w = H::inv(w); g = H::inv(g); }
         t.scale = H::wire(H::inv(H::two_pow(lg)));
-        unsigned grid = (unsigned)((std::max(nlo, nhi) + 255) / 256);
-        hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.lo, t.hi, H::wire(w), lg, t.h);
-        hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.glo, t.ghi, H::wire(g), lg, t.h);
+        unsigned grid = (unsigned)((std::max<size_t>(std::max(nlo, nhi), 512) + 255) / 256);
+        hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.lo, t.hi, t.inner, H::wire(w), lg, t.h);
+        hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.glo, t.ghi, (F*)nullptr, H::wire(g), lg, t.h);
         HIP_OK(hipGetLastError());
         return cache.emplace(key, t).first->second;
     }
@@ -81,7 +81,7 @@ public:
         if (lg > F::TWO_ADICITY || order < 0 || order > 3) HIP_OK(hipErrorInvalidValue);
         const int inverse = direction == NTT_INVERSE;
         const table_set& ts = tables(gpu.hip_id, lg, inverse, stream);
-        ntt_tables<F> T{ts.lo, ts.hi, lg, ts.h, ts.scale}, G{ts.glo, ts.ghi, lg, ts.h, ts.scale};
+        ntt_tables<F> T{ts.lo, ts.hi, ts.inner, lg, ts.h, ts.scale}, G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale};
         const size_t n = (size_t)1 << lg;
         const unsigned egrid = (unsigned)((n + 255) / 256);
 
@@ -102,9 +102,16 @@ public:
             P.apply_scale = inverse && i == pl.npass - 1;
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);
-            size_t lds = (tile_elems + ((size_t)1 << (P.S - 1))) * sizeof(F);
-            if (gs) hipLaunchKernelGGL((k_ntt_pass<F, true>), dim3(tiles), dim3(256), lds, stream, d, T, P);
-            else    hipLaunchKernelGGL((k_ntt_pass<F, false>), dim3(tiles), dim3(256), lds, stream, d, T, P);
+            size_t lds = ntt_lds_elems(P) * sizeof(F);
+#define SPPARK_NTT_LAUNCH(R1, R2)                                                                              \
+            do {                                                                                               \
+                if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, true, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);   \
+                          else         hipLaunchKernelGGL((k_ntt_pass<F, true, false, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P); } \
+                else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, false, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);  \
+                          else         hipLaunchKernelGGL((k_ntt_pass<F, false, false, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P); } \
+            } while (0)
+            SPPARK_NTT_DISPATCH_S(P.S, SPPARK_NTT_LAUNCH);
+#undef SPPARK_NTT_LAUNCH
         }
         if (inverse && type == NTT_COSET)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)!bitrev);

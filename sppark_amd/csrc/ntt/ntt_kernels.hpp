@@ -2,22 +2,32 @@
 //
 // Same observable semantics as the reference's driver (ntt/ntt.cuh:161-213:
 // NN = bit_rev + CT, NR = GS, RN = CT, RR = GS + bit_rev; coset scaling of
-// ntt/kernels.cu:131-153) but a different decomposition: the transform is cut
-// into PASSES, each pass is a batch of independent 2^S-point transforms done
-// entirely in LDS on a tile of [2^S rows] x [C adjacent columns] (C*sizeof(F)
-// = one 128-byte line, so the strided passes stay coalesced), followed (GS) or
-// preceded (CT) by ONE diagonal twiddle multiplication per element:
+// ntt/kernels.cu:131-153) but a different decomposition.  The transform is cut
+// into PASSES of S <= 8 stages; a pass is a batch of independent 2^S-point
+// transforms on a tile of [2^S rows] x [C adjacent columns] (C*sizeof(F) = one
+// 128-byte line, so strided passes stay coalesced) followed (GS) or preceded
+// (CT) by ONE diagonal twiddle per element:
 //
 //   GS/DIF pass on a sub-problem of size n_cur = 2^S * Q, element (mid, lo):
 //        y[mid][lo] = DIF_{2^S}(x[.][lo])[mid] * w_{n_cur}^(lo * rev_S(mid))
-//   and the next pass works on the Q-sized rows independently.  CT/DIT is the
+//   the next pass works on the Q-sized rows independently.  CT/DIT is the
 //   transposed network: passes in reverse order, twiddle first.
 //
-// Twiddles w_n^e come from two tables of <= 2^12 entries each (w^e_lo, w^(e_hi<<h))
+// Inside a pass the 2^S-point transform is itself split 2^R1 x 2^R2 and done
+// in REGISTERS: each lane loads 2^R1 (<= 16) elements straight from HBM, runs
+// the R1 butterfly stages on them, applies the w_{2^S} twiddle, exchanges once
+// through LDS, runs the R2 stages, applies the inter-pass twiddle and stores
+// straight back to HBM -- one LDS write + one LDS read per element per pass
+// (the reference's narrow kernels, ntt/kernels/ct_mixed_radix_narrow.cu:98-154,
+// do 5 shuffle stages + shared-memory stages on 32-lane warps).
+// For Goldilocks the in-register butterflies need no multiplier at all: every
+// root of order <= 64 is a power of two (gl64_dev::mul_pow2).
+//
+// Twiddles w_n^e come from two tables of <= 2^12 entries (w^e_lo, w^(e_hi<<h))
 // instead of the reference's four 7-bit windows (ntt/parameters.cuh:72-145).
 //
-// Each phase is a SPPARK_DEVFN function of (tid, nthreads) so that the host
-// emulation harness (tests/emu) can run the same index math on the CPU.
+// Each round is a SPPARK_DEVFN function of (tid, nthreads) so that the host
+// emulation harness (tests/emu) runs the same index math on the CPU.
 #pragma once
 #include "../ff/small_fields_dev.hpp"
 
@@ -26,13 +36,14 @@ namespace sppark_amd {
 template<class F> struct ntt_tables {
     const F* lo;        // w^k,            k < 2^h
     const F* hi;        // w^(k << h),     k < 2^(lg_n - h)
+    const F* inner;     // inner[(1 << R) + k] = w_{2^R}^k, R <= 8, k < 2^R
     unsigned lg_n, h;
     F scale;            // 1/n for the inverse transform (Montgomery form where applicable)
 };
 
 struct ntt_pass {
     unsigned lg_cur;    // log2 of the sub-problem size this pass splits
-    unsigned S;         // stages done in LDS
+    unsigned S;         // stages in this pass (<= 8)
     unsigned lgC;       // log2 columns (lo) per tile
     unsigned lgG;       // log2 sub-problems per tile (only when the tile spans all Q columns)
     int apply_scale;    // multiply by tables.scale when storing (inverse, last executed pass)
@@ -52,92 +63,187 @@ SPPARK_DEVFN unsigned bit_rev32(unsigned x, unsigned bits)
 template<class F> SPPARK_DEVFN F ntt_twiddle(const ntt_tables<F>& T, size_t e)
 {   return T.lo[e & (((size_t)1 << T.h) - 1)] * T.hi[e >> T.h];   }
 
-// inner[k] = w_{2^S}^k, k < 2^(S-1)
-template<class F>
-SPPARK_DEVFN void ntt_phase_inner_table(F* inner, const ntt_tables<F>& T, unsigned S, unsigned tid, unsigned nt)
+// in-register 2^R-point transforms on x[0 .. 2^R)
+template<class F, bool INV, unsigned R>
+SPPARK_DEVFN void radix_dif(F* x, const F* inner)              // natural in -> bit-reversed out
 {
-    for (unsigned k = tid; k < (1u << (S - 1)); k += nt)
-        inner[k] = ntt_twiddle(T, (size_t)k << (T.lg_n - S));
+    if (R == 0) return;
+    #pragma unroll
+    for (unsigned t = 0; t < R; t++) {
+        const unsigned lgh = R - 1 - t, half = 1u << lgh;
+        #pragma unroll
+        for (unsigned j = 0; j < ((1u << R) >> 1); j++) {
+            const unsigned off = j & (half - 1), m0 = ((j >> lgh) << (lgh + 1)) + off, m1 = m0 + half;
+            F a = x[m0], b = x[m1];
+            x[m0] = a + b;
+            x[m1] = F::template mul_root<INV>(a - b, R, off << t, inner);
+        }
+    }
+}
+template<class F, bool INV, unsigned R>
+SPPARK_DEVFN void radix_dit(F* x, const F* inner)              // bit-reversed in -> natural out
+{
+    if (R == 0) return;
+    #pragma unroll
+    for (unsigned t = 0; t < R; t++) {
+        const unsigned lgh = t, half = 1u << lgh;
+        #pragma unroll
+        for (unsigned j = 0; j < ((1u << R) >> 1); j++) {
+            const unsigned off = j & (half - 1), m0 = ((j >> lgh) << (lgh + 1)) + off, m1 = m0 + half;
+            F a = x[m0], b = F::template mul_root<INV>(x[m1], R, off << (R - 1 - t), inner);
+            x[m0] = a + b;
+            x[m1] = a - b;
+        }
+    }
 }
 
-template<class F, bool DIF>
-SPPARK_DEVFN void ntt_phase_load(F* tile, const F* data, const ntt_tables<F>& T, const ntt_pass& P,
+// tile geometry helpers ------------------------------------------------------
+struct ntt_tile_geom { size_t row0; unsigned c0, lgQ; };
+SPPARK_DEVFN ntt_tile_geom ntt_geom(const ntt_pass& P, size_t tile_id)
+{
+    ntt_tile_geom g; g.lgQ = P.lg_cur - P.S;
+    if (P.lgG) { g.row0 = (tile_id << P.lgG) << P.S; g.c0 = 0; }
+    else {
+        size_t tiles_per_sub = (size_t)1 << (g.lgQ - P.lgC);
+        g.row0 = (tile_id / tiles_per_sub) << P.S;
+        g.c0 = (unsigned)(tile_id % tiles_per_sub) << P.lgC;
+    }
+    return g;
+}
+// LDS index of tile row gm (= g*2^S + mid), column c.  One pad row (C elements
+// = 32 banks) per 2^R2 rows: in the strided round two consecutive values of `a`
+// then land on opposite halves of the 64 banks instead of on the same ones.
+template<unsigned R2>
+SPPARK_DEVFN unsigned ntt_lds_index(unsigned gm, unsigned c, unsigned lgC)
+{   return ((gm + (gm >> R2)) << lgC) + c;   }
+
+// A work group of the HIGH-bits round: fixed (g, b, c), the 2^R1 values of a.
+// A work group of the LOW-bits round:  fixed (g, a, c), the 2^R2 values of b.
+// Row (mid) = a * 2^R2 + b.
+
+// GS/DIF pass, round 1 (high bits): HBM -> registers -> DIF_{2^R1} -> * w_{2^S}^(b*rev(a)) -> LDS
+// CT/DIT pass, round 2 (high bits): LDS -> * w_{2^S}^(b*rev(a)) -> DIT_{2^R1} -> scale -> HBM
+template<class F, bool DIF, bool INV, unsigned R1, unsigned R2>
+SPPARK_DEVFN void ntt_round_high(F* data, F* tile, const ntt_tables<F>& T, const ntt_pass& P,
                                  size_t tile_id, unsigned tid, unsigned nt)
 {
-    const unsigned lgQ = P.lg_cur - P.S, S = P.S;
-    const unsigned E = 1u << (P.lgG + S + P.lgC), C = 1u << P.lgC;
-    size_t row0; unsigned c0;                           // first (sub*2^S + mid) row, first column
-    if (P.lgG) { row0 = (tile_id << P.lgG) << S; c0 = 0; }
-    else { size_t tiles_per_sub = (size_t)1 << (lgQ - P.lgC); row0 = (tile_id / tiles_per_sub) << S; c0 = (unsigned)(tile_id % tiles_per_sub) << P.lgC; }
-    for (unsigned e = tid; e < E; e += nt) {
-        unsigned c = e & (C - 1), gm = e >> P.lgC;
-        F v = data[((row0 + gm) << lgQ) + c0 + c];
-        if (!DIF && lgQ) {                              // CT: diagonal twiddle before the local transform
-            unsigned mid = gm & ((1u << S) - 1);
-            size_t ex = (size_t)(c0 + c) * bit_rev32(mid, S);
-            v = v * ntt_twiddle(T, ex << (T.lg_n - P.lg_cur));
+    constexpr unsigned S = R1 + R2;
+    const ntt_tile_geom geo = ntt_geom(P, tile_id);
+    const unsigned ngroups = 1u << (P.lgG + R2 + P.lgC), C = 1u << P.lgC;
+    for (unsigned gi = tid; gi < ngroups; gi += nt) {
+        const unsigned c = gi & (C - 1), rest = gi >> P.lgC;
+        const unsigned b = rest & ((1u << R2) - 1), g = rest >> R2;
+        F x[1u << R1];
+        #pragma unroll
+        for (unsigned a = 0; a < (1u << R1); a++) {
+            const unsigned gm = (g << S) + (a << R2) + b;
+            if (DIF || R2 == 0) x[a] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
+            else                x[a] = tile[ntt_lds_index<R2>(gm, c, P.lgC)];
         }
-        tile[e] = v;
-    }
-}
-
-template<class F, bool DIF>
-SPPARK_DEVFN void ntt_phase_stage(F* tile, const F* inner, const ntt_pass& P, unsigned t, unsigned tid, unsigned nt)
-{
-    const unsigned S = P.S, C = 1u << P.lgC;
-    const unsigned nb = 1u << (P.lgG + S - 1 + P.lgC);
-    for (unsigned bf = tid; bf < nb; bf += nt) {
-        unsigned c = bf & (C - 1), r = bf >> P.lgC;
-        unsigned g = r >> (S - 1), j = r & ((1u << (S - 1)) - 1);
-        unsigned lgh = DIF ? S - 1 - t : t;             // log2 of the butterfly span
-        unsigned half = 1u << lgh, off = j & (half - 1), blk = j >> lgh;
-        unsigned m0 = (blk << (lgh + 1)) + off, m1 = m0 + half;
-        unsigned i0 = (((g << S) + m0) << P.lgC) + c, i1 = (((g << S) + m1) << P.lgC) + c;
-        F w = inner[off << (S - 1 - lgh)];
-        F a = tile[i0], b = tile[i1];
-        if (DIF) { tile[i0] = a + b; tile[i1] = (a - b) * w; }
-        else     { F bw = b * w; tile[i0] = a + bw; tile[i1] = a - bw; }
-    }
-}
-
-template<class F, bool DIF>
-SPPARK_DEVFN void ntt_phase_store(F* data, const F* tile, const ntt_tables<F>& T, const ntt_pass& P,
-                                  size_t tile_id, unsigned tid, unsigned nt)
-{
-    const unsigned lgQ = P.lg_cur - P.S, S = P.S;
-    const unsigned E = 1u << (P.lgG + S + P.lgC), C = 1u << P.lgC;
-    size_t row0; unsigned c0;
-    if (P.lgG) { row0 = (tile_id << P.lgG) << S; c0 = 0; }
-    else { size_t tiles_per_sub = (size_t)1 << (lgQ - P.lgC); row0 = (tile_id / tiles_per_sub) << S; c0 = (unsigned)(tile_id % tiles_per_sub) << P.lgC; }
-    for (unsigned e = tid; e < E; e += nt) {
-        unsigned c = e & (C - 1), gm = e >> P.lgC;
-        F v = tile[e];
-        if (DIF && lgQ) {                               // GS: diagonal twiddle after the local transform
-            unsigned mid = gm & ((1u << S) - 1);
-            size_t ex = (size_t)(c0 + c) * bit_rev32(mid, S);
-            v = v * ntt_twiddle(T, ex << (T.lg_n - P.lg_cur));
+        if (DIF) {
+            radix_dif<F, INV, R1>(x, T.inner);
+            #pragma unroll
+            for (unsigned a = 0; a < (1u << R1); a++) {
+                if (R2) { unsigned e = b * bit_rev32(a, R1); if (e) x[a] = x[a] * T.inner[(1u << S) + e]; }
+                if (R2 == 0) {                          // single-round pass: finish here
+                    if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                    if (P.apply_scale) x[a] = x[a] * T.scale;
+                    data[((geo.row0 + (g << S) + a) << geo.lgQ) + geo.c0 + c] = x[a];
+                } else {
+                    tile[ntt_lds_index<R2>((g << S) + (a << R2) + b, c, P.lgC)] = x[a];
+                }
+            }
+        } else {
+            #pragma unroll
+            for (unsigned a = 0; a < (1u << R1); a++) {
+                if (R2) { unsigned e = b * bit_rev32(a, R1); if (e) x[a] = x[a] * T.inner[(1u << S) + e]; }
+                if (R2 == 0 && geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+            }
+            radix_dit<F, INV, R1>(x, T.inner);
+            #pragma unroll
+            for (unsigned a = 0; a < (1u << R1); a++) {
+                if (P.apply_scale) x[a] = x[a] * T.scale;
+                data[((geo.row0 + (g << S) + (a << R2) + b) << geo.lgQ) + geo.c0 + c] = x[a];
+            }
         }
-        if (P.apply_scale) v = v * T.scale;
-        data[((row0 + gm) << lgQ) + c0 + c] = v;
     }
 }
 
-template<class F, bool DIF>
+// GS/DIF pass, round 2 (low bits): LDS -> DIF_{2^R2} -> * w_{n_cur}^(lo*rev_S(mid)) -> scale -> HBM
+// CT/DIT pass, round 1 (low bits): HBM -> * w_{n_cur}^(lo*rev_S(mid)) -> DIT_{2^R2} -> LDS
+template<class F, bool DIF, bool INV, unsigned R1, unsigned R2>
+SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const ntt_pass& P,
+                                size_t tile_id, unsigned tid, unsigned nt)
+{
+    constexpr unsigned S = R1 + R2;
+    const ntt_tile_geom geo = ntt_geom(P, tile_id);
+    const unsigned ngroups = 1u << (P.lgG + R1 + P.lgC), C = 1u << P.lgC;
+    for (unsigned gi = tid; gi < ngroups; gi += nt) {
+        const unsigned c = gi & (C - 1), rest = gi >> P.lgC;
+        const unsigned a = rest & ((1u << R1) - 1), g = rest >> R1;
+        F x[1u << R2];
+        #pragma unroll
+        for (unsigned b = 0; b < (1u << R2); b++) {
+            const unsigned gm = (g << S) + (a << R2) + b;
+            if (DIF) x[b] = tile[ntt_lds_index<R2>(gm, c, P.lgC)];
+            else {
+                x[b] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
+                if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+            }
+        }
+        if (DIF) {
+            radix_dif<F, INV, R2>(x, T.inner);
+            #pragma unroll
+            for (unsigned b = 0; b < (1u << R2); b++) {
+                if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                if (P.apply_scale) x[b] = x[b] * T.scale;
+                data[((geo.row0 + (g << S) + (a << R2) + b) << geo.lgQ) + geo.c0 + c] = x[b];
+            }
+        } else {
+            radix_dit<F, INV, R2>(x, T.inner);
+            #pragma unroll
+            for (unsigned b = 0; b < (1u << R2); b++)
+                tile[ntt_lds_index<R2>((g << S) + (a << R2) + b, c, P.lgC)] = x[b];
+        }
+    }
+}
+
+template<class F, bool DIF, bool INV, unsigned R1, unsigned R2>
 __global__ __launch_bounds__(256)
 void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
 {
     extern __shared__ unsigned char ntt_lds[];
     F* tile = reinterpret_cast<F*>(ntt_lds);
-    F* inner = tile + ((size_t)1 << (P.lgG + P.S + P.lgC));
     const unsigned tid = threadIdx.x, nt = blockDim.x;
-    ntt_phase_inner_table(inner, T, P.S, tid, nt);
-    ntt_phase_load<F, DIF>(tile, data, T, P, blockIdx.x, tid, nt);
-    __syncthreads();
-    for (unsigned t = 0; t < P.S; t++) {
-        ntt_phase_stage<F, DIF>(tile, inner, P, t, tid, nt);
+    if constexpr (R2 == 0) {
+        ntt_round_high<F, DIF, INV, R1, R2>(data, tile, T, P, blockIdx.x, tid, nt);
+    } else if (DIF) {
+        ntt_round_high<F, DIF, INV, R1, R2>(data, tile, T, P, blockIdx.x, tid, nt);
         __syncthreads();
+        ntt_round_low<F, DIF, INV, R1, R2>(data, tile, T, P, blockIdx.x, tid, nt);
+    } else {
+        ntt_round_low<F, DIF, INV, R1, R2>(data, tile, T, P, blockIdx.x, tid, nt);
+        __syncthreads();
+        ntt_round_high<F, DIF, INV, R1, R2>(data, tile, T, P, blockIdx.x, tid, nt);
     }
-    ntt_phase_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+}
+
+// (R1, R2) = (ceil(S/2), floor(S/2)); CALL(R1, R2) is expanded for the pass's S
+#define SPPARK_NTT_DISPATCH_S(S, CALL)                                  \
+    switch (S) {                                                        \
+        case 1: CALL(1, 0); break; case 2: CALL(1, 1); break;           \
+        case 3: CALL(2, 1); break; case 4: CALL(2, 2); break;           \
+        case 5: CALL(3, 2); break; case 6: CALL(3, 3); break;           \
+        case 7: CALL(4, 3); break; default: CALL(4, 4); break;          \
+    }
+
+// LDS elements a tile needs (with the pad words of ntt_lds_index)
+static inline size_t ntt_lds_elems(const ntt_pass& P)
+{
+    unsigned R2 = P.S / 2;
+    if (R2 == 0) return 0;
+    size_t rows = (size_t)1 << (P.lgG + P.S);
+    return (rows + (rows >> R2)) << P.lgC;
 }
 
 // bit-reversal permutation in place (NN and RR orders; ntt/ntt.cuh:44-79)
@@ -170,16 +276,21 @@ __global__ __launch_bounds__(256) void k_coset(F* data, ntt_tables<F> G, int bit
     if (i < ((size_t)1 << G.lg_n)) coset_item(data, G, bitrev, i);
 }
 
-// table generation: lo[k] = base^k (k < 2^h), hi[k] = (base^(2^h))^k (k < 2^(lg_n-h))
+// table generation: lo[k] = base^k (k < 2^h), hi[k] = (base^(2^h))^k (k < 2^(lg_n-h)),
+// inner[(1 << R) + k] = w_{2^R}^k = base^(k << (lg_n - R)) for R <= min(8, lg_n)
 template<class F>
-SPPARK_DEVFN void table_item(F* lo, F* hi, F base, unsigned lg_n, unsigned h, size_t k)
+SPPARK_DEVFN void table_item(F* lo, F* hi, F* inner, F base, unsigned lg_n, unsigned h, size_t k)
 {
     if (k < ((size_t)1 << h)) lo[k] = field_pow(base, k);
     if (k < ((size_t)1 << (lg_n - h))) { F b = base; for (unsigned s = 0; s < h; s++) b = b * b; hi[k] = field_pow(b, k); }
+    if (inner && k >= 2 && k < 512) {
+        unsigned R = 31 - __builtin_clz((unsigned)k), e = (unsigned)k - (1u << R);
+        inner[k] = R <= lg_n ? field_pow(base, (u64)e << (lg_n - R)) : F::one();
+    }
 }
 template<class F>
-__global__ __launch_bounds__(256) void k_tables(F* lo, F* hi, F base, unsigned lg_n, unsigned h)
-{   table_item(lo, hi, base, lg_n, h, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+__global__ __launch_bounds__(256) void k_tables(F* lo, F* hi, F* inner, F base, unsigned lg_n, unsigned h)
+{   table_item(lo, hi, inner, base, lg_n, h, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // ---- planning (host) ---------------------------------------------------------
 struct ntt_plan { ntt_pass pass[8]; unsigned npass; };
@@ -189,15 +300,12 @@ struct ntt_plan { ntt_pass pass[8]; unsigned npass; };
 static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg_tile)
 {
     ntt_plan pl; pl.npass = 0;
-    const unsigned Smax_strided = lg_tile - lgCmax, Smax_last = lg_tile;
-    unsigned np = 1;
-    if (lg_n > Smax_last) { np = 2; while ((np - 1) * Smax_strided + Smax_last < lg_n) np++; }
+    const unsigned Smax = 8;
+    unsigned np = (lg_n + Smax - 1) / Smax;
     unsigned rem = lg_n;
     for (unsigned i = 0; i < np; i++) {
         unsigned left = np - i;
-        unsigned S = (rem + left - 1) / left;                   // near-equal split
-        if (left > 1 && S > Smax_strided) S = Smax_strided;
-        if (left == 1) S = rem;
+        unsigned S = (rem + left - 1) / left;                   // near-equal split, <= 8
         ntt_pass p; p.lg_cur = rem; p.S = S; p.apply_scale = 0;
         unsigned lgQ = rem - S;
         if (lgQ >= lgCmax) { p.lgC = lgCmax; p.lgG = 0; }

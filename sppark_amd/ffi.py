@@ -96,6 +96,8 @@ def load(name):
         L.compute_ntt.restype = _Error
         L.sppark_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci, vp]
         L.sppark_ntt.restype = _Error
+        L.sppark_devtest_small_field_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_small_field_op.restype = _Error
     _LIBS[name] = L
     return L
 

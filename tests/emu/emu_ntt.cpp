@@ -24,17 +24,17 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     const size_t n = (size_t)1 << lg;
     const int inverse = direction == 1;
     unsigned h = lg < 12 ? lg : 12;
-    std::vector<F> lo(1u << h), hi((size_t)1 << (lg - h)), glo(1u << h), ghi((size_t)1 << (lg - h));
+    std::vector<F> lo(1u << h), hi((size_t)1 << (lg - h)), glo(1u << h), ghi((size_t)1 << (lg - h)), inner(512);
     F w = F::top_root();
     for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = w * w;
     F g = F::group_gen();
     if (inverse) { w = finv(w); g = finv(g); }
-    for (size_t k = 0; k < std::max(lo.size(), hi.size()); k++) {
-        table_item(lo.data(), hi.data(), w, lg, h, k);
-        table_item(glo.data(), ghi.data(), g, lg, h, k);
+    for (size_t k = 0; k < std::max<size_t>(std::max(lo.size(), hi.size()), 512); k++) {
+        table_item(lo.data(), hi.data(), inner.data(), w, lg, h, k);
+        table_item(glo.data(), ghi.data(), (F*)nullptr, g, lg, h, k);
     }
     F two = F::one() + F::one();
-    ntt_tables<F> T{lo.data(), hi.data(), lg, h, finv(field_pow(two, lg))}, G{glo.data(), ghi.data(), lg, h, F::one()};
+    ntt_tables<F> T{lo.data(), hi.data(), inner.data(), lg, h, finv(field_pow(two, lg))}, G{glo.data(), ghi.data(), nullptr, lg, h, F::one()};
 
     bool bitrev, gs;
     switch (order) {
@@ -50,22 +50,20 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
         ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
         P.apply_scale = inverse && i == pl.npass - 1;
         size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
-        std::vector<F> tile(tile_elems), inner((size_t)1 << (P.S - 1));
+        std::vector<F> tile(ntt_lds_elems(P) + 1);
         for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {
-            for (unsigned tid = 0; tid < nt; tid++) ntt_phase_inner_table(inner.data(), T, P.S, tid, nt);
-            for (unsigned tid = 0; tid < nt; tid++) {
-                if (gs) ntt_phase_load<F, true>(tile.data(), d, T, P, tile_id, tid, nt);
-                else    ntt_phase_load<F, false>(tile.data(), d, T, P, tile_id, tid, nt);
-            }
-            for (unsigned t = 0; t < P.S; t++)
-                for (unsigned tid = 0; tid < nt; tid++) {
-                    if (gs) ntt_phase_stage<F, true>(tile.data(), inner.data(), P, t, tid, nt);
-                    else    ntt_phase_stage<F, false>(tile.data(), inner.data(), P, t, tid, nt);
-                }
-            for (unsigned tid = 0; tid < nt; tid++) {
-                if (gs) ntt_phase_store<F, true>(d, tile.data(), T, P, tile_id, tid, nt);
-                else    ntt_phase_store<F, false>(d, tile.data(), T, P, tile_id, tid, nt);
-            }
+#define EMU_ROUNDS(R1, R2)                                                                                         \
+            do {                                                                                                   \
+                if (gs) {                                                                                          \
+                    for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_high<F, true, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_high<F, true, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                    if (R2) for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_low<F, true, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_low<F, true, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                } else {                                                                                           \
+                    if (R2) for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_low<F, false, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_low<F, false, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                    for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_high<F, false, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_high<F, false, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                }                                                                                                  \
+            } while (0)
+            SPPARK_NTT_DISPATCH_S(P.S, EMU_ROUNDS);
+#undef EMU_ROUNDS
         }
     }
     if (inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)!bitrev, i);

@@ -17,6 +17,57 @@ def _oracle_fn(O, field):
     return O.ntt_gl64 if field == "gl64" else O.ntt_bb31
 
 
+def test_device_small_field_ops(libs):
+    """element-wise gl64 / bb31 arithmetic on the GPU vs Python big-ints, edge-heavy
+    inputs, including chained and divergent use (hand-written carry chains)."""
+    import random
+    from sppark_amd import ffi
+    random.seed(3)
+    for field, P, dt in (("gl64", 0xffffffff00000001, np.uint64), ("bb31", 0x78000001, np.uint32)):
+        L = ffi.load(field)
+        M32 = 0xffffffff
+        R = 1 if field == "gl64" else pow(1 << 32, P - 2, P)         # bb31 values are Montgomery residues
+
+        def rnd():
+            r = random.random()
+            if field == "bb31":
+                return random.choice([0, 1, P - 1, P - 2]) if r < 0.2 else random.getrandbits(32) % P
+            if r < 0.2:
+                return random.choice([0, 1, P - 1, P - 2, M32, M32 << 32, (M32 << 32) - 1, 1 << 32, (1 << 32) - 1, (1 << 32) + 1])
+            if r < 0.4:
+                return ((M32 << 32) | random.getrandbits(32)) % P
+            if r < 0.6:
+                return random.getrandbits(32)
+            return random.getrandbits(64) % P
+        n = 1 << 13
+        a = np.array([rnd() for _ in range(n)], dtype=dt); b = np.array([rnd() for _ in range(n)], dtype=dt)
+        for op in (0, 1, 2, 3, 4, 5, 6):
+            if field == "bb31" and op == 3:
+                continue
+            out = np.zeros(n, dtype=dt)
+            ffi.check(L, L.sppark_devtest_small_field_op(op, out.ctypes.data, a.ctypes.data, b.ctypes.data, n))
+            for i in range(n):
+                x, y = int(a[i]), int(b[i])
+                mul = lambda u, v: u * v * R % P
+                if op == 0: e = (x + y) % P
+                elif op == 1: e = (x - y) % P
+                elif op == 2: e = mul(x, y)
+                elif op == 3: e = x * pow(2, (y & 0xff) % 192, P) % P
+                elif op == 4:
+                    e = x
+                    for _ in range(12): e = mul(e, e)
+                elif op == 5:
+                    e, bb, k = (1 if field == "gl64" else (1 << 32) % P), x, y & 0xffff
+                    while k:
+                        if k & 1: e = mul(e, bb)
+                        bb = mul(bb, bb); k >>= 1
+                else:
+                    e = x
+                    if i & 1:
+                        for _ in range(i & 15): e = (mul(e, e) + y) % P
+                assert int(out[i]) == e, (field, op, hex(x), hex(y))
+
+
 def test_ntt_golden_vectors(oracle, libs):
     """vectors from the independent big-int DFT in tests/golden/make_golden.py"""
     import sppark_amd

@@ -154,7 +154,8 @@ def main():
     if rank == 0:
         a_ms = float(np.mean(accum_ms))
         achieved = MSM_BYTES_PER_POINT * n / (a_ms * 1e-3) / 1e9
-        nwins = 16
+        plan = ctx.plan(n)
+        nwins = plan["windows"]
         line = {
             "metric": "MSM points/sec (BLS12-381 G1, 2^%d points per GPU)" % args.lg,
             "value": world * n * args.steps / elapsed, "unit": "points/s",
@@ -163,14 +164,14 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BLS12-381 G1 Pippenger MSM, 2^%d points per GPU, device-resident inputs "
                                    "(BASELINE configs[2]%s)" % (args.lg, "; sharded x%d with RCCL all-gather of partial sums" % world if world > 1 else ""),
-                       "curve": "bls12_381", "points_per_gpu": n, "window_bits": 16, "windows": nwins,
+                       "curve": "bls12_381", "points_per_gpu": n, "window_bits": plan["window_bits"], "windows": nwins,
                        "distinct_points": 2048, "scalars": "uniform 254-bit"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_accumulate",
                          "kernel_ms": a_ms,
                          "note": "MSM is integer-multiplier bound, not HBM bound (SURVEY F11): the kernel does "
                                  "%d mixed additions per launch = %.3e additions/s against a measured "
-                                 "5.14e9/s k_fieldbench ceiling" % (nwins * n, nwins * n / (a_ms * 1e-3))},
+                                 "5.14e9/s mixed-addition micro-benchmark" % (nwins * n, nwins * n / (a_ms * 1e-3))},
             "phases_ms": {"digits_sort": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
             "cpu_baseline": cpu, "ntt": ntt,
         }

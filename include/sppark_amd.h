@@ -82,6 +82,8 @@ SppError sppark_msm_set_stream(sppark_msm_ctx *ctx, void *stream);
 /* wbits/L/F/K/nslabs = 0 keeps the automatic choice */
 SppError sppark_msm_tune(sppark_msm_ctx *ctx, unsigned wbits, unsigned L, unsigned F,
                          unsigned K, unsigned nslabs);
+/* low_bits of the bucket index sorted by the second LDS level (0 = automatic) */
+SppError sppark_msm_tune_sort(sppark_msm_ctx *ctx, unsigned low_bits);
 SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affine_sz,
                             int host_points, int host_scalars);
 /* mont != 0: scalars are in Montgomery form (msm_t::invoke's `mont`). */
@@ -91,6 +93,8 @@ SppError sppark_msm_enable_timing(sppark_msm_ctx *ctx, int on);
 /* which: 0 digits+sort, 1 bucket accumulation kernel, 2 all device work (ms of the last invoke) */
 float    sppark_msm_kernel_ms(const sppark_msm_ctx *ctx, int which);
 size_t   sppark_msm_scratch_bytes(const sppark_msm_ctx *ctx);
+/* plan for npoints: {window bits, windows, buckets/window, run length, partitions, low bits, fan-in, chunk} */
+void     sppark_msm_plan(const sppark_msm_ctx *ctx, size_t npoints, unsigned out[8]);
 
 /* Host-side helpers on Jacobian points (no GPU needed): out = sum of n points;
  * affine = (x, y) of a Jacobian point, infinity -> all-zero.  Used by the

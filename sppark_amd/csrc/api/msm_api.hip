@@ -75,11 +75,14 @@ SPPARK_FFI RustError sppark_msm_tune(sppark_msm_ctx* ctx, unsigned wbits, unsign
                                      unsigned K, unsigned nslabs)
 {
     return guarded([&] {
-        if ((K & (K - 1)) || wbits > 16) HIP_OK(hipErrorInvalidValue);
+        if ((K & (K - 1)) || wbits > 24) HIP_OK(hipErrorInvalidValue);
         ctx->impl.tune.wbits = wbits; ctx->impl.tune.L = L; ctx->impl.tune.F = F;
         ctx->impl.tune.K = K; ctx->impl.tune.nslabs = nslabs;
     });
 }
+// split of the bucket index between the two sort levels (0 = automatic)
+SPPARK_FFI RustError sppark_msm_tune_sort(sppark_msm_ctx* ctx, unsigned low_bits)
+{   return guarded([&] { ctx->impl.tune.LB = low_bits; });   }
 SPPARK_FFI RustError sppark_msm_reserve(sppark_msm_ctx* ctx, size_t npoints, size_t ffi_affine_sz,
                                         int host_points, int host_scalars)
 {   return guarded([&] { ctx->impl.reserve_for(npoints, ffi_affine_sz, host_points, host_scalars); });   }
@@ -97,6 +100,13 @@ SPPARK_FFI RustError sppark_msm_enable_timing(sppark_msm_ctx* ctx, int on)
 {   return guarded([&] { ctx->impl.enable_timing(on != 0); });   }
 SPPARK_FFI float sppark_msm_kernel_ms(const sppark_msm_ctx* ctx, int which) { return ctx->impl.kernel_ms(which); }
 SPPARK_FFI size_t sppark_msm_scratch_bytes(const sppark_msm_ctx* ctx) { return ctx->impl.scratch_bytes(); }
+// plan the context would use for |npoints|: out = {window bits (longest), windows, buckets per window,
+// run length L, level-A partitions, level-B low bits, record fan-in F, bucket chunk K}
+SPPARK_FFI void sppark_msm_plan(const sppark_msm_ctx* ctx, size_t npoints, unsigned out[8])
+{
+    msm_plan p = ctx->impl.plan_for(npoints);
+    out[0] = p.wbits; out[1] = p.nwins; out[2] = p.NB; out[3] = p.L; out[4] = p.NA; out[5] = p.LB; out[6] = p.F; out[7] = p.K;
+}
 
 // ---- host-side point helpers (no GPU work) --------------------------------
 SPPARK_FFI void sppark_g1_jacobian_sum(void* out, const void* points, size_t n)

@@ -24,7 +24,9 @@
 namespace sppark_amd {
 
 struct msm_plan {
-    unsigned n, wbits, nwins, NB;       // NB = 2^(wbits-1) buckets per window
+    unsigned n, wbits, nwins, NB;       // wbits = longest window, NB = 2^(wbits-1) buckets per window
+    unsigned nbits;                     // scalar bits, split evenly over the windows
+    unsigned HB, LB, NA;                // bucket index = (k_hi : k_lo), NA = 2^HB partitions per window
     unsigned L, chunks_per_win;         // accumulate run length
     unsigned nslabs, slab_sz;           // hist/scatter point slabs
     unsigned F;                         // reduce_runs fan-in
@@ -32,7 +34,7 @@ struct msm_plan {
 };
 
 struct msm_tunables {                   // 0 = automatic
-    unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0;
+    unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0, LB = 0;
 };
 
 static inline unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
@@ -42,11 +44,21 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     msm_plan p;
     p.n = (unsigned)npoints;
     unsigned lg = lg2_floor(npoints ? npoints : 1);
-    // window: LDS must hold 2^(wbits-1) u32 counters (<= 128 KB of the 160 KB)
-    p.wbits = t.wbits ? t.wbits : std::min(16u, std::max(6u, lg > 4 ? lg - 4 : 0u));
-    p.wbits = std::min(16u, std::max(2u, p.wbits));
+    // window: ~2^6 entries per bucket on average; both halves of the bucket index
+    // must fit LDS counters (2^15 u32 = 128 KB of the 160 KB) => wbits - 1 <= 30, capped at 24
+    p.wbits = t.wbits ? t.wbits : std::min(22u, std::max(6u, lg > 4 ? lg - 4 : 0u));      // measured optimum at 2^20..2^26
+    p.wbits = std::min(24u, std::max(2u, p.wbits));
     p.nwins = (scalar_bits - 1) / p.wbits + 1;      // as pippenger.cuh:365
+    p.nbits = scalar_bits;
+    p.wbits = scalar_bits / p.nwins + (scalar_bits % p.nwins ? 1 : 0);     // even split (window_len)
     p.NB = 1u << (p.wbits - 1);
+    // many small level-A partitions (<= 2^12 per window) keep level B's two passes
+    // over a partition inside L2 (measured: profiles/r01_sort_split_sweep.log)
+    p.LB = t.LB ? std::min(t.LB, p.wbits - 1) : (p.wbits - 1 > 12 ? p.wbits - 1 - 12 : 0);
+    if (p.LB > 13) p.LB = 13;                       // 2^LB LDS counters + scan words
+    if (p.wbits - 1 - p.LB > 15) p.LB = p.wbits - 1 - 15;
+    p.HB = p.wbits - 1 - p.LB;
+    p.NA = 1u << p.HB;
     size_t entries = (size_t)p.n * p.nwins;
     unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(64, std::max<size_t>(4, entries / 262144));
     p.L = L;
@@ -81,7 +93,7 @@ private:
     bool timing = false;
 
     struct layout {
-        size_t points, scalars, digits, sorted, H, tot, off, buckets;
+        size_t points, scalars, digits, sorted, partA, H, tot, offA, off, buckets;
         size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, total;
     };
 
@@ -95,8 +107,10 @@ private:
         l.scalars = take(sc_bytes);
         l.digits  = take((size_t)p.nwins * p.n * 4);
         l.sorted  = take((size_t)p.nwins * p.n * 4);
-        l.H       = take((size_t)p.nwins * p.nslabs * p.NB * 4);
-        l.tot     = take((size_t)p.nwins * p.NB * 4);
+        l.partA   = take((size_t)p.nwins * p.n * 8);
+        l.H       = take((size_t)p.nwins * p.nslabs * p.NA * 4);
+        l.tot     = take((size_t)p.nwins * p.NA * 4);
+        l.offA    = take((size_t)p.nwins * (p.NA + 1) * 4);
         l.off     = take((size_t)p.nwins * (p.NB + 1) * 4);
         l.buckets = take((size_t)p.nwins * p.NB * sizeof(bucket_t));
         size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win;
@@ -152,6 +166,7 @@ public:
     }
     float kernel_ms(int which) const { return which >= 0 && which < 3 ? last_ms[which] : -1.f; }
     size_t scratch_bytes() const { return blob_sz; }
+    msm_plan plan_for(size_t npoints) const { return make_plan(npoints, FRp::NBITS, tune); }
 
     // Size the blob for |npoints| ahead of time (so a timed invoke does not allocate).
     void reserve_for(size_t npoints, size_t ffi_affine_sz, bool host_points, bool host_scalars)
@@ -203,26 +218,33 @@ public:
         {
             unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
             hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, stream,
-                               digits, d_scalars, p.n, p.nwins, p.wbits, (int)mont);
+                               digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont);
             HIP_OK(hipGetLastError());
         }
         {
-            size_t lds = (size_t)p.NB * 4;
-            if (lds > 65536) {
-                HIP_OK(hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                HIP_OK(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            uint2* partA = (uint2*)(blob + l.partA);
+            u32* offA = (u32*)(blob + l.offA);
+            size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + 4096;
+            if (ldsA > 65536) {
+                HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+                HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
             }
-            hipLaunchKernelGGL(k_hist, dim3(p.nslabs, p.nwins), dim3(1024), lds, stream,
-                               H, digits, p.n, p.nslabs, p.slab_sz, p.NB);
+            if (ldsB > 65536)
+                HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+            hipLaunchKernelGGL(k_histA, dim3(p.nslabs, p.nwins), dim3(1024), ldsA, stream,
+                               H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
             HIP_OK(hipGetLastError());
-            size_t nb_total = (size_t)p.nwins * p.NB;
-            hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((nb_total + 255) / 256)), dim3(256), 0, stream,
-                               H, tot, p.nslabs, p.NB, p.nwins);
+            size_t na_total = (size_t)p.nwins * p.NA;
+            hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((na_total + 255) / 256)), dim3(256), 0, stream,
+                               H, tot, p.nslabs, p.NA, p.nwins);
             HIP_OK(hipGetLastError());
-            hipLaunchKernelGGL(k_scan_buckets, dim3(p.nwins), dim3(1024), 0, stream, off, tot, p.NB);
+            hipLaunchKernelGGL(k_scan_parts, dim3(p.nwins), dim3(1024), 0, stream, offA, tot, p.NA);
             HIP_OK(hipGetLastError());
-            hipLaunchKernelGGL(k_scatter, dim3(p.nslabs, p.nwins), dim3(1024), lds, stream,
-                               sorted, digits, H, off, p.n, p.nslabs, p.slab_sz, p.NB);
+            hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, p.nwins), dim3(1024), ldsA, stream,
+                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+            HIP_OK(hipGetLastError());
+            hipLaunchKernelGGL(k_sortB, dim3(p.NA, p.nwins), dim3(1024), ldsB, stream,
+                               sorted, off, partA, offA, p.n, p.NA, p.LB);
             HIP_OK(hipGetLastError());
         }
         HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
@@ -301,7 +323,7 @@ public:
             memcpy(c, &sums[w], sizeof(c));
             point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
             out.add(s);
-            if (w) for (unsigned k = 0; k < p.wbits; k++) out.dbl();
+            if (w) for (unsigned k = 0; k < window_len(w - 1, p.nwins, p.nbits); k++) out.dbl();
         }
     }
 };

@@ -42,18 +42,27 @@ static constexpr u32 KEY_NONE = 0xffffffffu;
 // Digit recoding (any recoding with the same sum is valid; only the group
 // element is observable -- SURVEY Appendix A.6):
 //   s > (r-1)/2  ->  s = r - s, all signs flipped   (cf. pippenger.cuh:96-99)
-//   d_w = bits [w*c, w*c+c) + carry;  d_w > 2^(c-1)  ->  d_w -= 2^c, carry = 1
-// so |d_w| <= 2^(c-1) and bucket index = |d_w| - 1  (cf. sort.cuh:92).
+//   d_w = bits of window w + carry;  d_w > 2^(len_w-1)  ->  d_w -= 2^len_w, carry = 1
+// so |d_w| <= 2^(len_w-1) and bucket index = |d_w| - 1  (cf. sort.cuh:92).
+// The nbits scalar bits are split EVENLY over the windows (len_w = base or
+// base+1): no window is left with only a few significant bits, which would put
+// every point of that window into a handful of buckets (the reference spreads
+// its short top window with an lshift trick instead, sort.cuh:92,111,339).
 // Output word: bit31 = sign, low bits = |digit|, 0 = no contribution.
 // |limb(k)| returns 32-bit limb k of the reduced magnitude (k <= N, limb N = 0).
+__host__ __device__ inline unsigned window_len(unsigned w, unsigned nwins, unsigned nbits)   // also used by the host Horner
+{   return nbits / nwins + (w < nbits % nwins ? 1u : 0u);   }
+
 template<class LimbFn>
 SPPARK_DEVFN void recode_digits(u32* digits, size_t n, size_t i, LimbFn limb, bool flip,
-                                unsigned nwins, unsigned wbits)
+                                unsigned nwins, unsigned nbits)
 {
-    const u32 half = 1u << (wbits - 1), full = 1u << wbits, mask = full - 1;
     u32 carry = 0;
-    for (unsigned w = 0, bit = 0; w < nwins; w++, bit += wbits) {
+    for (unsigned w = 0, bit = 0; w < nwins; w++) {
+        const unsigned len = window_len(w, nwins, nbits);
+        const u32 half = 1u << (len - 1), full = 1u << len, mask = full - 1;
         const unsigned li = bit >> 5, sh = bit & 31;
+        bit += len;
         u64 two = limb(li) | ((u64)limb(li + 1) << 32);
         u32 d = ((u32)(two >> sh) & mask) + carry;
         bool minus = d > half;
@@ -87,7 +96,7 @@ SPPARK_DEVFN FR load_scalar_abs(const u32* scalars, size_t i, int mont, bool& fl
 template<class FR>
 __global__ __launch_bounds__(256)
 void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
-                 unsigned n, unsigned nwins, unsigned wbits, int mont)
+                 unsigned n, unsigned nwins, unsigned nbits, int mont)
 {
     constexpr int N = FR::N;
     __shared__ u32 limbs[N + 2][256];                   // transposed: dynamic limb index without scratch
@@ -98,7 +107,7 @@ void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
         #pragma unroll
         for (int k = 0; k < N; k++) limbs[k][tid] = s.v[k];
         limbs[N][tid] = 0; limbs[N + 1][tid] = 0;
-        recode_digits(digits, n, i, [&](unsigned k) { return limbs[k][tid]; }, flip, nwins, wbits);
+        recode_digits(digits, n, i, [&](unsigned k) { return limbs[k][tid]; }, flip, nwins, nbits);
     }
 }
 

@@ -1,59 +1,75 @@
 // Counting-sort kernels of the MSM pipeline (non-template; included by exactly
 // one translation unit, api/msm_api.hip).  See msm_kernels.hpp for the overview.
+//
+// Bucket index k = |digit| - 1 in [0, 2^(c-1)) is split k = (k_hi : k_lo), HB + LB
+// = c - 1 bits, and grouped in two LDS-resident levels:
+//
+//   level A  (window, point slab) block: histogram of k_hi in LDS (2^HB counters),
+//            slab/bucket exclusive scans, then scatter of 8-byte records
+//            (point index | sign<<31, k_lo) into 2^HB partitions per window.  Each
+//            block feeds 2^HB output streams (8 KB each at n = 2^26), not 2^(c-1).
+//   level B  (window, k_hi) block: histogram of k_lo in LDS (2^LB counters), block
+//            scan, bucket offsets out, then scatter of the 4-byte entries inside
+//            the partition's own contiguous output range (256 KB at n = 2^26).
+//
+// All counting and cursor arithmetic happens in LDS (ds_add / ds_add_rtn); no
+// global atomics anywhere.  The reference instead sorts with two cooperative
+// grid-synchronised passes sized for <= 32 blocks (msm/sort.cuh:120-357).
 #pragma once
 #include "../ff/mont_dev.hpp"
 
 namespace sppark_amd {
 
-// ---------------------------------------------------------------------------
-// hist: block (slab, window) counts its slab's digits of that window in LDS.
-// H[(w*nslabs + slab)*NB + b] = count.
-// ---------------------------------------------------------------------------
+// H[(w*nslabs + slab)*NA + k_hi] = count of the slab's window-w digits in partition k_hi
 __global__ __launch_bounds__(1024)
-void k_hist(u32* __restrict__ H, const u32* __restrict__ digits, unsigned n,
-            unsigned nslabs, unsigned slab_sz, unsigned NB)
+void k_histA(u32* __restrict__ H, const u32* __restrict__ digits, unsigned n,
+             unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
 {
     extern __shared__ u32 lds_cnt[];
     const unsigned slab = blockIdx.x, w = blockIdx.y;
-    for (unsigned b = threadIdx.x; b < NB; b += blockDim.x) lds_cnt[b] = 0;
+    for (unsigned b = threadIdx.x; b < NA; b += blockDim.x) lds_cnt[b] = 0;
     __syncthreads();
 
     const unsigned lo = slab * slab_sz, hi = min(n, lo + slab_sz);
     const u32* dig = digits + (size_t)w * n;
-    for (unsigned i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        u32 d = dig[i];
-        if (d) atomicAdd(&lds_cnt[(d & 0x7fffffffu) - 1], 1u);
+    // four independent loads in flight per lane before the LDS atomics
+    for (unsigned i = lo + threadIdx.x; i < hi; i += 4 * blockDim.x) {
+        u32 d[4];
+        #pragma unroll
+        for (int u = 0; u < 4; u++) { unsigned j = i + u * blockDim.x; d[u] = j < hi ? dig[j] : 0; }
+        #pragma unroll
+        for (int u = 0; u < 4; u++) if (d[u]) atomicAdd(&lds_cnt[((d[u] & 0x7fffffffu) - 1) >> LB], 1u);
     }
     __syncthreads();
 
-    u32* out = H + ((size_t)w * nslabs + slab) * NB;
-    for (unsigned b = threadIdx.x; b < NB; b += blockDim.x) out[b] = lds_cnt[b];
+    u32* out = H + ((size_t)w * nslabs + slab) * NA;
+    for (unsigned b = threadIdx.x; b < NA; b += blockDim.x) out[b] = lds_cnt[b];
 }
 
-// slab-exclusive prefix per (window, bucket); tot[w*NB+b] = bucket total
+// slab-exclusive prefix per (window, partition); tot[w*NA+b] = partition total
 __global__ __launch_bounds__(256)
-void k_scan_slabs(u32* __restrict__ H, u32* __restrict__ tot, unsigned nslabs, unsigned NB, unsigned nwins)
+void k_scan_slabs(u32* __restrict__ H, u32* __restrict__ tot, unsigned nslabs, unsigned NA, unsigned nwins)
 {
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (size_t)nwins * NB) return;
-    const unsigned w = id / NB, b = id % NB;
+    if (id >= (size_t)nwins * NA) return;
+    const unsigned w = id / NA, b = id % NA;
     u32 run = 0;
     for (unsigned s = 0; s < nslabs; s++) {
-        u32* p = H + ((size_t)w * nslabs + s) * NB + b;
+        u32* p = H + ((size_t)w * nslabs + s) * NA + b;
         u32 t = *p; *p = run; run += t;
     }
     tot[id] = run;
 }
 
-// bucket-exclusive prefix per window: off[w*(NB+1) + b], off[..+NB] = #entries
+// partition-exclusive prefix per window: offA[w*(NA+1) + b], offA[..+NA] = #entries
 __global__ __launch_bounds__(1024)
-void k_scan_buckets(u32* __restrict__ off, const u32* __restrict__ tot, unsigned NB)
+void k_scan_parts(u32* __restrict__ offA, const u32* __restrict__ tot, unsigned NA)
 {
     __shared__ u32 part[1024];
     const unsigned w = blockIdx.x, tid = threadIdx.x;
-    const unsigned per = (NB + 1023) / 1024;
-    const unsigned lo = min(NB, tid * per), hi = min(NB, lo + per);
-    const u32* t = tot + (size_t)w * NB;
+    const unsigned per = (NA + 1023) / 1024;
+    const unsigned lo = min(NA, tid * per), hi = min(NA, lo + per);
+    const u32* t = tot + (size_t)w * NA;
     u32 sum = 0;
     for (unsigned b = lo; b < hi; b++) sum += t[b];
     part[tid] = sum;
@@ -65,35 +81,101 @@ void k_scan_buckets(u32* __restrict__ off, const u32* __restrict__ tot, unsigned
         __syncthreads();
     }
     u32 run = part[tid] - sum;
-    u32* o = off + (size_t)w * (NB + 1);
+    u32* o = offA + (size_t)w * (NA + 1);
     for (unsigned b = lo; b < hi; b++) { o[b] = run; run += t[b]; }
-    if (tid == 1023) o[NB] = part[1023];
+    if (tid == 1023) o[NA] = part[1023];
 }
 
-// ---------------------------------------------------------------------------
-// scatter: LDS cursors = slab-exclusive + bucket-exclusive offsets.
-// sorted[w*n + pos] = point index | sign<<31
-// ---------------------------------------------------------------------------
+// level-A scatter: partA[w*n + pos] = { point index | sign<<31, k_lo }
 __global__ __launch_bounds__(1024)
-void k_scatter(u32* __restrict__ sorted, const u32* __restrict__ digits,
-               const u32* __restrict__ H, const u32* __restrict__ off,
-               unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NB)
+void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
+                const u32* __restrict__ H, const u32* __restrict__ offA,
+                unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
 {
     extern __shared__ u32 lds_cur[];
     const unsigned slab = blockIdx.x, w = blockIdx.y;
-    const u32* h = H + ((size_t)w * nslabs + slab) * NB;
-    const u32* o = off + (size_t)w * (NB + 1);
-    for (unsigned b = threadIdx.x; b < NB; b += blockDim.x) lds_cur[b] = h[b] + o[b];
+    const u32* h = H + ((size_t)w * nslabs + slab) * NA;
+    const u32* o = offA + (size_t)w * (NA + 1);
+    for (unsigned b = threadIdx.x; b < NA; b += blockDim.x) lds_cur[b] = h[b] + o[b];
     __syncthreads();
 
     const unsigned lo = slab * slab_sz, hi = min(n, lo + slab_sz);
     const u32* dig = digits + (size_t)w * n;
+    uint2* dst = partA + (size_t)w * n;
+    const u32 lomask = (1u << LB) - 1;
+    for (unsigned i = lo + threadIdx.x; i < hi; i += 4 * blockDim.x) {
+        u32 d[4];
+        #pragma unroll
+        for (int u = 0; u < 4; u++) { unsigned j = i + u * blockDim.x; d[u] = j < hi ? dig[j] : 0; }
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (d[u]) {
+                u32 k = (d[u] & 0x7fffffffu) - 1;
+                u32 pos = atomicAdd(&lds_cur[k >> LB], 1u);
+                dst[pos] = make_uint2((i + u * blockDim.x) | (d[u] & 0x80000000u), k & lomask);
+            }
+        }
+    }
+}
+
+// level B: block (k_hi, w) groups its partition by k_lo.
+//   off[w*(NB+1) + k_hi*2^LB + j] = first position of bucket (k_hi, j) in window w's list
+//   sorted[w*n + pos] = point index | sign<<31
+__global__ __launch_bounds__(1024)
+void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __restrict__ partA,
+             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LB)
+{
+    extern __shared__ u32 lds[];            // 2^LB counters, then 1024 scan words
+    const unsigned NL = 1u << LB;
+    u32* cnt = lds;
+    u32* part = lds + NL;
+    const unsigned khi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const u32* oA = offA + (size_t)w * (NA + 1);
+    const unsigned begin = oA[khi], end = oA[khi + 1];
+    const uint2* src = partA + (size_t)w * n;
+
+    for (unsigned b = tid; b < NL; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    for (unsigned i = begin + tid; i < end; i += 4096) {
+        u32 k[4];
+        #pragma unroll
+        for (int u = 0; u < 4; u++) { unsigned j = i + u * 1024; k[u] = j < end ? src[j].y : 0xffffffffu; }
+        #pragma unroll
+        for (int u = 0; u < 4; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
+    }
+    __syncthreads();
+
+    // exclusive scan of cnt[0..NL) in place, offsets relative to |begin|
+    const unsigned per = (NL + 1023) / 1024;
+    const unsigned lo = min(NL, tid * per), hi = min(NL, lo + per);
+    u32 sum = 0;
+    for (unsigned b = lo; b < hi; b++) sum += cnt[b];
+    part[tid] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        u32 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = begin + part[tid] - sum;
+    const size_t NB = (size_t)NA << LB;
+    u32* o = off + (size_t)w * (NB + 1) + ((size_t)khi << LB);
+    for (unsigned b = lo; b < hi; b++) { u32 c = cnt[b]; cnt[b] = run; o[b] = run; run += c; }
+    if (khi == NA - 1 && tid == 0) off[(size_t)w * (NB + 1) + NB] = end;
+    __syncthreads();
+
     u32* dst = sorted + (size_t)w * n;
-    for (unsigned i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        u32 d = dig[i];
-        if (d) {
-            u32 pos = atomicAdd(&lds_cur[(d & 0x7fffffffu) - 1], 1u);
-            dst[pos] = i | (d & 0x80000000u);
+    for (unsigned i = begin + tid; i < end; i += 4096) {
+        uint2 r[4];
+        #pragma unroll
+        for (int u = 0; u < 4; u++) { unsigned j = i + u * 1024; r[u] = j < end ? src[j] : make_uint2(0, 0xffffffffu); }
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (r[u].y != 0xffffffffu) {
+                u32 pos = atomicAdd(&cnt[r[u].y], 1u);
+                dst[pos] = r[u].x;
+            }
         }
     }
 }

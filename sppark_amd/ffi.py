@@ -68,6 +68,8 @@ def load(name):
         L.sppark_msm_set_stream.restype = _Error
         L.sppark_msm_tune.argtypes = [vp, cu, cu, cu, cu, cu]
         L.sppark_msm_tune.restype = _Error
+        L.sppark_msm_tune_sort.argtypes = [vp, cu]
+        L.sppark_msm_tune_sort.restype = _Error
         L.sppark_msm_reserve.argtypes = [vp, sz, sz, ci, ci]
         L.sppark_msm_reserve.restype = _Error
         L.sppark_msm_invoke.argtypes = [vp, vp, vp, sz, vp, ci, sz]
@@ -78,6 +80,7 @@ def load(name):
         L.sppark_msm_kernel_ms.restype = ctypes.c_float
         L.sppark_msm_scratch_bytes.argtypes = [vp]
         L.sppark_msm_scratch_bytes.restype = sz
+        L.sppark_msm_plan.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint * 8)]
         L.sppark_g1_jacobian_sum.argtypes = [vp, vp, sz]
         L.sppark_g1_to_affine.argtypes = [vp, vp]
         L.sppark_g1_generate.argtypes = [vp, sz, sz, ctypes.c_uint64]

@@ -86,6 +86,9 @@ class MsmContext:
     def tune(self, wbits=0, L=0, F=0, K=0, nslabs=0):
         ffi.check(self.L, self.L.sppark_msm_tune(self.h, wbits, L, F, K, nslabs))
 
+    def tune_sort(self, low_bits=0):
+        ffi.check(self.L, self.L.sppark_msm_tune_sort(self.h, low_bits))
+
     def reserve(self, npoints, ffi_affine_sz, host_points=False, host_scalars=False):
         ffi.check(self.L, self.L.sppark_msm_reserve(self.h, npoints, ffi_affine_sz,
                                                     int(host_points), int(host_scalars)))
@@ -98,6 +101,12 @@ class MsmContext:
 
     def scratch_bytes(self):
         return int(self.L.sppark_msm_scratch_bytes(self.h))
+
+    def plan(self, npoints):
+        out = (ctypes.c_uint * 8)()
+        self.L.sppark_msm_plan(self.h, npoints, ctypes.byref(out))
+        keys = ("window_bits", "windows", "buckets_per_window", "run_length", "partitions", "low_bits", "fan_in", "bucket_chunk")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def invoke(self, points, scalars, npoints=None, mont=False, ffi_affine_sz=None):
         stride = ffi_affine_sz or 2 * self.fb

@@ -18,7 +18,7 @@
 using namespace sppark_amd;
 
 // plan/tunables only (no HIP runtime needed)
-struct msm_plan { unsigned n, wbits, nwins, NB, L, chunks_per_win, nslabs, slab_sz, F, K; };
+struct msm_plan { unsigned n, wbits, nwins, nbits, NB, HB, LB, NA, L, chunks_per_win, nslabs, slab_sz, F, K; };
 
 static unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
 
@@ -66,9 +66,12 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     msm_plan p;
     p.n = (unsigned)npoints;
     unsigned lg = lg2_floor(npoints);
-    p.wbits = wbits ? wbits : std::min(16u, std::max(6u, lg > 4 ? lg - 4 : 0u));
+    p.wbits = wbits ? wbits : std::min(20u, std::max(6u, lg > 6 ? lg - 6 : 0u));
     p.nwins = (curve_p::fr::NBITS - 1) / p.wbits + 1;
+    p.nbits = curve_p::fr::NBITS;
+    p.wbits = p.nbits / p.nwins + (p.nbits % p.nwins ? 1 : 0);
     p.NB = 1u << (p.wbits - 1);
+    p.LB = (p.wbits - 1) / 2; p.HB = p.wbits - 1 - p.LB; p.NA = 1u << p.HB;
     size_t entries = (size_t)p.n * p.nwins;
     p.L = L ? L : (unsigned)std::min<size_t>(64, std::max<size_t>(4, entries / 262144));
     p.chunks_per_win = (p.n + p.L - 1) / p.L;
@@ -87,37 +90,49 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         fr_d s = load_scalar_abs<fr_d>(sc32.data(), i, mont, flip);
         u32 limbs[fr_d::N + 2] = {0};
         for (int k = 0; k < fr_d::N; k++) limbs[k] = s.v[k];
-        recode_digits(digits.data(), p.n, i, [&](unsigned k) { return limbs[k]; }, flip, p.nwins, p.wbits);
+        recode_digits(digits.data(), p.n, i, [&](unsigned k) { return limbs[k]; }, flip, p.nwins, p.nbits);
     }
 
-    // ---- hist / scan / scatter (translation of msm_sort_kernels.hpp) ----
-    std::vector<u32> H((size_t)p.nwins * p.nslabs * p.NB, 0), tot((size_t)p.nwins * p.NB), off((size_t)p.nwins * (p.NB + 1));
-    for (unsigned w = 0; w < p.nwins; w++)
+    // ---- two-level counting sort (translation of msm_sort_kernels.hpp) ----
+    std::vector<u32> H((size_t)p.nwins * p.nslabs * p.NA, 0), tot((size_t)p.nwins * p.NA), offA((size_t)p.nwins * (p.NA + 1));
+    std::vector<u32> off((size_t)p.nwins * (p.NB + 1));
+    std::vector<uint2> partA((size_t)p.nwins * p.n);
+    const u32 lomask = (1u << p.LB) - 1;
+    for (unsigned w = 0; w < p.nwins; w++)                              // k_histA
         for (unsigned slab = 0; slab < p.nslabs; slab++) {
             unsigned lo = slab * p.slab_sz, hi = std::min(p.n, lo + p.slab_sz);
-            u32* cnt = &H[((size_t)w * p.nslabs + slab) * p.NB];
-            for (unsigned i = lo; i < hi; i++) { u32 d = digits[(size_t)w * p.n + i]; if (d) cnt[(d & 0x7fffffffu) - 1]++; }
+            u32* cnt = &H[((size_t)w * p.nslabs + slab) * p.NA];
+            for (unsigned i = lo; i < hi; i++) { u32 d = digits[(size_t)w * p.n + i]; if (d) cnt[((d & 0x7fffffffu) - 1) >> p.LB]++; }
         }
-    for (size_t id = 0; id < (size_t)p.nwins * p.NB; id++) {
-        unsigned w = id / p.NB, b = id % p.NB; u32 run = 0;
-        for (unsigned s = 0; s < p.nslabs; s++) { u32* q = &H[((size_t)w * p.nslabs + s) * p.NB + b]; u32 t = *q; *q = run; run += t; }
+    for (size_t id = 0; id < (size_t)p.nwins * p.NA; id++) {            // k_scan_slabs
+        unsigned w = id / p.NA, b = id % p.NA; u32 run = 0;
+        for (unsigned s = 0; s < p.nslabs; s++) { u32* q = &H[((size_t)w * p.nslabs + s) * p.NA + b]; u32 t = *q; *q = run; run += t; }
         tot[id] = run;
     }
-    for (unsigned w = 0; w < p.nwins; w++) {
+    for (unsigned w = 0; w < p.nwins; w++) {                            // k_scan_parts
         u32 run = 0;
-        for (unsigned b = 0; b < p.NB; b++) { off[(size_t)w * (p.NB + 1) + b] = run; run += tot[(size_t)w * p.NB + b]; }
-        off[(size_t)w * (p.NB + 1) + p.NB] = run;
+        for (unsigned b = 0; b < p.NA; b++) { offA[(size_t)w * (p.NA + 1) + b] = run; run += tot[(size_t)w * p.NA + b]; }
+        offA[(size_t)w * (p.NA + 1) + p.NA] = run;
     }
-    for (unsigned w = 0; w < p.nwins; w++)
+    for (unsigned w = 0; w < p.nwins; w++)                              // k_scatterA
         for (unsigned slab = 0; slab < p.nslabs; slab++) {
-            std::vector<u32> cur(p.NB);
-            for (unsigned b = 0; b < p.NB; b++) cur[b] = H[((size_t)w * p.nslabs + slab) * p.NB + b] + off[(size_t)w * (p.NB + 1) + b];
+            std::vector<u32> cur(p.NA);
+            for (unsigned b = 0; b < p.NA; b++) cur[b] = H[((size_t)w * p.nslabs + slab) * p.NA + b] + offA[(size_t)w * (p.NA + 1) + b];
             unsigned lo = slab * p.slab_sz, hi = std::min(p.n, lo + p.slab_sz);
-            // reverse order inside the slab: any order within a bucket must work
-            for (unsigned i = hi; i-- > lo;) {
+            for (unsigned i = hi; i-- > lo;) {                          // reverse: any order inside a partition must work
                 u32 d = digits[(size_t)w * p.n + i];
-                if (d) sorted[(size_t)w * p.n + cur[(d & 0x7fffffffu) - 1]++] = i | (d & 0x80000000u);
+                if (d) { u32 k = (d & 0x7fffffffu) - 1; partA[(size_t)w * p.n + cur[k >> p.LB]++] = make_uint2(i | (d & 0x80000000u), k & lomask); }
             }
+        }
+    for (unsigned w = 0; w < p.nwins; w++)                              // k_sortB
+        for (unsigned khi = 0; khi < p.NA; khi++) {
+            unsigned begin = offA[(size_t)w * (p.NA + 1) + khi], end = offA[(size_t)w * (p.NA + 1) + khi + 1];
+            std::vector<u32> cnt(1u << p.LB, 0);
+            for (unsigned i = begin; i < end; i++) cnt[partA[(size_t)w * p.n + i].y]++;
+            u32 run = begin;
+            for (unsigned b = 0; b < (1u << p.LB); b++) { u32 c = cnt[b]; cnt[b] = run; off[(size_t)w * (p.NB + 1) + ((size_t)khi << p.LB) + b] = run; run += c; }
+            if (khi == p.NA - 1) off[(size_t)w * (p.NB + 1) + p.NB] = end;
+            for (unsigned i = end; i-- > begin;) { uint2 r = partA[(size_t)w * p.n + i]; sorted[(size_t)w * p.n + cnt[r.y]++] = r.x; }
         }
 
     // ---- accumulate + record levels ----
@@ -170,7 +185,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         memcpy(c, &iw[w], sizeof(c));
         point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
         out.add(s);
-        if (w) for (unsigned k = 0; k < p.wbits; k++) out.dbl();
+        if (w) for (unsigned k = 0; k < window_len(w - 1, p.nwins, p.nbits); k++) out.dbl();
     }
     memcpy(out_jac, &out, sizeof(out));
     return 0;

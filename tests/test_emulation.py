@@ -71,7 +71,7 @@ def test_msm_pipeline_on_host(oracle, curve):
     for n, wb, LL, F, K, ns, flagged in ((1, 0, 0, 0, 0, 0, False), (2, 0, 0, 0, 0, 0, True), (33, 0, 0, 0, 0, 0, False),
                                          (1000, 0, 0, 0, 0, 0, True), (1000, 7, 4, 4, 2, 3, False),
                                          (700, 9, 16, 8, 4, 2, True), (2048, 10, 8, 32, 8, 1, False),
-                                         (300, 2, 4, 4, 2, 1, False), (300, 16, 64, 32, 8, 1, False)):
+                                         (300, 2, 4, 4, 2, 1, False), (300, 16, 64, 32, 8, 1, False), (500, 19, 8, 8, 8, 2, True)):
         pts, sc = recipe.msm_inputs(curve, n, 1234 + n + wb, flagged=flagged)
         out = np.zeros(3 * fb, dtype=np.uint8)
         L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns)

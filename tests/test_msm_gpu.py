@@ -158,7 +158,8 @@ def test_msm_empty_and_all_infinity(oracle, libs):
 
 
 @pytest.mark.parametrize("tune", [dict(wbits=7, L=4, F=4, K=2, nslabs=3), dict(wbits=12, L=16, F=8, K=4, nslabs=2),
-                                  dict(wbits=16, L=64, F=32, K=8, nslabs=1), dict(wbits=2, L=4, F=4, K=2, nslabs=1)])
+                                  dict(wbits=16, L=64, F=32, K=8, nslabs=1), dict(wbits=2, L=4, F=4, K=2, nslabs=1),
+                                  dict(wbits=20, L=8, F=8, K=8, nslabs=2), dict(wbits=23, L=4, F=16, K=16, nslabs=1)])
 def test_msm_tunables(oracle, libs, tune):
     """every plan parameter away from its default must give the same group element"""
     import sppark_amd

@@ -14,38 +14,9 @@ import sppark_amd
 from sppark_amd import ffi
 
 OUT = {}
-L = ffi.load("bls12_381")
 NAMES = ["mad_u64_u32 x8 indep", "mad_u64_u32 x8 dep", "mad+addc x8 dep", "mad+addc 2 chains x8", "mad+addc+s_nop x8 dep",
          "mul_lo_u32 x8 dep", "mul_hi_u32 x8 dep", "mad_u32_u24 x8 dep", "add_co+addc x8 dep", "fma_f64 x8 (4 chains)",
          "lshl_add_u64 x8 dep", "add_u32 x8 dep", "mul_lo_u32 x8 (4 chains)"]
-
-print("== instruction micro-benchmarks (cycles per 8-instruction block, per wave) ==")
-ub = {}
-for which, nm in enumerate(NAMES):
-    row = {}
-    for blocks, threads in ((256, 256), (256, 512), (256, 1024), (1024, 256)):
-        ms = ctypes.c_float(); cyc = ctypes.c_double()
-        ffi.check(L, L.sppark_devtest_ubench(which, 4000, blocks, threads, ctypes.byref(ms), ctypes.byref(cyc)))
-        waves = blocks * threads // 64
-        blk_per_s = waves * 4000 / (ms.value * 1e-3)
-        row["%dx%d" % (blocks, threads)] = {"ms": ms.value, "cyc_per_block": cyc.value, "blocks_per_s": blk_per_s}
-    ub[nm] = row
-    print("%-28s" % nm, " ".join("%s: %7.1f cyc %6.3f ms |" % (k, v["cyc_per_block"], v["ms"]) for k, v in row.items()))
-OUT["ubench"] = ub
-
-print("== field-level throughput (BLS12-381 fp) ==")
-fbres = {}
-for curve in ("bls12_381", "bn254"):
-    Lc = ffi.load(curve)
-    for op, nm, iters in ((0, "mul", 400), (1, "sqr", 400), (2, "add", 4000), (3, "xyzz madd", 60), (4, "xyzz add", 40)):
-        for blocks, threads in ((256, 256), (512, 256), (1024, 256), (2048, 256)):
-            ms = ctypes.c_float()
-            ffi.check(Lc, Lc.sppark_devtest_fieldbench(op, iters, blocks, threads, ctypes.byref(ms)))
-            rate = blocks * threads * iters / (ms.value * 1e-3)
-            fbres["%s %s %dx%d" % (curve, nm, blocks, threads)] = {"ms": ms.value, "ops_per_s": rate}
-            print("%-10s %-10s %5dx%d  %8.3f ms  %.3e ops/s" % (curve, nm, blocks, threads, ms.value, rate))
-OUT["fieldbench"] = fbres
-json.dump(OUT, open("gpurun_out/probe1.json", "w"), indent=1)
 
 print("== MSM timing (device-resident inputs) ==")
 msmres = {}
@@ -55,6 +26,8 @@ for curve, fb in (("bls12_381", 48), ("bn254", 32)):
     ctx = sppark_amd.MsmContext(curve)
     ctx.enable_timing(True)
     for lg in (16, 20, 22, 24, 26):
+        if len(sys.argv) > 1 and str(lg) not in sys.argv[1:]:
+            continue
         if curve == "bn254" and lg not in (20, 24, 26):
             continue
         n = 1 << lg
@@ -64,7 +37,7 @@ for curve, fb in (("bls12_381", 48), ("bn254", 32)):
         sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
         sc[:, 31] &= 0x1f
         torch.cuda.synchronize()
-        for wb in ((0,) if lg < 24 else (0, 14, 15)):
+        for wb in ((0,) if lg < 24 else (0, 16, 18, 20, 22)):
             ctx.tune(wbits=wb)
             t0 = time.time(); out = ctx.invoke(pts, sc); t1 = time.time()       # includes allocation
             t0 = time.time(); out = ctx.invoke(pts, sc); torch.cuda.synchronize(); t1 = time.time()
@@ -75,6 +48,6 @@ for curve, fb in (("bls12_381", 48), ("bn254", 32)):
             print("%-10s 2^%d wbits=%-2d  wall %9.2f ms  sort %8.2f  accum %9.2f  device %9.2f  scratch %.2f GB  %.3e pts/s"
                   % (curve, lg, wb, r["wall_ms"], r["sort_ms"], r["accum_ms"], r["device_ms"], r["scratch_GB"], r["pts_per_s"]))
             OUT["msm"] = msmres
-            json.dump(OUT, open("gpurun_out/probe1.json", "w"), indent=1)
+            json.dump(OUT, open("gpurun_out/probe_msm.json", "w"), indent=1)
         del pts, sc
     ctx.close()

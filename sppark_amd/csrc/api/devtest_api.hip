@@ -17,8 +17,7 @@ __global__ void k_field_op(u32* out, const u32* a, const u32* b, unsigned n, int
     constexpr int N = F::N;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    F x, y, r;
-    for (int k = 0; k < N; k++) { x.v[k] = a[(size_t)i * N + k]; y.v[k] = b[(size_t)i * N + k]; }
+    F x = F::from_wire(a + (size_t)i * N), y = F::from_wire(b + (size_t)i * N), r;
     switch (op) {
         case 0: r = x + y; break;
         case 1: r = x - y; break;
@@ -29,21 +28,21 @@ __global__ void k_field_op(u32* out, const u32* a, const u32* b, unsigned n, int
         case 6: r = x.to(); break;
         default: r = x.dbl(); break;
     }
-    for (int k = 0; k < N; k++) out[(size_t)i * N + k] = r.v[k];
+    r.to_wire(out + (size_t)i * N);
 }
 
 // op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
-__global__ void k_xyzz_op(bucket_d* out, const bucket_d* a, const unsigned char* b, unsigned n, int op)
+__global__ void k_xyzz_op(bucket_m* out, const bucket_m* a, const unsigned char* b, unsigned n, int op)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bucket_d p = bucket_d::load(&a[i]);
     if (op == 0) {
-        p.add(bucket_d::load(reinterpret_cast<const bucket_d*>(b) + i));
+        p.add(bucket_d::load(reinterpret_cast<const bucket_m*>(b) + i));
     } else if (op == 3) {
         p.dbl();
     } else {
-        affine_dev<fp_d> q = load_affine<fp_d, false>(b, i, 2 * sizeof(fp_d));
+        affine_dev<fp_d> q = load_affine<fp_d, false>(b, i, 8 * fp_d::N);
         p.madd(q, op == 2);
     }
     p.store(&out[i]);
@@ -84,8 +83,8 @@ SPPARK_FFI RustError sppark_devtest_xyzz_op(int op, void* out, const void* a, co
 {
     return guarded([&] {
         (void)select_gpu(-1);
-        size_t ab = n * sizeof(bucket_d), bb = n * (op == 0 ? sizeof(bucket_d) : 2 * sizeof(fp_d));
-        bucket_d *d_a, *d_o; unsigned char* d_b;
+        size_t ab = n * sizeof(bucket_m), bb = n * (op == 0 ? sizeof(bucket_m) : 8 * fp_d::N);
+        bucket_m *d_a, *d_o; unsigned char* d_b;
         HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_o, ab)); HIP_OK(hipMalloc((void**)&d_b, bb ? bb : 16));
         HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice));
         if (op != 3) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
@@ -220,9 +219,10 @@ SPPARK_FFI RustError sppark_devtest_ubench(int which, int iters, unsigned blocks
 __global__ void k_fieldbench(int op, int iters, u32* io)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    fp_d x, y;
-    for (int k = 0; k < fp_d::N; k++) { x.v[k] = io[k] ^ (i * 2654435761u >> 3); y.v[k] = io[k + fp_d::N] + i; }
-    x.v[fp_d::N - 1] &= 0x0fffffff; y.v[fp_d::N - 1] &= 0x0fffffff;
+    u32 wx[fp_d::N], wy[fp_d::N];
+    for (int k = 0; k < fp_d::N; k++) { wx[k] = io[k] ^ (i * 2654435761u >> 3); wy[k] = io[k + fp_d::N] + i; }
+    wx[fp_d::N - 1] &= 0x0fffffff; wy[fp_d::N - 1] &= 0x0fffffff;
+    fp_d x = fp_d::from_wire(wx), y = fp_d::from_wire(wy);
     if (op <= 2) {
         for (int it = 0; it < iters; it++) {
             if (op == 0) x = x * y; else if (op == 1) x = x.sqr(); else x = x + y;

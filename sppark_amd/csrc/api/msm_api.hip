@@ -9,14 +9,14 @@
 // the big kernels are instantiated in their own translation units
 // (msm/k_accumulate.hip, k_reduce.hip, k_bucket1.hip, k_bucketN.hip)
 namespace sppark_amd {
-extern template __global__ void k_accumulate<fp_d, false>(bucket_d*, u32*, bucket_d*, const unsigned char*, unsigned,
+extern template __global__ void k_accumulate<fp_d, false>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
-extern template __global__ void k_accumulate<fp_d, true>(bucket_d*, u32*, bucket_d*, const unsigned char*, unsigned,
+extern template __global__ void k_accumulate<fp_d, true>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
-extern template __global__ void k_reduce_runs<fp_d>(bucket_d*, u32*, bucket_d*, const u32*, const bucket_d*,
+extern template __global__ void k_reduce_runs<fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                     unsigned, unsigned, unsigned, int);
-extern template __global__ void k_bucket_level1<fp_d>(bucket_d*, bucket_d*, const bucket_d*, unsigned, unsigned, unsigned);
-extern template __global__ void k_bucket_levelN<fp_d>(bucket_d*, bucket_d*, const bucket_d*, const bucket_d*,
+extern template __global__ void k_bucket_level1<fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_levelN<fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
 }
 
@@ -138,16 +138,18 @@ __device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 j)
 }
 
 __global__ __launch_bounds__(64)
-void k_generate(xyzz_dev<fp_d>* out, unsigned n, u64 seed)
+void k_generate(bucket_m* out, unsigned n, u64 seed)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     affine_dev<fp_d> g;
+    u32 gx[fp_d::N], gy[fp_d::N];
     #pragma unroll
     for (int k = 0; k < fp_d::N / 2; k++) {
-        g.X.v[2*k] = (u32)curve_p::GX64[k]; g.X.v[2*k+1] = (u32)(curve_p::GX64[k] >> 32);
-        g.Y.v[2*k] = (u32)curve_p::GY64[k]; g.Y.v[2*k+1] = (u32)(curve_p::GY64[k] >> 32);
+        gx[2*k] = (u32)curve_p::GX64[k]; gx[2*k+1] = (u32)(curve_p::GX64[k] >> 32);
+        gy[2*k] = (u32)curve_p::GY64[k]; gy[2*k+1] = (u32)(curve_p::GY64[k] >> 32);
     }
+    g.X = fp_d::from_wire(gx); g.Y = fp_d::from_wire(gy);
     g.inf = false;
     u64 kw[4];
     for (int w = 0; w < 4; w++) kw[w] = splitmix64_at(seed, (u64)i * 4 + w);
@@ -168,7 +170,7 @@ SPPARK_FFI RustError sppark_g1_generate(void* out, size_t stride, size_t n, uint
     return guarded([&] {
         if (n == 0) return;
         (void)select_gpu(-1);
-        typedef xyzz_dev<fp_d> bucket_t;
+        typedef bucket_m bucket_t;
         bucket_t* d_pts;
         HIP_OK(hipMalloc((void**)&d_pts, n * sizeof(bucket_t)));
         hipLaunchKernelGGL(k_generate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_pts, (unsigned)n, seed);

@@ -33,15 +33,22 @@ SPPARK_DEVFN affine_dev<F> load_affine(const unsigned char* base, size_t idx, un
     constexpr int N = F::N;
     const unsigned char* p = base + idx * (size_t)stride;
     const uint2* q = reinterpret_cast<const uint2*>(p);
+    u32 wx[N], wy[N];
+    #pragma unroll
+    for (int i = 0; i < N / 2; i++) { uint2 w = q[i]; wx[2*i] = w.x; wx[2*i+1] = w.y; }
+    #pragma unroll
+    for (int i = 0; i < N / 2; i++) { uint2 w = q[N/2 + i]; wy[2*i] = w.x; wy[2*i+1] = w.y; }
     affine_dev<F> a;
-    #pragma unroll
-    for (int i = 0; i < N / 2; i++) { uint2 w = q[i]; a.X.v[2*i] = w.x; a.X.v[2*i+1] = w.y; }
-    #pragma unroll
-    for (int i = 0; i < N / 2; i++) { uint2 w = q[N/2 + i]; a.Y.v[2*i] = w.x; a.Y.v[2*i+1] = w.y; }
+    a.X = F::from_wire(wx); a.Y = F::from_wire(wy);
     if (FLAGGED) a.inf = (p[2 * N * 4] & 1) != 0;
     else         a.inf = a.X.is_zero() & a.Y.is_zero();
     return a;
 }
+
+// Memory image of a bucket: X | Y | ZZZ | ZZ in the wire format (32-bit limbs),
+// i.e. the reference's xyzz_t layout (ec/xyzz_t.hpp:17), whatever limb size the
+// register type uses.
+template<int N> struct alignas(16) xyzz_mem { u32 w[4 * N]; };
 
 template<class F> struct xyzz_dev {
     F X, Y, ZZZ, ZZ;
@@ -132,22 +139,26 @@ template<class F> struct xyzz_dev {
         X = X3; Y = Y3;
     }
 
-    SPPARK_DEVFN void store(xyzz_dev* dst) const
+    typedef xyzz_mem<F::N> mem_t;
+
+    SPPARK_DEVFN void store(mem_t* dst) const
     {
         constexpr int N = F::N;
+        u32 s[4 * N];
+        X.to_wire(s); Y.to_wire(s + N); ZZZ.to_wire(s + 2 * N); ZZ.to_wire(s + 3 * N);
         uint4* d = reinterpret_cast<uint4*>(dst);
-        const u32* s = reinterpret_cast<const u32*>(this);
         #pragma unroll
         for (int i = 0; i < N; i++) d[i] = make_uint4(s[4*i], s[4*i+1], s[4*i+2], s[4*i+3]);
     }
-    SPPARK_DEVFN static xyzz_dev load(const xyzz_dev* src)
+    SPPARK_DEVFN static xyzz_dev load(const mem_t* src)
     {
         constexpr int N = F::N;
-        xyzz_dev r;
+        u32 d[4 * N];
         const uint4* q = reinterpret_cast<const uint4*>(src);
-        u32* d = reinterpret_cast<u32*>(&r);
         #pragma unroll
         for (int i = 0; i < N; i++) { uint4 w = q[i]; d[4*i] = w.x; d[4*i+1] = w.y; d[4*i+2] = w.z; d[4*i+3] = w.w; }
+        xyzz_dev r;
+        r.X = F::from_wire(d); r.Y = F::from_wire(d + N); r.ZZZ = F::from_wire(d + 2 * N); r.ZZ = F::from_wire(d + 3 * N);
         return r;
     }
 };

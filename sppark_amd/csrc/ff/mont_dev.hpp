@@ -68,6 +68,12 @@ template<class P> struct mont_dev {
     static constexpr int N = P::N;
     u32 v[N];
 
+    // wire format == register format for the 32-bit-limb class
+    SPPARK_DEVFN static mont_dev from_wire(const u32* w)
+    {   mont_dev r; for (int i = 0; i < N; i++) r.v[i] = w[i]; return r;   }
+    SPPARK_DEVFN void to_wire(u32* w) const
+    {   for (int i = 0; i < N; i++) w[i] = v[i];   }
+
     SPPARK_DEVFN static mont_dev zero()
     {   mont_dev r; for (int i = 0; i < N; i++) r.v[i] = 0; return r;   }
     SPPARK_DEVFN static mont_dev one()

@@ -1,5 +1,5 @@
 #include "curve_select.hpp"
 #include "msm_kernels.hpp"
 namespace sppark_amd {
-template __global__ void k_bucket_level1<fp_d>(bucket_d*, bucket_d*, const bucket_d*, unsigned, unsigned, unsigned);
+template __global__ void k_bucket_level1<fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
 }

@@ -74,12 +74,12 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
 template<class FPp, class FRp>
 class msm_t {
 public:
-    typedef mont_dev<FPp> fp_d;
+    typedef fp_class<FPp> fp_d;
     typedef mont_dev<FRp> fr_d;
     typedef mont_host<FPp> fp_h;
-    typedef xyzz_dev<fp_d> bucket_t;
+    typedef typename xyzz_dev<fp_d>::mem_t bucket_t;       // memory image: wire format
     typedef jacobian_host<fp_h> point_t;
-    static constexpr size_t FP_BYTES = sizeof(fp_d);
+    static constexpr size_t FP_BYTES = 4 * FPp::N;
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
 
 private:

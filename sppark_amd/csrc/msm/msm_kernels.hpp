@@ -119,7 +119,7 @@ void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
 // are stored straight into buckets[key].
 // ---------------------------------------------------------------------------
 template<class FP, bool FLAGGED>
-SPPARK_DEVFN void accumulate_chunk(xyzz_dev<FP>* buckets, u32* rec_key, xyzz_dev<FP>* rec_pt,
+SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_mem<FP::N>* rec_pt,
                                    const unsigned char* points, unsigned stride,
                                    const u32* sorted, const u32* off,
                                    unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win,
@@ -169,8 +169,8 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_dev<FP>* buckets, u32* rec_key, xyzz_dev
 
 template<class FP, bool FLAGGED>
 __global__ __launch_bounds__(256)
-void k_accumulate(xyzz_dev<FP>* __restrict__ buckets,
-                  u32* __restrict__ rec_key, xyzz_dev<FP>* __restrict__ rec_pt,
+void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
+                  u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict__ rec_pt,
                   const unsigned char* __restrict__ points, unsigned stride,
                   const u32* __restrict__ sorted, const u32* __restrict__ off,
                   unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win)
@@ -184,8 +184,8 @@ void k_accumulate(xyzz_dev<FP>* __restrict__ buckets,
 // |last| = this is the final level (single work item): every run is complete.
 // ---------------------------------------------------------------------------
 template<class FP>
-SPPARK_DEVFN void reduce_runs_chunk(xyzz_dev<FP>* buckets, u32* out_key, xyzz_dev<FP>* out_pt,
-                                    const u32* in_key, const xyzz_dev<FP>* in_pt,
+SPPARK_DEVFN void reduce_runs_chunk(xyzz_mem<FP::N>* buckets, u32* out_key, xyzz_mem<FP::N>* out_pt,
+                                    const u32* in_key, const xyzz_mem<FP::N>* in_pt,
                                     unsigned nrec, unsigned F, unsigned nthreads, int last, unsigned t)
 {
     if (t >= nthreads) return;
@@ -222,9 +222,9 @@ SPPARK_DEVFN void reduce_runs_chunk(xyzz_dev<FP>* buckets, u32* out_key, xyzz_de
 
 template<class FP>
 __global__ __launch_bounds__(256)
-void k_reduce_runs(xyzz_dev<FP>* __restrict__ buckets,
-                   u32* __restrict__ out_key, xyzz_dev<FP>* __restrict__ out_pt,
-                   const u32* __restrict__ in_key, const xyzz_dev<FP>* __restrict__ in_pt,
+void k_reduce_runs(xyzz_mem<FP::N>* __restrict__ buckets,
+                   u32* __restrict__ out_key, xyzz_mem<FP::N>* __restrict__ out_pt,
+                   const u32* __restrict__ in_key, const xyzz_mem<FP::N>* __restrict__ in_pt,
                    unsigned nrec, unsigned F, unsigned nthreads, int last)
 {
     reduce_runs_chunk<FP>(buckets, out_key, out_pt, in_key, in_pt, nrec, F, nthreads, last,
@@ -237,13 +237,13 @@ void k_reduce_runs(xyzz_dev<FP>* __restrict__ buckets,
 // (running-sum trick of msm/pippenger.hpp:40-56 / pippenger.cuh:225-296)
 // ---------------------------------------------------------------------------
 template<class FP>
-SPPARK_DEVFN void bucket_level1_item(xyzz_dev<FP>* A, xyzz_dev<FP>* Wt, const xyzz_dev<FP>* buckets,
+SPPARK_DEVFN void bucket_level1_item(xyzz_mem<FP::N>* A, xyzz_mem<FP::N>* Wt, const xyzz_mem<FP::N>* buckets,
                                      unsigned NB, unsigned K, unsigned nwins, size_t id)
 {
     const unsigned nchunks = NB / K;
     if (id >= (size_t)nwins * nchunks) return;
     const unsigned w = id / nchunks, u = id % nchunks;
-    const xyzz_dev<FP>* row = buckets + (size_t)w * NB + (size_t)u * K;
+    const xyzz_mem<FP::N>* row = buckets + (size_t)w * NB + (size_t)u * K;
     xyzz_dev<FP> acc = xyzz_dev<FP>::load(&row[K - 1]), ret = acc;
     for (unsigned j = K - 1; j--;) {
         acc.add(xyzz_dev<FP>::load(&row[j]));
@@ -254,15 +254,15 @@ SPPARK_DEVFN void bucket_level1_item(xyzz_dev<FP>* A, xyzz_dev<FP>* Wt, const xy
 
 template<class FP>
 __global__ __launch_bounds__(256)
-void k_bucket_level1(xyzz_dev<FP>* __restrict__ A, xyzz_dev<FP>* __restrict__ Wt,
-                     const xyzz_dev<FP>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins)
+void k_bucket_level1(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __restrict__ Wt,
+                     const xyzz_mem<FP::N>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins)
 {   bucket_level1_item<FP>(A, Wt, buckets, NB, K, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // level >= 2: chunk u of K items (A_j, Wt_j), each item spanning 2^lgG buckets:
 //   A'[u] = sum_j A_j      Wt'[u] = sum_j Wt_j + 2^lgG * sum_j j*A_j
 template<class FP>
-SPPARK_DEVFN void bucket_levelN_item(xyzz_dev<FP>* A2, xyzz_dev<FP>* Wt2,
-                                     const xyzz_dev<FP>* A1, const xyzz_dev<FP>* Wt1,
+SPPARK_DEVFN void bucket_levelN_item(xyzz_mem<FP::N>* A2, xyzz_mem<FP::N>* Wt2,
+                                     const xyzz_mem<FP::N>* A1, const xyzz_mem<FP::N>* Wt1,
                                      unsigned nitems, unsigned K, unsigned lgG, unsigned nwins, size_t id)
 {
     const unsigned nchunks = nitems / K;
@@ -285,8 +285,8 @@ SPPARK_DEVFN void bucket_levelN_item(xyzz_dev<FP>* A2, xyzz_dev<FP>* Wt2,
 
 template<class FP>
 __global__ __launch_bounds__(256)
-void k_bucket_levelN(xyzz_dev<FP>* __restrict__ A2, xyzz_dev<FP>* __restrict__ Wt2,
-                     const xyzz_dev<FP>* __restrict__ A1, const xyzz_dev<FP>* __restrict__ Wt1,
+void k_bucket_levelN(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restrict__ Wt2,
+                     const xyzz_mem<FP::N>* __restrict__ A1, const xyzz_mem<FP::N>* __restrict__ Wt1,
                      unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)
 {   bucket_levelN_item<FP>(A2, Wt2, A1, Wt1, nitems, K, lgG, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 

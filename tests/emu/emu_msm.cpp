@@ -26,10 +26,10 @@ extern "C" int emu_field_op(int field, int op, void* out, const void* a, const v
 {
     for (size_t i = 0; i < n; i++) {
         if (field == 0) {
-            fp_d x, y, r; memcpy(&x, (const char*)a + i * sizeof(x), sizeof(x)); memcpy(&y, (const char*)b + i * sizeof(y), sizeof(y));
+            fp_d x = fp_d::from_wire((const u32*)a + i * fp_d::N), y = fp_d::from_wire((const u32*)b + i * fp_d::N), r;
             switch (op) { case 0: r = x + y; break; case 1: r = x - y; break; case 2: r = x * y; break; case 3: r = x.sqr(); break;
                           case 4: r = x.neg(); break; case 5: r = x.from(); break; case 6: r = x.to(); break; default: r = x.dbl(); }
-            memcpy((char*)out + i * sizeof(r), &r, sizeof(r));
+            r.to_wire((u32*)out + i * fp_d::N);
         } else {
             fr_d x, y, r; memcpy(&x, (const char*)a + i * sizeof(x), sizeof(x)); memcpy(&y, (const char*)b + i * sizeof(y), sizeof(y));
             switch (op) { case 0: r = x + y; break; case 1: r = x - y; break; case 2: r = x * y; break; case 3: r = x.sqr(); break;
@@ -43,12 +43,12 @@ extern "C" int emu_field_op(int field, int op, void* out, const void* a, const v
 // op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
 extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size_t n)
 {
-    const bucket_d* pa = (const bucket_d*)a; bucket_d* po = (bucket_d*)out;
+    const bucket_m* pa = (const bucket_m*)a; bucket_m* po = (bucket_m*)out;
     for (size_t i = 0; i < n; i++) {
         bucket_d p = bucket_d::load(&pa[i]);
-        if (op == 0) p.add(bucket_d::load((const bucket_d*)b + i));
+        if (op == 0) p.add(bucket_d::load((const bucket_m*)b + i));
         else if (op == 3) p.dbl();
-        else { affine_dev<fp_d> q = load_affine<fp_d, false>((const unsigned char*)b, i, 2 * sizeof(fp_d)); p.madd(q, op == 2); }
+        else { affine_dev<fp_d> q = load_affine<fp_d, false>((const unsigned char*)b, i, 8 * fp_d::N); p.madd(q, op == 2); }
         p.store(&po[i]);
     }
     return 0;
@@ -79,7 +79,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
     p.F = std::max(4u, F ? F : 32u);
     p.K = std::min(K ? K : 8u, p.NB);
-    const bool flagged = stride > 2 * sizeof(fp_d);
+    const bool flagged = stride > 8 * fp_d::N;
 
     // ---- breakdown (k_breakdown) ----
     std::vector<u32> digits((size_t)p.nwins * p.n), sorted((size_t)p.nwins * p.n);
@@ -136,11 +136,11 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         }
 
     // ---- accumulate + record levels ----
-    std::vector<bucket_d> buckets((size_t)p.nwins * p.NB);
-    memset(buckets.data(), 0, buckets.size() * sizeof(bucket_d));
+    std::vector<bucket_m> buckets((size_t)p.nwins * p.NB);
+    memset(buckets.data(), 0, buckets.size() * sizeof(bucket_m));
     size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win, nrecB = 2 * ((nrecA + p.F - 1) / p.F);
     std::vector<u32> keyA(nrecA), keyB(nrecB);
-    std::vector<bucket_d> ptA(nrecA), ptB(nrecB);
+    std::vector<bucket_m> ptA(nrecA), ptB(nrecB);
     // the device gather may read up to the padded stride; copy points into an 8-byte aligned buffer
     std::vector<uint64_t> pts_al((npoints * stride + 15) / 8);
     memcpy(pts_al.data(), points, npoints * stride);
@@ -154,7 +154,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         }
     {
         size_t nrec = nrecA;
-        u32 *ik = keyA.data(), *ok = keyB.data(); bucket_d *ip = ptA.data(), *op = ptB.data();
+        u32 *ik = keyA.data(), *ok = keyB.data(); bucket_m *ip = ptA.data(), *op = ptB.data();
         for (;;) {
             unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
             int last = nthreads == 1;
@@ -168,11 +168,11 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
 
     // ---- bucket sums ----
     size_t n1 = (size_t)p.nwins * (p.NB / p.K);
-    std::vector<bucket_d> A1(n1), W1(n1), A2(n1), W2(n1);
+    std::vector<bucket_m> A1(n1), W1(n1), A2(n1), W2(n1);
     unsigned nitems = p.NB / p.K;
     for (size_t id = 0; id < n1; id++) bucket_level1_item<fp_d>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id);
     unsigned lgG = lg2_floor(p.K);
-    bucket_d *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
+    bucket_m *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
     while (nitems > 1) {
         unsigned Kc = std::min(p.K, nitems);
         size_t nthr = (size_t)p.nwins * (nitems / Kc);

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--ntt-lg", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -60,8 +61,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # SPPARK_FORCE_DIST=1 exercises the RCCL exchange with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("SPPARK_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, "--gpus must equal WORLD_SIZE"
 
@@ -73,12 +78,12 @@ def main():
 
     def step():
         part = ctx.invoke(pts, sc)
-        if world > 1:
+        if use_dist:
             return multi_gpu.combine_partials(multi_gpu.all_gather_bytes(part))
         return part
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -92,7 +97,7 @@ def main():
         accum_ms.append(ctx.kernel_ms(1)); sort_ms.append(ctx.kernel_ms(0)); dev_ms.append(ctx.kernel_ms(2))
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -125,7 +130,40 @@ def main():
                "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "whole forward transform (3 LDS-tile passes) vs 16 B/element algorithmic"}}
+                            "note": "whole forward transform (3 register-radix passes, 0.8 GB of traffic) vs 16 B/element algorithmic"}}
+
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        # BASELINE configs[4]: alt_bn128 G1 MSM + BabyBear NTT (multi-field instantiation)
+        bpts, bsc = make_msm_inputs(args.lg, 7, "bn254", 32)
+        bctx = sppark_amd.MsmContext("bn254", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
+        bctx.invoke(bpts, bsc)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(3):
+            bctx.invoke(bpts, bsc)
+        torch.cuda.synchronize()
+        extras["alt_bn128_g1_msm_points_per_s"] = 3 * n / (time.perf_counter() - t1)
+        bctx.close(); del bpts, bsc
+        y = torch.randint(0, 0x78000000, (1 << args.ntt_lg,), dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream)
+        e1.record(); torch.cuda.synchronize()
+        extras["babybear_ntt_elems_per_s"] = 20 * (1 << args.ntt_lg) / (e0.elapsed_time(e1) * 1e-3)
+        # through-the-FFI path with HOST buffers (PCIe inclusive; never the headline value)
+        lgh = min(args.lg, 24)
+        hp = np.zeros(((1 << lgh), 104), dtype=np.uint8); hp[:, :96] = pts[:1 << lgh].cpu().numpy()
+        hs = sc[:1 << lgh].cpu().numpy()
+        sppark_amd.multi_scalar_mult_arkworks(hp[:4096], hs[:4096])
+        t1 = time.perf_counter()
+        sppark_amd.multi_scalar_mult_arkworks(hp, hs)
+        extras["mult_pippenger_inf_host_buffers"] = {"points": 1 << lgh, "seconds": time.perf_counter() - t1,
+                                                     "points_per_s": (1 << lgh) / (time.perf_counter() - t1)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -173,11 +211,11 @@ def main():
                                  "%d mixed additions per launch = %.3e additions/s against a measured "
                                  "5.14e9/s mixed-addition micro-benchmark" % (nwins * n, nwins * n / (a_ms * 1e-3))},
             "phases_ms": {"digits_sort": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
-            "cpu_baseline": cpu, "ntt": ntt,
+            "cpu_baseline": cpu, "ntt": ntt, "extras": extras,
         }
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

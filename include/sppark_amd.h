@@ -65,6 +65,8 @@ bool  cuda_available(void);
 void  drop_gpu_ptr_t(void **ref);           /* gpu_ptr_t<void>& : one pointer to a ref-counted block */
 void *clone_gpu_ptr_t(void *const *ref);    /* returns gpu_ptr_t<void>::by_value                      */
 void  drop_error_message(char *msg);
+/* poc/go/poc.cu:17-32 — Go bridge smoke test: launches a trivial kernel; message always set */
+SppError cuda_func(void *ptr);
 
 /* ------------------------------------------------------------------------ */
 /* 2. Extension surface (device-resident inputs, reusable scratch, timers)   */
@@ -105,6 +107,12 @@ void sppark_g1_to_affine(void *out_xy, const void *jacobian);
  * out: affine, stride bytes apart (flag byte written when stride > 2*sizeof(fp)).
  * out may be a host or device pointer.  Synthetic-input generator for benches. */
 SppError sppark_g1_generate(void *out, size_t stride, size_t n, uint64_t seed);
+
+/* gpu_ptr_t<void> handles for C callers (the reference creates them from C++ only):
+ * allocate `bytes` of device memory behind a ref-counted handle / read its device pointer.
+ * Release with drop_gpu_ptr_t, share with clone_gpu_ptr_t. */
+void *sppark_gpu_ptr_alloc(size_t bytes);
+void *sppark_gpu_ptr_get(void *const *ref);
 
 /* NTT on a device- or host-resident buffer with an explicit stream. */
 SppError sppark_ntt(size_t device_id, void *inout, uint32_t lg_domain_size,

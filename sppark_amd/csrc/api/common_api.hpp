@@ -50,3 +50,16 @@ SPPARK_FFI void* sppark_gpu_ptr_get(void* const* ref)
 // reference's build drivers (rust/src/build.rs:9, go/sppark.go:296).
 SPPARK_FFI void drop_error_message(char* ptr)
 {   free(ptr);   }
+
+// Go bridge smoke test symbol (poc/go/poc.cu:17-32, called by poc/go/poc.go:3-22):
+// launches a trivial kernel and returns {code, strdup(message)} -- the message
+// is always set, as in the reference.
+__global__ void sppark_hello_kernel(int* flag) { if (flag) *flag = 1; }
+SPPARK_FFI sppark_amd::RustError cuda_func(void* ptr)
+{
+    (void)ptr;
+    hipLaunchKernelGGL(sppark_hello_kernel, dim3(1), dim3(1), 0, 0, (int*)nullptr);
+    hipError_t err = hipGetLastError();
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    return sppark_amd::RustError{(int)err, strdup(hipGetErrorString(err))};
+}

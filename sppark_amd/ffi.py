@@ -53,6 +53,8 @@ def load(name):
     vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
     L.cuda_available.restype = ctypes.c_bool
     L.drop_error_message.argtypes = [vp]
+    L.cuda_func.argtypes = [vp]
+    L.cuda_func.restype = _Error
     L.drop_gpu_ptr_t.argtypes = [ctypes.POINTER(vp)]
     L.clone_gpu_ptr_t.argtypes = [ctypes.POINTER(vp)]
     L.clone_gpu_ptr_t.restype = vp

@@ -22,7 +22,8 @@ def declared_symbols():
 def test_header_symbols_exported(libs):
     syms = declared_symbols()
     assert "mult_pippenger_inf" in syms and "compute_ntt" in syms and "cuda_available" in syms
-    common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message"}
+    common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message", "cuda_func",
+              "sppark_gpu_ptr_alloc", "sppark_gpu_ptr_get"}
     msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1")}
     ntt_only = {"compute_ntt", "sppark_ntt"}
     assert set(syms) == common | msm_only | ntt_only

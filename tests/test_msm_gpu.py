@@ -250,3 +250,24 @@ def test_msm_large_linearity(oracle, libs):
     m = 1 << 16
     assert (sppark_amd.to_affine(ctx.invoke(pts[:m], a[:m])) == O.msm_affine(0, pts[:m], a[:m], algo=0, param=8)).all()
     ctx.close()
+
+
+def test_go_bridge_smoke_and_gpu_ptr(libs):
+    """poc/go/poc_test.go:8-15: cuda_func runs when IsCudaAvailable(); gpu_ptr_t
+    clone/drop keep the ref-count protocol of util/gpu_t.cuh:269-318."""
+    import ctypes
+    from sppark_amd import ffi
+    L = ffi.load("bls12_381")
+    assert L.cuda_available()
+    err = L.cuda_func(None)
+    assert err.code == 0 and ctypes.string_at(err.message)
+    L.drop_error_message(err.message)
+    L.sppark_gpu_ptr_alloc.argtypes = [ctypes.c_size_t]; L.sppark_gpu_ptr_alloc.restype = ctypes.c_void_p
+    L.sppark_gpu_ptr_get.argtypes = [ctypes.POINTER(ctypes.c_void_p)]; L.sppark_gpu_ptr_get.restype = ctypes.c_void_p
+    a = ctypes.c_void_p(L.sppark_gpu_ptr_alloc(1 << 20))
+    assert a.value and L.sppark_gpu_ptr_get(ctypes.byref(a))
+    b = ctypes.c_void_p(L.clone_gpu_ptr_t(ctypes.byref(a)))
+    assert b.value == a.value
+    L.drop_gpu_ptr_t(ctypes.byref(a))
+    assert a.value is None and L.sppark_gpu_ptr_get(ctypes.byref(b))      # still alive through the clone
+    L.drop_gpu_ptr_t(ctypes.byref(b))

@@ -67,6 +67,9 @@ def lib():
         L.oracle_ntt_bb31.argtypes = [vp, ctypes.c_uint, ci, ci, ci]
         L.oracle_ntt_naive_gl64.argtypes = [vp, vp, ctypes.c_uint, ci]
         L.oracle_ntt_naive_bb31.argtypes = [vp, vp, ctypes.c_uint, ci]
+        L.oracle_ntt_fr.argtypes = [ci, vp, ctypes.c_uint, ci, ci, ci]
+        L.oracle_ntt_naive_fr.argtypes = [ci, vp, vp, ctypes.c_uint, ci]
+        L.oracle_fr_root.argtypes = [ci, vp, ctypes.c_uint]
         L.oracle_gl64_root.argtypes = [ctypes.c_uint]; L.oracle_gl64_root.restype = u64
         L.oracle_bb31_root.argtypes = [ctypes.c_uint]; L.oracle_bb31_root.restype = ctypes.c_uint32
         L.oracle_gl64_mul.argtypes = [u64, u64]; L.oracle_gl64_mul.restype = u64
@@ -199,6 +202,28 @@ def ntt_bb31(a, order=NN, direction=FORWARD, type=STANDARD):
     assert a.size == 1 << lg
     lib().oracle_ntt_bb31(_ptr(a), lg, order, direction, type)
     return a
+
+
+def ntt_fr(curve, a, order=NN, direction=FORWARD, type=STANDARD):
+    """a: (n, 4) uint64 Montgomery limbs of the curve's scalar field"""
+    a = np.array(a, dtype=np.uint64).reshape(-1, 4)
+    lg = int(a.shape[0]).bit_length() - 1
+    assert a.shape[0] == 1 << lg
+    lib().oracle_ntt_fr(curve, _ptr(a), lg, order, direction, type)
+    return a
+
+
+def ntt_naive_fr(curve, a, inverse=False):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(a)
+    lib().oracle_ntt_naive_fr(curve, _ptr(out), _ptr(a), int(a.shape[0]).bit_length() - 1, int(inverse))
+    return out
+
+
+def fr_root(curve, lg):
+    out = np.zeros(4, dtype=np.uint64)
+    lib().oracle_fr_root(curve, _ptr(out), lg)
+    return out
 
 
 def ntt_naive_gl64(a, inverse=False):

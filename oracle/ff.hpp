@@ -193,12 +193,32 @@ public:
     }
     friend mont_t operator/(int one_, const mont_t& a)
     {   if (one_ != 1) __builtin_trap(); return a.reciprocal();   }
+
+    // NTT conventions of ntt/parameters/{bls12_381,alt_bn128}.h:11-14: group_gen
+    // (7 resp. 5) and forward_roots_of_unity[S] = group_gen^((r-1)/2^S)
+    // (checked against the reference tables by tests/test_oracle.py).
+    static const unsigned TWO_ADICITY = P::TWO_ADICITY;
+    static mont_t group_gen()
+    {   mont_t g; g.zero(); for (unsigned i = 0; i < P::GEN; i++) g += one(); return g;   }
+    static mont_t top_root()
+    {
+        uint64_t e[N];
+        for (size_t i = 0; i < N; i++) e[i] = P::MOD[i];
+        e[0] -= 1;
+        mont_t r = one(), b = group_gen();
+        for (size_t bit = P::TWO_ADICITY; bit < 64 * N; bit++) {
+            if ((e[bit / 64] >> (bit % 64)) & 1) r *= b;
+            b ^= 2;
+        }
+        return r;
+    }
 };
 
 // ---------------------------------------------------------------------------
 // Parameter sets.  TO_LIMB values are the reference's tables.
 // ---------------------------------------------------------------------------
-struct bls12_381_fp_params {        // ff/bls12-381.hpp:100-116
+struct bls12_381_fp_params {
+    static const unsigned TWO_ADICITY = 0, GEN = 0;   // NTT domain (scalar fields only)        // ff/bls12-381.hpp:100-116
     static const size_t N = 6, NBITS = 381;
     static constexpr uint64_t MOD[6] = {
         0xb9feffffffffaaab, 0x1eabfffeb153ffff, 0x6730d2a0f6b0f624,
@@ -211,7 +231,8 @@ struct bls12_381_fp_params {        // ff/bls12-381.hpp:100-116
         0x77ce585370525745, 0x5c071a97a256ec6d, 0x15f65ec3fa80e493 };
     static const uint64_t M0 = 0x89f3fffcfffcfffd;
 };
-struct bls12_381_fr_params {        // ff/bls12-381.hpp:125-138
+struct bls12_381_fr_params {
+    static const unsigned TWO_ADICITY = 32, GEN = 7;   // NTT domain (scalar fields only)        // ff/bls12-381.hpp:125-138
     static const size_t N = 4, NBITS = 255;
     static constexpr uint64_t MOD[4] = {
         0xffffffff00000001, 0x53bda402fffe5bfe, 0x3339d80809a1d805, 0x73eda753299d7d48 };
@@ -221,7 +242,8 @@ struct bls12_381_fr_params {        // ff/bls12-381.hpp:125-138
         0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f };
     static const uint64_t M0 = 0xfffffffeffffffff;
 };
-struct alt_bn128_fp_params {        // ff/alt_bn128.hpp:88-101
+struct alt_bn128_fp_params {
+    static const unsigned TWO_ADICITY = 0, GEN = 0;   // NTT domain (scalar fields only)        // ff/alt_bn128.hpp:88-101
     static const size_t N = 4, NBITS = 254;
     static constexpr uint64_t MOD[4] = {
         0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029 };
@@ -231,7 +253,8 @@ struct alt_bn128_fp_params {        // ff/alt_bn128.hpp:88-101
         0xd35d438dc58f0d9d, 0x0a78eb28f5c70b3d, 0x666ea36f7879462c, 0x0e0a77c19a07df2f };
     static const uint64_t M0 = 0x87d20782e4866389;
 };
-struct alt_bn128_fr_params {        // ff/alt_bn128.hpp:111-124
+struct alt_bn128_fr_params {
+    static const unsigned TWO_ADICITY = 28, GEN = 5;   // NTT domain (scalar fields only)        // ff/alt_bn128.hpp:111-124
     static const size_t N = 4, NBITS = 254;
     static constexpr uint64_t MOD[4] = {
         0x43e1f593f0000001, 0x2833e84879b97091, 0xb85045b68181585d, 0x30644e72e131a029 };

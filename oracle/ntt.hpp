@@ -48,6 +48,7 @@ template<class F> static F finv(F a, unsigned lg_order)   // a has order 2^lg_or
 template<class F> static F field_inverse(F a);             // a^(p-2)
 template<> inline gl64 field_inverse<gl64>(gl64 a) { return fpow(a, gl64::MOD - 2); }
 template<> inline bb31 field_inverse<bb31>(bb31 a) { return fpow(a, (uint64_t)bb31::MOD - 2); }
+template<class P> static mont_t<P> field_inverse(mont_t<P> a) { return a.reciprocal(); }
 
 template<class F> static void bit_rev_permute(F* a, unsigned lg)
 {

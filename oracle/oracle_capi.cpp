@@ -296,6 +296,23 @@ void oracle_ntt_naive_gl64(uint64_t* out, const uint64_t* in, unsigned lg, int i
 void oracle_ntt_naive_bb31(uint32_t* out, const uint32_t* in, unsigned lg, int inv)
 {   ntt_naive(reinterpret_cast<bb31*>(out), reinterpret_cast<const bb31*>(in), lg, inv != 0);   }
 
+// 256-bit scalar fields: field 0 = BLS12-381 Fr, 1 = alt_bn128 Fr; elements are 4 x u64 Montgomery limbs
+void oracle_ntt_fr(int field, uint64_t* inout, unsigned lg, int order, int direction, int type)
+{
+    if (field == 0) ntt(reinterpret_cast<bls12_381_fr*>(inout), lg, order, direction, type);
+    else            ntt(reinterpret_cast<alt_bn128_fr*>(inout), lg, order, direction, type);
+}
+void oracle_ntt_naive_fr(int field, uint64_t* out, const uint64_t* in, unsigned lg, int inv)
+{
+    if (field == 0) ntt_naive(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg, inv != 0);
+    else            ntt_naive(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg, inv != 0);
+}
+void oracle_fr_root(int field, uint64_t* out, unsigned lg)
+{
+    if (field == 0) { auto w = root_of_unity<bls12_381_fr>(lg); memcpy(out, w.v, 32); }
+    else            { auto w = root_of_unity<alt_bn128_fr>(lg); memcpy(out, w.v, 32); }
+}
+
 uint64_t oracle_gl64_root(unsigned lg) { return root_of_unity<gl64>(lg).raw(); }
 uint32_t oracle_bb31_root(unsigned lg) { return root_of_unity<bb31>(lg).raw(); }
 uint64_t oracle_gl64_mul(uint64_t a, uint64_t b) { return (gl64::from_raw(a) * gl64::from_raw(b)).raw(); }

@@ -21,7 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          "-Wno-duplicate-decl-specifier"]
 
 MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
-           "msm/k_bucket1.hip", "msm/k_bucketN.hip", "api/devtest_api.hip"]
+           "msm/k_bucket1.hip", "msm/k_bucketN.hip", "api/devtest_api.hip",
+           "api/ntt_api.hip:SPPARK_NTT_WITH_MSM"]          # compute_ntt over the curve's scalar field
 NTT_TUS = ["api/ntt_api.hip"]
 
 TARGETS = {
@@ -49,7 +50,8 @@ def _sources_stamp():
 def _compile(job):
     src, obj, feature = job
     t0 = time.time()
-    cmd = [HIPCC] + FLAGS + ["-D" + feature, "-c", os.path.join(CSRC, src), "-o", obj]
+    src, _, extra = src.partition(":")
+    cmd = [HIPCC] + FLAGS + ["-D" + feature] + (["-D" + extra] if extra else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     return src, feature, time.time() - t0, r.returncode, r.stderr
 
@@ -59,7 +61,7 @@ def build(only=None, force=False, verbose=True, jobs=None):
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = _sources_stamp()
     names = [n for n in TARGETS if (only is None or n in only)]
-    names = [n for n in names if all(os.path.exists(os.path.join(CSRC, s)) for s in TARGETS[n][1])]
+    names = [n for n in names if all(os.path.exists(os.path.join(CSRC, s.split(":")[0])) for s in TARGETS[n][1])]
     todo, links = [], {}
     for n in names:
         feature, tus = TARGETS[n]
@@ -69,7 +71,7 @@ def build(only=None, force=False, verbose=True, jobs=None):
             continue
         objs = []
         for s in tus:
-            obj = os.path.join(OBJDIR, "%s__%s.o" % (n, s.replace("/", "_")))
+            obj = os.path.join(OBJDIR, "%s__%s.o" % (n, s.split(":")[0].replace("/", "_")))
             objs.append(obj)
             todo.append((s, obj, feature))
         links[n] = objs

@@ -1,8 +1,13 @@
 // C-ABI of the NTT library (one .so per field: -DFEATURE_GOLDILOCKS /
 // -DFEATURE_BABY_BEAR, as poc/ntt-cuda/build.rs selects them).  Declarations +
 // reference citations: include/sppark_amd.h.
+#include "../ff/params.hpp"
 #include "../ntt/ntt_driver.hpp"
-#include "common_api.hpp"
+#ifdef SPPARK_NTT_WITH_MSM            // same .so as msm_api.hip, which already defines the common symbols
+# define SPPARK_FFI extern "C" __attribute__((visibility("default")))
+#else
+# include "common_api.hpp"
+#endif
 
 using namespace sppark_amd;
 
@@ -10,6 +15,10 @@ using namespace sppark_amd;
 typedef gl64_dev fr_t;
 #elif defined(FEATURE_BABY_BEAR)
 typedef bb31_dev fr_t;
+#elif defined(FEATURE_BLS12_381)       // poc/ntt-cuda/cuda/ntt_api.cu:7-8 -> ff/bls12-381.hpp fr_t
+typedef fr256_dev<bls12_381_fr_p> fr_t;
+#elif defined(FEATURE_BN254)           // ntt_api.cu:15-16 -> ff/alt_bn128.hpp fr_t
+typedef fr256_dev<alt_bn128_fr_p> fr_t;
 #else
 # error "no FEATURE"
 #endif
@@ -58,20 +67,16 @@ __global__ void k_small_field_op(fr_t* out, const fr_t* a, const fr_t* b, unsign
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fr_t x = a[i], y = b[i], r;
+    fr_t x = a[i], y = b[i], r = x;
     if (op == 0) r = x + y;
     else if (op == 1) r = x - y;
     else if (op == 2) r = x * y;
     else if (op == 4) { r = x; for (int k = 0; k < 12; k++) r = r * r; }
-    else if (op == 5) r = field_pow(x, (u64)(y.v & 0xffff));
+    else if (op == 5) r = field_pow(x, (u64)(*reinterpret_cast<const u32*>(&y) & 0xffff));
     else if (op == 6) { r = x; if (i & 1) { for (unsigned k = 0; k < (i & 15); k++) r = r * r + y; } }
-    else {
 #if defined(FEATURE_GOLDILOCKS)
-        r = gl64_dev::mul_pow2(x, (unsigned)(y.v & 0xff) % 192);
-#else
-        r = x;
+    else r = gl64_dev::mul_pow2(x, (unsigned)(y.v & 0xff) % 192);
 #endif
-    }
     out[i] = r;
 }
 

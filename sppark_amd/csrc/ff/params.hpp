@@ -40,6 +40,8 @@ struct bls12_381_fp_p {
 // BLS12-381 scalar field, ff/bls12-381.hpp:35-51 / :125-138
 struct bls12_381_fr_p {
     static constexpr int N = 8, N64 = 4, NBITS = 255;
+    // NTT: group_gen = 7, roots[k] = 7^((r-1)/2^k), S = 32 (ntt/parameters/bls12_381.h:11-14)
+    static constexpr unsigned TWO_ADICITY = 32, GROUP_GEN = 7;
     static constexpr uint64_t MOD64[4] = {
         0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL };
     static constexpr uint64_t RR64[4] = {           // 2^512 mod r
@@ -78,6 +80,8 @@ struct alt_bn128_fp_p {
 // alt_bn128 scalar field, ff/alt_bn128.hpp:32-48 / :111-124
 struct alt_bn128_fr_p {
     static constexpr int N = 8, N64 = 4, NBITS = 254;
+    // NTT: group_gen = 5, roots[k] = 5^((r-1)/2^k), S = 28 (ntt/parameters/alt_bn128.h:11-14)
+    static constexpr unsigned TWO_ADICITY = 28, GROUP_GEN = 5;
     static constexpr uint64_t MOD64[4] = {
         0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL };
     static constexpr uint64_t RR64[4] = {

@@ -4,6 +4,8 @@
 // device and kept for the life of the process, kernel sequence on one stream.
 #pragma once
 #include "ntt_kernels.hpp"
+#include "../ff/fr256_dev.hpp"
+#include "../ff/mont_host.hpp"
 #include "../util/runtime.hpp"
 #include <map>
 #include <mutex>
@@ -38,14 +40,45 @@ template<> struct host_field<bb31_dev> {                        // canonical ari
     static bb31_dev wire(u64 canonical) { bb31_dev r; r.v = (u32)((canonical << 32) % P); return r; }
 };
 
+// 256-bit fields: everything stays in the Montgomery domain, which is the wire format
+template<class P> struct host_field<fr256_dev<P>> {
+    typedef mont_host<P> H;
+    struct elem { H v; };
+    static elem mul(const elem& a, const elem& b) { return elem{a.v * b.v}; }
+    static elem one() { return elem{H::one()}; }
+    static elem small(unsigned k) { elem r{H::zero()}; for (unsigned i = 0; i < k; i++) r.v = r.v + H::one(); return r; }
+    static elem inv(const elem& a) { return elem{a.v.inverse()}; }
+    static elem gen() { return small(P::GROUP_GEN); }
+    static elem top_root()                          // gen^((r-1) >> S)
+    {
+        uint64_t e[P::N64];
+        for (int i = 0; i < P::N64; i++) e[i] = P::MOD64[i];
+        e[0] -= 1;                                  // r is odd
+        elem r = one(), b = gen();
+        for (unsigned bit = P::TWO_ADICITY; bit < 64 * P::N64; bit++) {
+            if ((e[bit / 64] >> (bit % 64)) & 1) r = mul(r, b);
+            // square AFTER use: b = gen^(2^(bit - S + 1))
+            b = mul(b, b);
+        }
+        return r;
+    }
+    static elem two_pow(unsigned lg) { elem r = one(), two = small(2); for (unsigned i = 0; i < lg; i++) r = mul(r, two); return r; }
+    static fr256_dev<P> wire(const elem& a) { fr256_dev<P> r; memcpy(r.v, a.v.v, sizeof(r.v)); return r; }
+};
+
 template<class F>
 class ntt_engine {
     struct table_set { F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale; };
     std::map<std::tuple<int, unsigned, int>, table_set> cache;     // (hip device, lg, inverse)
     std::mutex mtx;
 
-    static constexpr unsigned LG_LINE = sizeof(F) == 8 ? 4 : 5;     // elements per 128-byte line
-    static constexpr unsigned LG_TILE = sizeof(F) == 8 ? 12 : 13;   // 32 KB LDS tile
+    // elements per 128-byte line / per 32 KB LDS tile
+    static constexpr unsigned LG_LINE = sizeof(F) == 4 ? 5 : sizeof(F) == 8 ? 4 : 2;
+    static constexpr unsigned LG_TILE = sizeof(F) == 4 ? 13 : sizeof(F) == 8 ? 12 : 10;
+    // stages per pass.  For 256-bit elements hipcc keeps the 16-element arrays of a radix-16
+    // round in scratch memory (528 B/lane); fewer stages per pass avoid that but cost more
+    // passes and measured slower at 2^20..2^24 (7-14 ms vs 8 ms), so 8 stays for now.
+    static constexpr unsigned S_MAX = 8;
 
     const table_set& tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
     {
@@ -59,9 +92,9 @@ class ntt_engine {
         size_t nlo = (size_t)1 << t.h, nhi = (size_t)1 << (lg - t.h);
         HIP_OK(hipMalloc((void**)&t.lo, (2 * (nlo + nhi) + 512) * sizeof(F)));
         t.hi = t.lo + nlo; t.glo = t.hi + nhi; t.ghi = t.glo + nlo; t.inner = t.ghi + nhi;
-        u64 w = H::top_root();
+        auto w = H::top_root();
         for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = H::mul(w, w);
-        u64 g = H::gen();
+        auto g = H::gen();
         if (inverse) { w = H::inv(w); g = H::inv(g); }
         t.scale = H::wire(H::inv(H::two_pow(lg)));
         unsigned grid = (unsigned)((std::max<size_t>(std::max(nlo, nhi), 512) + 255) / 256);
@@ -96,7 +129,9 @@ public:
         if (!inverse && type == NTT_COSET)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
 
-        ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE);
+        unsigned smax = S_MAX;
+        if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) smax = v; }   // tuning knob
+        ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, smax);
         for (unsigned i = 0; i < pl.npass; i++) {
             ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
             P.apply_scale = inverse && i == pl.npass - 1;

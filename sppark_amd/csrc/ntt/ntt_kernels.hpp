@@ -293,14 +293,13 @@ __global__ __launch_bounds__(256) void k_tables(F* lo, F* hi, F* inner, F base, 
 {   table_item(lo, hi, inner, base, lg_n, h, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // ---- planning (host) ---------------------------------------------------------
-struct ntt_plan { ntt_pass pass[8]; unsigned npass; };
+struct ntt_plan { ntt_pass pass[16]; unsigned npass; };
 
 // GS/DIF order (pass 0 splits the whole transform).  |lgCmax| = log2 of the
 // elements in one 128-byte line, |lg_tile| = log2 of the LDS tile capacity.
-static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg_tile)
+static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg_tile, unsigned Smax = 8)
 {
     ntt_plan pl; pl.npass = 0;
-    const unsigned Smax = 8;
     unsigned np = (lg_n + Smax - 1) / Smax;
     unsigned rem = lg_n;
     for (unsigned i = 0; i < np; i++) {

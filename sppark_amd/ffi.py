@@ -96,7 +96,7 @@ def load(name):
         L.sppark_devtest_ubench.restype = _Error
         L.sppark_devtest_fieldbench.argtypes = [ci, ci, cu, cu, ctypes.POINTER(ctypes.c_float)]
         L.sppark_devtest_fieldbench.restype = _Error
-    if name in NTT_FIELDS:
+    if name in NTT_FIELDS or name in CURVES:
         L.compute_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci]
         L.compute_ntt.restype = _Error
         L.sppark_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci, vp]

@@ -22,7 +22,9 @@ class NTTType(enum.IntEnum):
     Coset = 1
 
 
-_ELEM_BYTES = {"gl64": 8, "bb31": 4}
+# one library per field (poc/ntt-cuda/build.rs features): gl64, bb31, and the scalar
+# fields of the two curves (256-bit Montgomery elements)
+_ELEM_BYTES = {"gl64": 8, "bb31": 4, "bls12_381": 32, "bn254": 32}
 
 
 def compute_ntt(device_id, inout, order, direction, ntt_type, field="gl64", stream=None):

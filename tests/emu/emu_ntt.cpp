@@ -2,7 +2,9 @@
 // Runs the phase functions of sppark_amd/csrc/ntt/ntt_kernels.hpp for every
 // (tile, thread) the GPU grid would cover, in the driver's launch order.
 #define SPPARK_HOST_EMULATION 1
+#include "../../sppark_amd/csrc/ff/params.hpp"
 #include "../../sppark_amd/csrc/ntt/ntt_kernels.hpp"
+#include "../../sppark_amd/csrc/ff/fr256_dev.hpp"
 #include <vector>
 #include <cstring>
 using namespace sppark_amd;
@@ -10,12 +12,33 @@ using namespace sppark_amd;
 #if defined(FEATURE_GOLDILOCKS)
 typedef gl64_dev F;
 static const unsigned LG_LINE = 4, LG_TILE = 12;
-#else
+static F finv(F a) { return field_pow(a, (u64)F::MOD - 2); }
+static F top_root() { return F::top_root(); }
+static F group_gen() { return F::group_gen(); }
+#elif defined(FEATURE_BABY_BEAR)
 typedef bb31_dev F;
 static const unsigned LG_LINE = 5, LG_TILE = 13;
-#endif
-
 static F finv(F a) { return field_pow(a, (u64)F::MOD - 2); }
+static F top_root() { return F::top_root(); }
+static F group_gen() { return F::group_gen(); }
+#else
+# if defined(FEATURE_BLS12_381)
+typedef bls12_381_fr_p FRP;
+# else
+typedef alt_bn128_fr_p FRP;
+# endif
+typedef fr256_dev<FRP> F;
+static const unsigned LG_LINE = 2, LG_TILE = 10;
+static F pow_big(F b, const uint64_t* e, unsigned from_bit)
+{
+    F r = F::one();
+    for (unsigned bit = from_bit; bit < 256; bit++) { if ((e[bit / 64] >> (bit % 64)) & 1) r = r * b; b = b * b; }
+    return r;
+}
+static F finv(F a) { uint64_t e[4]; for (int i = 0; i < 4; i++) e[i] = FRP::MOD64[i]; e[0] -= 2; return pow_big(a, e, 0); }
+static F group_gen() { F g = F::one(); F one = F::one(); for (unsigned i = 1; i < FRP::GROUP_GEN; i++) g = g + one; return g; }
+static F top_root() { uint64_t e[4]; for (int i = 0; i < 4; i++) e[i] = FRP::MOD64[i]; e[0] -= 1; return pow_big(group_gen(), e, FRP::TWO_ADICITY); }
+#endif
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
@@ -25,9 +48,9 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     const int inverse = direction == 1;
     unsigned h = lg < 12 ? lg : 12;
     std::vector<F> lo(1u << h), hi((size_t)1 << (lg - h)), glo(1u << h), ghi((size_t)1 << (lg - h)), inner(512);
-    F w = F::top_root();
+    F w = top_root();
     for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = w * w;
-    F g = F::group_gen();
+    F g = group_gen();
     if (inverse) { w = finv(w); g = finv(g); }
     for (size_t k = 0; k < std::max<size_t>(std::max(lo.size(), hi.size()), 512); k++) {
         table_item(lo.data(), hi.data(), inner.data(), w, lg, h, k);
@@ -45,7 +68,10 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     }
     if (!inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)bitrev, i);
 
-    ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE);
+#ifndef EMU_SMAX
+#define EMU_SMAX 8
+#endif
+    ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
     for (unsigned i = 0; i < pl.npass; i++) {
         ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
         P.apply_scale = inverse && i == pl.npass - 1;

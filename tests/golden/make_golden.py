@@ -105,6 +105,22 @@ def make_ntt():
                             out = np.array([v * R % p for v in y], dtype=np.uint32)
                         cases.append({"field": field, "lg": lg, "order": order, "direction": direction,
                                       "type": typ, "input": hexs(x), "expect": hexs(out)})
+    # 256-bit scalar fields (wire format: Montgomery, R = 2^256); roots g^((r-1)/2^S), g = 7 / 5
+    R256 = 1 << 256
+    for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28)):
+        p = O.FR_MODULUS[curve]
+        rinv = pow(R256, p - 2, p)
+        top = pow(gen, (p - 1) >> S, p)
+        for lg in (1, 3, 4):
+            x = recipe.ntt_input(field, lg, 0x5eed5eed0003 + lg)
+            xc = [int.from_bytes(row.tobytes(), "little") * rinv % p for row in x]
+            for order in range(4):
+                for direction in range(2):
+                    for typ in range(2):
+                        y = py_ntt(xc, lg, order, direction, typ, p, top, S, gen)
+                        out = np.frombuffer(b"".join((v * R256 % p).to_bytes(32, "little") for v in y), dtype=np.uint64)
+                        cases.append({"field": field, "lg": lg, "order": order, "direction": direction,
+                                      "type": typ, "input": hexs(x), "expect": hexs(out)})
     json.dump(cases, open(os.path.join(HERE, "ntt_golden.json"), "w"), indent=0)
     print("ntt cases:", len(cases))
 

@@ -40,6 +40,10 @@ def msm_inputs(curve, n, seed, ndistinct=64, flagged=False, edge=True):
 def ntt_input(field, lg, seed):
     rng = np.random.default_rng(seed)
     n = 1 << lg
+    if field in ("bls12_381", "bn254"):                     # 256-bit scalar field: (n, 4) u64 limbs < r
+        r = O.FR_MODULUS[O.BLS12_381 if field == "bls12_381" else O.BN254]
+        vals = [int.from_bytes(rng.bytes(40), "little") % r for _ in range(n)]
+        return np.array([[(v >> (64 * k)) & 0xffffffffffffffff for k in range(4)] for v in vals], dtype=np.uint64)
     if field == "gl64":
         return (rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)) % np.uint64(O.GL64_P)
     return (rng.integers(0, 1 << 32, size=n, dtype=np.uint64) % O.BB31_P).astype(np.uint32)

@@ -27,12 +27,17 @@ def _emu(feature):
     return L
 
 
-@pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR")])
+@pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR"),
+                                           ("bls12_381", "BLS12_381"), ("bn254", "BN254")])
 def test_ntt_kernels_on_host(oracle, field, feature):
     O = oracle
     L = _emu(feature)
-    f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
-    for lg in list(range(1, 15)) + [16]:
+    if field in ("bls12_381", "bn254"):
+        curve = O.BLS12_381 if field == "bls12_381" else O.BN254
+        f = lambda x, order, direction, typ: O.ntt_fr(curve, x, order, direction, typ)
+    else:
+        f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+    for lg in (list(range(1, 15)) + [16]) if field in ("gl64", "bb31") else (list(range(1, 12)) + [13]):
         x = recipe.ntt_input(field, lg, 100 + lg)
         for order in range(4):
             for direction in range(2):

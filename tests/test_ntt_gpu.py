@@ -11,9 +11,13 @@ import recipe
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIELDS = ["gl64", "bb31"]
+WIDE = ["bls12_381", "bn254"]
 
 
 def _oracle_fn(O, field):
+    if field in WIDE:
+        curve = O.BLS12_381 if field == "bls12_381" else O.BN254
+        return lambda x, order, direction, typ: O.ntt_fr(curve, x, order, direction, typ)
     return O.ntt_gl64 if field == "gl64" else O.ntt_bb31
 
 
@@ -72,19 +76,19 @@ def test_ntt_golden_vectors(oracle, libs):
     """vectors from the independent big-int DFT in tests/golden/make_golden.py"""
     import sppark_amd
     for c in json.load(open(os.path.join(HERE, "golden", "ntt_golden.json"))):
-        dt = np.uint64 if c["field"] == "gl64" else np.uint32
+        dt = np.uint32 if c["field"] == "bb31" else np.uint64
         x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt).copy()
         e = np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)
         sppark_amd.compute_ntt(0, x, c["order"], c["direction"], c["type"], c["field"])
         assert (x == e).all(), c
 
 
-@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("field", FIELDS + WIDE)
 def test_ntt_vs_oracle_all_modes(oracle, libs, field):
     import sppark_amd
     O = oracle
     f = _oracle_fn(O, field)
-    for lg in list(range(1, 15)) + [16, 18, 20]:
+    for lg in (list(range(1, 15)) + [16, 18, 20]) if field in FIELDS else (list(range(1, 13)) + [14, 16]):
         x = recipe.ntt_input(field, lg, 7 + lg)
         for order in range(4):
             for direction in range(2):
@@ -96,14 +100,15 @@ def test_ntt_vs_oracle_all_modes(oracle, libs, field):
                     assert (y == f(x, order, direction, typ)).all(), (field, lg, order, direction, typ)
 
 
-@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("field", FIELDS + WIDE)
 def test_ntt_reference_test_shapes(oracle, libs, field):
-    """poc/ntt-cuda/tests/ntt.rs:9-78 and goldilocks_test.go:11-32:
-    NTT_NN == NTT_RR; iNTT(NTT(v)) == v in NN and RR; iNTT_RN(NTT_NR(v)) == v."""
+    """poc/ntt-cuda/tests/ntt.rs:9-152 and goldilocks_test.go:11-32:
+    NTT_NN == NTT_RR; iNTT(NTT(v)) == v in NN and RR; iNTT_RN(NTT_NR(v)) == v;
+    coset round trip (the 256-bit fields are additionally pinned against the
+    oracle, whose roots are the reference tables', in test_ntt_vs_oracle_all_modes)."""
     import sppark_amd
     from sppark_amd import NTTInputOutputOrder as Ord
-    top = 24 if field == "gl64" else 24
-    for lg in list(range(1, 21)) + [22, top]:
+    for lg in (list(range(1, 21)) + [22, 24]) if field in FIELDS else (list(range(1, 17)) + [18, 20]):
         v = recipe.ntt_input(field, lg, lg)
         nn = sppark_amd.NTT(0, v.copy(), Ord.NN, field)
         rr = sppark_amd.NTT(0, v.copy(), Ord.RR, field)

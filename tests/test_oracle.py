@@ -116,11 +116,31 @@ def test_msm_empty(oracle):
 def test_ntt_golden(oracle):
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "ntt_golden.json"))):
-        dt = np.uint64 if c["field"] == "gl64" else np.uint32
+        dt = np.uint32 if c["field"] == "bb31" else np.uint64
         x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt)
         e = np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)
-        f = O.ntt_gl64 if c["field"] == "gl64" else O.ntt_bb31
-        assert (f(x, c["order"], c["direction"], c["type"]) == e).all(), c
+        if c["field"] in ("bls12_381", "bn254"):
+            curve = O.BLS12_381 if c["field"] == "bls12_381" else O.BN254
+            got = O.ntt_fr(curve, x.reshape(-1, 4), c["order"], c["direction"], c["type"]).reshape(-1)
+        else:
+            got = (O.ntt_gl64 if c["field"] == "gl64" else O.ntt_bb31)(x, c["order"], c["direction"], c["type"])
+        assert (got == e).all(), c
+
+
+def test_wide_ntt_roots_match_reference_tables(oracle):
+    """forward_roots_of_unity[k] of ntt/parameters/{bls12_381,alt_bn128}.h, every k
+    (the tables are read here, in the build container, only; nothing is copied)."""
+    import re
+    O = oracle
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("no /root/reference here")
+    for curve, name, S in ((O.BLS12_381, "bls12_381", 32), (O.BN254, "alt_bn128", 28)):
+        txt = open("/root/reference/ntt/parameters/%s.h" % name).read()
+        m = re.search(r"forward_roots_of_unity\[S \+ 1\] = \{(.*?)\};", txt, re.S)
+        ents = re.findall(r"FR_T\(vec256, (0x[0-9a-f]+)u, (0x[0-9a-f]+)u, (0x[0-9a-f]+)u, (0x[0-9a-f]+)u", m.group(1))
+        assert len(ents) == S + 1
+        for k in range(S + 1):
+            assert [int(v, 16) for v in ents[k]] == [int(v) for v in O.fr_root(curve, k)], (name, k)
 
 
 def test_ntt_kat_survey_a3(oracle):

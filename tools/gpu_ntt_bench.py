@@ -6,10 +6,10 @@ import sppark_amd
 from sppark_amd import NTTInputOutputOrder as Ord
 
 stream = torch.cuda.current_stream().cuda_stream
-for field, dt, eb in (("gl64", torch.int64, 8), ("bb31", torch.int32, 4)):
-    for lg in (16, 20, 22, 24, 26):
+for field, dt, eb in (("gl64", torch.int64, 8), ("bb31", torch.int32, 4), ("bls12_381", torch.int64, 32), ("bn254", torch.int64, 32)):
+    for lg in (16, 20, 22, 24) + ((26,) if eb < 32 else ()):
         n = 1 << lg
-        x = torch.randint(0, 2**30, (n,), dtype=dt, device="cuda")
+        x = torch.randint(0, 2**30, (n * (eb // 8 if eb >= 8 else 1),), dtype=dt, device="cuda")
         res = []
         for name, fn, order in (("fwd NR", sppark_amd.NTT, Ord.NR), ("inv RN", sppark_amd.iNTT, Ord.RN),
                                 ("fwd NN", sppark_amd.NTT, Ord.NN), ("coset fwd NR", sppark_amd.coset_NTT, Ord.NR)):

@@ -62,7 +62,7 @@ SPPARK_FFI RustError sppark_ntt(size_t device_id, void* inout, uint32_t lg_domai
 {   return guarded([&] { ntt_any(device_id, inout, lg_domain_size, ntt_order, ntt_direction, ntt_type, (hipStream_t)stream); });   }
 
 // ---- device test hook: element-wise field ops (tests/test_ntt_gpu.py) -----------
-// op 0: a+b  1: a-b  2: a*b  3: a*2^k (gl64 only; k = b's low byte mod 192)
+// op 0: a+b  1: a-b  2: a*b  3: a*2^k (gl64 only; k = b's low byte mod 192)  7/8: fused butterfly sum/difference
 __global__ void k_small_field_op(fr_t* out, const fr_t* a, const fr_t* b, unsigned n, int op)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,7 +75,14 @@ __global__ void k_small_field_op(fr_t* out, const fr_t* a, const fr_t* b, unsign
     else if (op == 5) r = field_pow(x, (u64)(*reinterpret_cast<const u32*>(&y) & 0xffff));
     else if (op == 6) { r = x; if (i & 1) { for (unsigned k = 0; k < (i & 15); k++) r = r * r + y; } }
 #if defined(FEATURE_GOLDILOCKS)
-    else r = gl64_dev::mul_pow2(x, (unsigned)(y.v & 0xff) % 192);
+    else if (op == 7 || op == 8) { fr_t sm, df; gl64_dev::bfly(x, y, sm, df); r = op == 7 ? sm : df; }
+    else {
+        const unsigned e = (unsigned)(y.v & 0xff) % 192;
+        r = gl64_dev::mul_pow2(x, e % 96);
+        if (e >= 96) r = gl64_dev::from_raw(0) - r;
+    }
+#else
+    else if (op == 7 || op == 8) { fr_t sm, df; fr_t::bfly(x, y, sm, df); r = op == 7 ? sm : df; }
 #endif
     out[i] = r;
 }

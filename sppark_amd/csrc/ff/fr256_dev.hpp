@@ -26,6 +26,10 @@ template<class P> struct alignas(16) fr256_dev : mont_dev<P> {
     template<bool INV>
     SPPARK_DEVFN static fr256_dev mul_root(const fr256_dev& x, unsigned R, unsigned k, const fr256_dev* inner)
     {   return k ? x * inner[(1u << R) + k] : x;   }
+    template<bool INV>
+    SPPARK_DEVFN static constexpr bool root_neg(unsigned, unsigned) { return false; }
+    SPPARK_DEVFN static void bfly(const fr256_dev& a, const fr256_dev& b, fr256_dev& s, fr256_dev& d)
+    {   fr256_dev t = a - b; s = a + b; d = t;   }
 };
 
 } // namespace sppark_amd

@@ -105,10 +105,85 @@ struct gl64_dev {
         const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
         const u64 p10 = (u64)a1 * b0 + (u32)p01;
         const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-        const u32 w0 = (u32)p00, w1 = (u32)p10, w2 = (u32)p11, w3 = (u32)(p11 >> 32);
-        // x = w0 + w1*2^32 + w2*2^64 + w3*2^96 = (w1:w0) - w3 + w2*(2^32-1)   (mod p)
-        gl64_dev t = canon(((u64)w1 << 32) | w0) - from_raw(w3);
-        return t + from_raw(((u64)w2 << 32) - w2);
+        return reduce128((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+    }
+    // w0 + w1*2^32 + w2*2^64 + w3*2^96 (mod p), canonical.  2^64 = 2^32 - 1 =: E and
+    // 2^96 = -1, so the value is V = (w1:w0) + w2*E - w3.  One mad (carry c) and one
+    // 64-bit subtraction (borrow b) leave u = V - (c - b)*2^64, and (c - b)*2^64 =
+    // (c - b)*E is added back as ONE 64-bit constant D in {-E, 0, +E} (neither
+    // direction can wrap again: V < 2^65 - 2^33 and V > -2^32); then x >= p ? x - p.
+    // Seven carry-chain instructions instead of the twelve of canon + sub + add.
+    SPPARK_DEVFN static gl64_dev reduce128(u32 w0, u32 w1, u32 w2, u32 w3)
+    {
+#if defined(SPPARK_GL64_ASM)
+        u64 t, c, c2;
+        const u64 lo64 = ((u64)w1 << 32) | w0;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=&s"(c) : "v"(w2), "v"(lo64));
+        const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
+        u32 u0, u1, x0, x1, k, kb, nk, r0, r1;
+        asm("v_sub_co_u32 %[u0], vcc, %[t0], %[w3]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[k], 0, -1, %[c]\n\t"
+            "v_subbrev_co_u32 %[u1], vcc, 0, %[t1], vcc\n\t"
+            "v_not_b32 %[nk], %[k]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[kb], 0, -1, vcc\n\t"
+            "v_sub_u32 %[k], %[k], %[kb]\n\t"             // D.lo = k - kb
+            "v_and_b32 %[nk], %[nk], %[kb]\n\t"           // D.hi = ~k & kb
+            "v_add_co_u32 %[u0], vcc, %[u0], %[k]\n\t"
+            "v_add_co_u32 %[x0], %[c2], -1, %[u0]\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %[u1], vcc, %[u1], %[nk], vcc\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %[x1], %[c2], 0, %[u1], %[c2]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %[r0], %[u0], %[x0], %[c2]\n\t"
+            "v_cndmask_b32 %[r1], %[u1], %[x1], %[c2]"
+            : [u0]"=&v"(u0), [u1]"=&v"(u1), [x0]"=&v"(x0), [x1]"=&v"(x1), [k]"=&v"(k), [kb]"=&v"(kb),
+              [nk]"=&v"(nk), [r0]"=&v"(r0), [r1]"=&v"(r1), [c2]"=&s"(c2)
+            : [t0]"v"(t0), [t1]"v"(t1), [w3]"v"(w3), [c]"s"(c) : "vcc");
+        return from_raw(((u64)r1 << 32) | r0);
+#else
+        const u64 lo64 = ((u64)w1 << 32) | w0, E = 0xffffffffULL;
+        u64 t = lo64 + (u64)w2 * E;
+        const u64 c = t < lo64;
+        const u64 b = t < w3;
+        u64 u = t - w3;
+        if (c && !b) u += E; else if (b && !c) u -= E;
+        return from_raw(u >= MOD ? u - MOD : u);
+#endif
+    }
+    // (a + b, a - b) in one interleaved sequence: the add chain (SGPR-pair carries)
+    // and the sub chain (VCC) fill each other's mandatory wait states.
+    SPPARK_DEVFN static void bfly(gl64_dev a, gl64_dev b, gl64_dev& s, gl64_dev& d)
+    {
+#if defined(SPPARK_GL64_ASM)
+        u32 a0 = (u32)a.v, a1 = (u32)(a.v >> 32), b0 = (u32)b.v, b1 = (u32)(b.v >> 32);
+        u32 lo, hi, ulo, uhi, dlo, dhi, t;
+        u64 c1, c2;
+        asm("v_add_co_u32 %[lo], %[c1], %[a0], %[b0]\n\t"
+            "v_sub_co_u32 %[dlo], vcc, %[a0], %[b0]\n\t"
+            "v_add_co_u32 %[ulo], %[c2], -1, %[lo]\n\t"
+            "v_addc_co_u32 %[hi], %[c1], %[a1], %[b1], %[c1]\n\t"
+            "v_subb_co_u32 %[dhi], vcc, %[a1], %[b1], vcc\n\t"
+            "v_addc_co_u32 %[uhi], %[c2], 0, %[hi], %[c2]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[t], 0, -1, vcc\n\t"
+            "s_nop 0\n\t"
+            "s_or_b64 %[c1], %[c1], %[c2]\n\t"
+            "v_sub_co_u32 %[dlo], vcc, %[dlo], %[t]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[lo], %[lo], %[ulo], %[c1]\n\t"
+            "v_cndmask_b32 %[hi], %[hi], %[uhi], %[c1]\n\t"
+            "v_subbrev_co_u32 %[dhi], vcc, 0, %[dhi], vcc"
+            : [lo]"=&v"(lo), [hi]"=&v"(hi), [ulo]"=&v"(ulo), [uhi]"=&v"(uhi), [dlo]"=&v"(dlo), [dhi]"=&v"(dhi),
+              [t]"=&v"(t), [c1]"=&s"(c1), [c2]"=&s"(c2)
+            : [a0]"v"(a0), [a1]"v"(a1), [b0]"v"(b0), [b1]"v"(b1) : "vcc", "scc");
+        s = from_raw(((u64)hi << 32) | lo);
+        d = from_raw(((u64)dhi << 32) | dlo);
+#else
+        s = a + b; d = a - b;
+#endif
     }
     // x >= p ? x - p : x      (x - p = x + 2^32 - 1 mod 2^64, and x >= p iff that addition carries)
     SPPARK_DEVFN static gl64_dev canon(u64 x)
@@ -136,28 +211,35 @@ struct gl64_dev {
     // reference's table (ntt/parameters/goldilocks.h:86-93: 0x8000000000 = 2^39).
     // With e known at compile time (unrolled butterflies) this is a handful of
     // shifts/adds instead of a 64x64 product.
-    SPPARK_DEVFN static gl64_dev mul_pow2(gl64_dev x, unsigned e)
+    SPPARK_DEVFN static gl64_dev mul_pow2(gl64_dev x, unsigned e)     // e in [0, 96)
     {
-        const bool neg = e >= 96;
-        if (neg) e -= 96;
         const unsigned q = e >> 5, sh = e & 31;
         const u32 x0 = (u32)x.v, x1 = (u32)(x.v >> 32);
         const u32 y0 = x0 << sh;
         const u32 y1 = sh ? (x1 << sh) | (x0 >> (32 - sh)) : x1;
         const u32 y2 = sh ? x1 >> (32 - sh) : 0;
-        gl64_dev r;
-        if (q == 0)      r = reduce_u96(((u64)y1 << 32) | y0, y2);
-        else if (q == 1) r = reduce_u96((u64)y0 << 32, y1) - from_raw(y2);
-        else             r = reduce_u96(0, y0) - from_raw(y1) - from_raw((u64)y2 << 32);
-        return neg ? from_raw(0) - r : r;
+        if (q == 0) return reduce128(y0, y1, y2, 0);
+        if (q == 1) return reduce128(0, y0, y1, y2);
+        // y0*2^64 + y1*2^96 + y2*2^128, and 2^128 = -2^32
+        return reduce128(0, 0, y0, y1) - from_raw((u64)y2 << 32);
     }
-    // x * w_{2^R}^k with the reference's root convention; INV selects w^-1
+    // w_{2^R}^k (w^-1 for INV) = +-2^e with the reference's root convention:
+    // root_neg() says whether the sign is minus, mul_root() multiplies by 2^e only.
+    // The butterflies absorb the sign by swapping their operands / outputs.
+    template<bool INV>
+    SPPARK_DEVFN static constexpr unsigned root_exp(unsigned R, unsigned k)
+    {
+        constexpr unsigned ER[7] = {0, 96, 48, 120, 156, 78, 39};   // w_{2^R} = 2^ER[R]
+        unsigned e = (ER[R] * k) % 192;
+        if (INV) e = (192 - e) % 192;
+        return e;
+    }
+    template<bool INV>
+    SPPARK_DEVFN static constexpr bool root_neg(unsigned R, unsigned k) { return root_exp<INV>(R, k) >= 96; }
     template<bool INV>
     SPPARK_DEVFN static gl64_dev mul_root(gl64_dev x, unsigned R, unsigned k, const gl64_dev*)
     {
-        const unsigned ER[7] = {0, 96, 48, 120, 156, 78, 39};       // w_{2^R} = 2^ER[R]
-        unsigned e = (ER[R] * k) % 192;
-        if (INV) e = (192 - e) % 192;
+        const unsigned e = root_exp<INV>(R, k) % 96;
         return e ? mul_pow2(x, e) : x;
     }
     static constexpr bool SHIFT_ROOTS = true;
@@ -191,6 +273,9 @@ struct bb31_dev {
     template<bool INV>
     SPPARK_DEVFN static bb31_dev mul_root(bb31_dev x, unsigned R, unsigned k, const bb31_dev* inner)
     {   return k ? x * inner[(1u << R) + k] : x;   }
+    template<bool INV>
+    SPPARK_DEVFN static constexpr bool root_neg(unsigned, unsigned) { return false; }
+    SPPARK_DEVFN static void bfly(bb31_dev a, bb31_dev b, bb31_dev& s, bb31_dev& d) { s = a + b; d = a - b; }
     static constexpr bool SHIFT_ROOTS = false;
 };
 

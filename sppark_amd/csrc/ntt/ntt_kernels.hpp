@@ -74,9 +74,12 @@ SPPARK_DEVFN void radix_dif(F* x, const F* inner)              // natural in -> 
         #pragma unroll
         for (unsigned j = 0; j < ((1u << R) >> 1); j++) {
             const unsigned off = j & (half - 1), m0 = ((j >> lgh) << (lgh + 1)) + off, m1 = m0 + half;
-            F a = x[m0], b = x[m1];
-            x[m0] = a + b;
-            x[m1] = F::template mul_root<INV>(a - b, R, off << t, inner);
+            // (a - b) * w with w = +-(root): a minus sign turns a - b into b - a
+            F sum, dif;
+            if (F::template root_neg<INV>(R, off << t)) F::bfly(x[m1], x[m0], sum, dif);
+            else                                        F::bfly(x[m0], x[m1], sum, dif);
+            x[m0] = sum;
+            x[m1] = F::template mul_root<INV>(dif, R, off << t, inner);
         }
     }
 }
@@ -90,9 +93,12 @@ SPPARK_DEVFN void radix_dit(F* x, const F* inner)              // bit-reversed i
         #pragma unroll
         for (unsigned j = 0; j < ((1u << R) >> 1); j++) {
             const unsigned off = j & (half - 1), m0 = ((j >> lgh) << (lgh + 1)) + off, m1 = m0 + half;
-            F a = x[m0], b = F::template mul_root<INV>(x[m1], R, off << (R - 1 - t), inner);
-            x[m0] = a + b;
-            x[m1] = a - b;
+            // a +- b*w with w = +-(root): a minus sign swaps the two outputs
+            F bw = F::template mul_root<INV>(x[m1], R, off << (R - 1 - t), inner), sum, dif;
+            F::bfly(x[m0], bw, sum, dif);
+            const bool neg = F::template root_neg<INV>(R, off << (R - 1 - t));
+            x[m0] = neg ? dif : sum;
+            x[m1] = neg ? sum : dif;
         }
     }
 }

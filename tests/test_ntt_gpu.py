@@ -45,7 +45,7 @@ def test_device_small_field_ops(libs):
             return random.getrandbits(64) % P
         n = 1 << 13
         a = np.array([rnd() for _ in range(n)], dtype=dt); b = np.array([rnd() for _ in range(n)], dtype=dt)
-        for op in (0, 1, 2, 3, 4, 5, 6):
+        for op in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             if field == "bb31" and op == 3:
                 continue
             out = np.zeros(n, dtype=dt)
@@ -53,8 +53,8 @@ def test_device_small_field_ops(libs):
             for i in range(n):
                 x, y = int(a[i]), int(b[i])
                 mul = lambda u, v: u * v * R % P
-                if op == 0: e = (x + y) % P
-                elif op == 1: e = (x - y) % P
+                if op in (0, 7): e = (x + y) % P
+                elif op in (1, 8): e = (x - y) % P
                 elif op == 2: e = mul(x, y)
                 elif op == 3: e = x * pow(2, (y & 0xff) % 192, P) % P
                 elif op == 4:

@@ -131,7 +131,11 @@ public:
 
         unsigned smax = S_MAX;
         if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) smax = v; }   // tuning knob
-        ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, smax);
+        unsigned lgc = LG_LINE, lgt = LG_TILE;
+        if (const char* e = getenv("SPPARK_NTT_LGC")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) lgc = v; }
+        if (const char* e = getenv("SPPARK_NTT_LGTILE")) { unsigned v = (unsigned)atoi(e); if (v >= 8 && v <= 14) lgt = v; }
+        if (lgt < smax + 1) lgt = smax + 1;
+        ntt_plan pl = make_ntt_plan(lg, lgc, lgt, smax);
         for (unsigned i = 0; i < pl.npass; i++) {
             ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
             P.apply_scale = inverse && i == pl.npass - 1;
@@ -140,6 +144,11 @@ public:
             size_t lds = ntt_lds_elems(P) * sizeof(F);
 #define SPPARK_NTT_LAUNCH(R1, R2)                                                                              \
             do {                                                                                               \
+                if (lds > 65536) {                                                                             \
+                    const void* fn = gs ? (inverse ? (const void*)k_ntt_pass<F, true, true, R1, R2> : (const void*)k_ntt_pass<F, true, false, R1, R2>)   \
+                                        : (inverse ? (const void*)k_ntt_pass<F, false, true, R1, R2> : (const void*)k_ntt_pass<F, false, false, R1, R2>); \
+                    HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+                }                                                                                              \
                 if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, true, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);   \
                           else         hipLaunchKernelGGL((k_ntt_pass<F, true, false, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P); } \
                 else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, false, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);  \

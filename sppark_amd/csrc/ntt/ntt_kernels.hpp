@@ -63,6 +63,30 @@ SPPARK_DEVFN unsigned bit_rev32(unsigned x, unsigned bits)
 template<class F> SPPARK_DEVFN F ntt_twiddle(const ntt_tables<F>& T, size_t e)
 {   return T.lo[e & (((size_t)1 << T.h) - 1)] * T.hi[e >> T.h];   }
 
+
+// Inter-pass twiddles of one work item.  Its 2^R elements need w^(col * rev_S(mid))
+// where rev_S(mid) = rev_R(j) * 2^lo_bits + fixed, j = the item's own index: that is
+// t0 * step^(rev_R(j)) with t0 = w^(col*fixed), step = w^(col << lo_bits).  Two table
+// look-ups (each a 64-lane gather of lo[] and hi[]) and 2^R + R - 2 products
+// generate all of them, instead of 2^R look-ups + 2^R products: the gathers, not
+// the arithmetic, were what bounded the passes.  pw[k] = t0 * step^k, natural k.
+template<class F, unsigned R, bool HAS_T0>
+SPPARK_DEVFN void ntt_twiddle_powers(F* pw, const ntt_tables<F>& T, size_t e_t0, size_t e_step)
+{
+    pw[0] = HAS_T0 ? ntt_twiddle(T, e_t0) : F::one();
+    if (R == 0) return;
+    F sj = ntt_twiddle(T, e_step);
+    #pragma unroll
+    for (unsigned j = 0; j < R; j++) {
+        #pragma unroll
+        for (unsigned k = 1u << j; k < (2u << j); k++)
+            pw[k] = (!HAS_T0 && k == (1u << j)) ? sj : pw[k - (1u << j)] * sj;
+        if (j + 1 < R) sj = sj * sj;
+    }
+}
+// wide elements keep the per-element look-up: 2^R extra 256-bit values do not fit the registers
+template<class F> struct ntt_gen_twiddles { static constexpr bool value = sizeof(F) <= 8; };
+
 // in-register 2^R-point transforms on x[0 .. 2^R)
 template<class F, bool INV, unsigned R>
 SPPARK_DEVFN void radix_dif(F* x, const F* inner)              // natural in -> bit-reversed out
@@ -146,13 +170,19 @@ SPPARK_DEVFN void ntt_round_high(F* data, F* tile, const ntt_tables<F>& T, const
             if (DIF || R2 == 0) x[a] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
             else                x[a] = tile[ntt_lds_index<R2>(gm, c, P.lgC)];
         }
+        // single-round pass (R2 == 0): the inter-pass twiddles w^(col * rev(a)) are applied here
+        constexpr bool GEN = ntt_gen_twiddles<F>::value && R2 == 0;
+        F pw[GEN ? (1u << R1) : 1];
+        if (GEN && geo.lgQ)
+            ntt_twiddle_powers<F, R1, false>(pw, T, 0, (size_t)(geo.c0 + c) << (T.lg_n - P.lg_cur));
         if (DIF) {
             radix_dif<F, INV, R1>(x, T.inner);
             #pragma unroll
             for (unsigned a = 0; a < (1u << R1); a++) {
                 if (R2) { unsigned e = b * bit_rev32(a, R1); if (e) x[a] = x[a] * T.inner[(1u << S) + e]; }
                 if (R2 == 0) {                          // single-round pass: finish here
-                    if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                    if (GEN) { if (geo.lgQ && a) x[a] = x[a] * pw[GEN ? bit_rev32(a, R1) : 0]; }
+                    else if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                     if (P.apply_scale) x[a] = x[a] * T.scale;
                     data[((geo.row0 + (g << S) + a) << geo.lgQ) + geo.c0 + c] = x[a];
                 } else {
@@ -163,7 +193,10 @@ SPPARK_DEVFN void ntt_round_high(F* data, F* tile, const ntt_tables<F>& T, const
             #pragma unroll
             for (unsigned a = 0; a < (1u << R1); a++) {
                 if (R2) { unsigned e = b * bit_rev32(a, R1); if (e) x[a] = x[a] * T.inner[(1u << S) + e]; }
-                if (R2 == 0 && geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                if (R2 == 0 && geo.lgQ) {
+                    if (GEN) { if (a) x[a] = x[a] * pw[GEN ? bit_rev32(a, R1) : 0]; }
+                    else { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                }
             }
             radix_dit<F, INV, R1>(x, T.inner);
             #pragma unroll
@@ -188,20 +221,34 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
         const unsigned c = gi & (C - 1), rest = gi >> P.lgC;
         const unsigned a = rest & ((1u << R1) - 1), g = rest >> R1;
         F x[1u << R2];
+        // w^(col * rev_S(a*2^R2 + b)) = w^(col*rev(a)) * (w^(col << R1))^rev(b)
+        constexpr bool GEN = ntt_gen_twiddles<F>::value;
+        F pw[GEN ? (1u << R2) : 1];
+        if (GEN && geo.lgQ) {
+            const unsigned sh = T.lg_n - P.lg_cur;
+            const size_t col = geo.c0 + c;
+            ntt_twiddle_powers<F, R2, true>(pw, T, (col * bit_rev32(a, R1)) << sh, (col << R1) << sh);
+        }
         #pragma unroll
         for (unsigned b = 0; b < (1u << R2); b++) {
             const unsigned gm = (g << S) + (a << R2) + b;
             if (DIF) x[b] = tile[ntt_lds_index<R2>(gm, c, P.lgC)];
             else {
                 x[b] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
-                if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                if (geo.lgQ) {
+                    if (GEN) x[b] = x[b] * pw[GEN ? bit_rev32(b, R2) : 0];
+                    else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                }
             }
         }
         if (DIF) {
             radix_dif<F, INV, R2>(x, T.inner);
             #pragma unroll
             for (unsigned b = 0; b < (1u << R2); b++) {
-                if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                if (geo.lgQ) {
+                    if (GEN) x[b] = x[b] * pw[GEN ? bit_rev32(b, R2) : 0];
+                    else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                }
                 if (P.apply_scale) x[b] = x[b] * T.scale;
                 data[((geo.row0 + (g << S) + (a << R2) + b) << geo.lgQ) + geo.c0 + c] = x[b];
             }
@@ -316,7 +363,7 @@ static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg
         if (lgQ >= lgCmax) { p.lgC = lgCmax; p.lgG = 0; }
         else {
             p.lgC = lgQ;
-            unsigned room = lg_tile - S - lgQ, nsub = lg_n - rem;  // log2 sub-problems available
+            unsigned room = lg_tile > S + lgQ ? lg_tile - S - lgQ : 0, nsub = lg_n - rem;  // log2 sub-problems available
             p.lgG = room < nsub ? room : nsub;
         }
         pl.pass[pl.npass++] = p;

@@ -194,6 +194,20 @@ def main():
         achieved = MSM_BYTES_PER_POINT * n / (a_ms * 1e-3) / 1e9
         plan = ctx.plan(n)
         nwins = plan["windows"]
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the
+        # timed run, so the value comes from the committed rocprofv3 --pmc passes of this
+        # same workload (profiles/r01_pmc_traffic.json); null for any other workload.
+        traffic, traffic_note = None, ""
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("lg") == args.lg and pmc.get("curve") == "bls12_381":
+                traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) / 1e9
+                traffic_note = ("; traffic = GB per launch from rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, "
+                                "profiles/r01_pmc_traffic.json): the 96-byte point gathers pull whole 128-byte lines, "
+                                "hidden behind the multiplier-bound arithmetic")
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "MSM points/sec (BLS12-381 G1, 2^%d points per GPU)" % args.lg,
             "value": world * n * args.steps / elapsed, "unit": "points/s",
@@ -205,11 +219,12 @@ def main():
                        "curve": "bls12_381", "points_per_gpu": n, "window_bits": plan["window_bits"], "windows": nwins,
                        "distinct_points": 2048, "scalars": "uniform 254-bit"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_accumulate",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
+                         "algorithmic_gb_per_launch": achieved * a_ms * 1e-3, "kernel": "k_accumulate",
                          "kernel_ms": a_ms,
                          "note": "MSM is integer-multiplier bound, not HBM bound (SURVEY F11): the kernel does "
                                  "%d mixed additions per launch = %.3e additions/s against a measured "
-                                 "5.14e9/s mixed-addition micro-benchmark" % (nwins * n, nwins * n / (a_ms * 1e-3))},
+                                 "5.14e9/s mixed-addition micro-benchmark" % (nwins * n, nwins * n / (a_ms * 1e-3)) + traffic_note},
             "phases_ms": {"digits_sort": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
             "cpu_baseline": cpu, "ntt": ntt, "extras": extras,
         }

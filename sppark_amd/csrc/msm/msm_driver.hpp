@@ -46,7 +46,12 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     unsigned lg = lg2_floor(npoints ? npoints : 1);
     // window: ~2^6 entries per bucket on average; both halves of the bucket index
     // must fit LDS counters (2^15 u32 = 128 KB of the 160 KB) => wbits - 1 <= 30, capped at 24
-    p.wbits = t.wbits ? t.wbits : std::min(22u, std::max(6u, lg > 4 ? lg - 4 : 0u));      // measured optimum at 2^20..2^26
+    // measured optima (profiles/r01_msm_small_sweep.log): ~2^4 entries per bucket at
+    // 2^20..2^26; below that the serial depth of the reduction levels dominates and
+    // much smaller windows (more, shorter windows in parallel) win
+    unsigned autow = lg >= 22 ? std::min(22u, lg - 4) : lg >= 20 ? 16u : lg == 19 ? 11u
+                   : lg >= 16 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
+    p.wbits = t.wbits ? t.wbits : autow;
     p.wbits = std::min(24u, std::max(2u, p.wbits));
     p.nwins = (scalar_bits - 1) / p.wbits + 1;      // as pippenger.cuh:365
     p.nbits = scalar_bits;
@@ -65,8 +70,8 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.chunks_per_win = (p.n + L - 1) / L;
     p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
-    p.F = std::max(4u, t.F ? t.F : 32u);       // fan-in < 3 would never shrink the record list
-    p.K = t.K ? t.K : 8;
+    p.F = std::max(4u, t.F ? t.F : 8u);        // fan-in < 3 would never shrink the record list
+    p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
     return p;
 }

@@ -5,7 +5,9 @@
  * -DFEATURE_* (rust/src/build.rs ccmd(), poc/{msm,ntt}-cuda/build.rs):
  *
  *   libsppark_bls12_381.so  mult_pippenger_inf, mult_pippenger          (BLS12-381 G1)
+ *                           compute_ntt                                 (BLS12-381 Fr, 2-adicity 32)
  *   libsppark_bn254.so      mult_pippenger_inf, mult_pippenger          (alt_bn128 G1)
+ *                           compute_ntt                                 (alt_bn128 Fr, 2-adicity 28)
  *   libsppark_gl64.so       compute_ntt                                 (Goldilocks)
  *   libsppark_bb31.so       compute_ntt                                 (BabyBear)
  *

@@ -90,7 +90,15 @@ SppError sppark_msm_tune(sppark_msm_ctx *ctx, unsigned wbits, unsigned L, unsign
 SppError sppark_msm_tune_sort(sppark_msm_ctx *ctx, unsigned low_bits);
 SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affine_sz,
                             int host_points, int host_scalars);
-/* mont != 0: scalars are in Montgomery form (msm_t::invoke's `mont`). */
+/* Preloaded bases (msm_t(points, np, ffi_affine_sz), msm/pippenger.cuh:351-385): copy npoints
+ * points (host or device pointer) into HBM owned by the context; afterwards
+ * sppark_msm_invoke(ctx, out, NULL, n <= npoints, scalars, ...) is the reference's
+ * invoke(out, scalars) (pippenger.cuh:604-605) on the first n of them.  npoints == 0 drops them. */
+SppError sppark_msm_set_points(sppark_msm_ctx *ctx, const void *points, size_t npoints,
+                               size_t ffi_affine_sz);
+size_t   sppark_msm_preloaded(const sppark_msm_ctx *ctx);
+/* mont != 0: scalars are in Montgomery form (msm_t::invoke's `mont`).
+ * points == NULL: use the preloaded points (ffi_affine_sz is then ignored). */
 SppError sppark_msm_invoke(sppark_msm_ctx *ctx, void *out, const void *points, size_t npoints,
                            const void *scalars, int mont, size_t ffi_affine_sz);
 SppError sppark_msm_enable_timing(sppark_msm_ctx *ctx, int on);
@@ -119,6 +127,22 @@ void *sppark_gpu_ptr_get(void *const *ref);
 /* NTT on a device- or host-resident buffer with an explicit stream. */
 SppError sppark_ntt(size_t device_id, void *inout, uint32_t lg_domain_size,
                     int ntt_order, int ntt_direction, int ntt_type, void *stream);
+
+/* Low-degree extension -- C++-only in the reference (class NTT, ntt/ntt.cuh).
+ * sppark_lde = NTT::LDE_aux (ntt.cuh:283-336) / NTT::LDE (:338-340): inout (host or device)
+ * holds 2^lg_domain_size evaluations in natural order in its first elements and has room for
+ * 2^(lg_domain_size+lg_blowup); on return it holds the evaluations of the same polynomial on
+ * the coset g*<w_ext> in natural order.  aux_out (NULL or 2^lg_domain_size elements, host or
+ * device) receives the polynomial's coefficients in natural order. */
+SppError sppark_lde(size_t device_id, void *inout, uint32_t lg_domain_size, uint32_t lg_blowup,
+                    void *aux_out, void *stream);
+/* NTT::LDE_powers(stream, d_inout, lg) (ntt.cuh:352-356): d_inout[i] *= g^bitrev(i), device buffer */
+SppError sppark_lde_powers(size_t device_id, void *d_inout, uint32_t lg_domain_size, void *stream);
+/* NTT::LDE_expand (ntt.cuh:358-365): d_out[i << lg_blowup] = d_in[i], zeros elsewhere; device
+ * buffers.  Unlike the reference (which accepts d_in aligned to the end of d_out and pays a
+ * grid-wide sync for it) the two buffers must not overlap: invalid-value error otherwise. */
+SppError sppark_lde_expand(size_t device_id, void *d_out, const void *d_in, uint32_t lg_domain_size,
+                           uint32_t lg_blowup, void *stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,9 @@ def lib():
         L.oracle_ntt_naive_bb31.argtypes = [vp, vp, ctypes.c_uint, ci]
         L.oracle_ntt_fr.argtypes = [ci, vp, ctypes.c_uint, ci, ci, ci]
         L.oracle_ntt_naive_fr.argtypes = [ci, vp, vp, ctypes.c_uint, ci]
+        L.oracle_lde.argtypes = [ci, vp, ctypes.c_uint, ctypes.c_uint, vp]
+        L.oracle_lde_powers.argtypes = [ci, vp, ctypes.c_uint]
+        L.oracle_lde_expand.argtypes = [ci, vp, vp, ctypes.c_uint, ctypes.c_uint]
         L.oracle_fr_root.argtypes = [ci, vp, ctypes.c_uint]
         L.oracle_gl64_root.argtypes = [ctypes.c_uint]; L.oracle_gl64_root.restype = u64
         L.oracle_bb31_root.argtypes = [ctypes.c_uint]; L.oracle_bb31_root.restype = ctypes.c_uint32
@@ -211,6 +214,42 @@ def ntt_fr(curve, a, order=NN, direction=FORWARD, type=STANDARD):
     assert a.shape[0] == 1 << lg
     lib().oracle_ntt_fr(curve, _ptr(a), lg, order, direction, type)
     return a
+
+
+_LDE_FIELDS = {"gl64": (0, np.uint64, 1), "bb31": (1, np.uint32, 1), "bls12_381": (2, np.uint64, 4), "bn254": (3, np.uint64, 4)}
+
+
+def lde(field, x, lg_blowup, want_aux=False):
+    """NTT::LDE_aux (ntt/ntt.cuh:283-336) on 2^lg_domain evaluations x; returns the
+    2^(lg_domain+lg_blowup) coset evaluations (and the coefficients when want_aux)."""
+    fid, dt, w = _LDE_FIELDS[field]
+    x = np.ascontiguousarray(x, dtype=dt).reshape(-1, w)
+    dom = x.shape[0]
+    lg = dom.bit_length() - 1
+    assert dom == 1 << lg
+    ext = np.zeros((dom << lg_blowup, w), dtype=dt)
+    ext[:dom] = x
+    aux = np.zeros((dom, w), dtype=dt) if want_aux else None
+    lib().oracle_lde(fid, _ptr(ext), lg, lg_blowup, _ptr(aux) if want_aux else None)
+    ext = ext.reshape(-1) if w == 1 else ext
+    if want_aux:
+        return ext, (aux.reshape(-1) if w == 1 else aux)
+    return ext
+
+
+def lde_powers(field, x):
+    fid, dt, w = _LDE_FIELDS[field]
+    x = np.array(x, dtype=dt).reshape(-1, w)
+    lib().oracle_lde_powers(fid, _ptr(x), x.shape[0].bit_length() - 1)
+    return x.reshape(-1) if w == 1 else x
+
+
+def lde_expand(field, x, lg_blowup):
+    fid, dt, w = _LDE_FIELDS[field]
+    x = np.ascontiguousarray(x, dtype=dt).reshape(-1, w)
+    out = np.zeros((x.shape[0] << lg_blowup, w), dtype=dt)
+    lib().oracle_lde_expand(fid, _ptr(out), _ptr(x), x.shape[0].bit_length() - 1, lg_blowup)
+    return out.reshape(-1) if w == 1 else out
 
 
 def ntt_naive_fr(curve, a, inverse=False):

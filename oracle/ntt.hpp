@@ -139,6 +139,44 @@ static void ntt(F* a, unsigned lg, int order, int direction, int type)
     if (order == RR) bit_rev_permute(a, lg);
 }
 
+// NTT::LDE_aux (ntt/ntt.cuh:283-336).  inout: 2^(lg_domain+lg_blowup) elements, the first
+// 2^lg_domain hold the input; aux (nullable): 2^lg_domain elements.
+template<class F>
+static void lde(F* inout, unsigned lg_domain, unsigned lg_blowup, F* aux)
+{
+    const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
+    std::vector<F> d(inout, inout + dom);
+    ntt(d.data(), lg_domain, NR, inverse, standard);                   // :301-303
+    if (aux) {                                                         // :312-315 bit_rev(aux, domain)
+        for (size_t i = 0; i < dom; i++) aux[bit_rev(i, lg_domain)] = d[i];
+    }
+    // LDE_spread_distribute_powers, perform_shift = true, ext_pow = false
+    // (ntt/kernels.cu:155-237): r = in[idx] * g^bit_rev(idx, lg_domain) lands at
+    // out[idx << lg_blowup], the other 2^lg_blowup - 1 slots are zero
+    std::vector<F> pw(dom);
+    F x = F::one(), g = F::group_gen();
+    for (size_t i = 0; i < dom; i++) { pw[i] = x; x *= g; }
+    const F zero = F::one() - F::one();
+    for (size_t o = 0; o < ext; o++) inout[o] = zero;
+    for (size_t idx = 0; idx < dom; idx++) inout[idx << lg_blowup] = d[idx] * pw[bit_rev(idx, lg_domain)];
+    ntt(inout, lg_domain + lg_blowup, RN, forward, standard);          // :321-323
+}
+
+// NTT::LDE_powers(stream, d_inout, lg) (ntt/ntt.cuh:352-356) = LDE_distribute_powers with
+// bitrev = true, lg_blowup = 0, forward generator (ntt/kernels.cu:131-153)
+template<class F>
+static void lde_powers_bitrev(F* inout, unsigned lg) { lde_powers(inout, lg, true, F::group_gen()); }
+
+// NTT::LDE_expand (ntt/ntt.cuh:358-365): spread without the shift
+template<class F>
+static void lde_expand(F* out, const F* in, unsigned lg_domain, unsigned lg_blowup)
+{
+    const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
+    const F zero = F::one() - F::one();
+    for (size_t o = 0; o < ext; o++) out[o] = zero;
+    for (size_t idx = 0; idx < dom; idx++) out[idx << lg_blowup] = in[idx];
+}
+
 // textbook DFT, natural in / natural out: X[k] = sum_j x[j] w^(jk)
 template<class F>
 static void ntt_naive(F* out, const F* in, unsigned lg, bool inv)

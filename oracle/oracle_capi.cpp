@@ -310,7 +310,36 @@ void oracle_ntt_naive_fr(int field, uint64_t* out, const uint64_t* in, unsigned 
 void oracle_fr_root(int field, uint64_t* out, unsigned lg)
 {
     if (field == 0) { auto w = root_of_unity<bls12_381_fr>(lg); memcpy(out, w.v, 32); }
+
     else            { auto w = root_of_unity<alt_bn128_fr>(lg); memcpy(out, w.v, 32); }
+}
+// LDE family; field: 0 gl64, 1 bb31, 2 bls12_381 fr, 3 alt_bn128 fr
+void oracle_lde(int field, void* inout, unsigned lg_domain, unsigned lg_blowup, void* aux)
+{
+    switch (field) {
+        case 0: lde(reinterpret_cast<gl64*>(inout), lg_domain, lg_blowup, reinterpret_cast<gl64*>(aux)); break;
+        case 1: lde(reinterpret_cast<bb31*>(inout), lg_domain, lg_blowup, reinterpret_cast<bb31*>(aux)); break;
+        case 2: lde(reinterpret_cast<bls12_381_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<bls12_381_fr*>(aux)); break;
+        default: lde(reinterpret_cast<alt_bn128_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<alt_bn128_fr*>(aux)); break;
+    }
+}
+void oracle_lde_powers(int field, void* inout, unsigned lg)
+{
+    switch (field) {
+        case 0: lde_powers_bitrev(reinterpret_cast<gl64*>(inout), lg); break;
+        case 1: lde_powers_bitrev(reinterpret_cast<bb31*>(inout), lg); break;
+        case 2: lde_powers_bitrev(reinterpret_cast<bls12_381_fr*>(inout), lg); break;
+        default: lde_powers_bitrev(reinterpret_cast<alt_bn128_fr*>(inout), lg); break;
+    }
+}
+void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain, unsigned lg_blowup)
+{
+    switch (field) {
+        case 0: lde_expand(reinterpret_cast<gl64*>(out), reinterpret_cast<const gl64*>(in), lg_domain, lg_blowup); break;
+        case 1: lde_expand(reinterpret_cast<bb31*>(out), reinterpret_cast<const bb31*>(in), lg_domain, lg_blowup); break;
+        case 2: lde_expand(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg_domain, lg_blowup); break;
+        default: lde_expand(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg_domain, lg_blowup); break;
+    }
 }
 
 uint64_t oracle_gl64_root(unsigned lg) { return root_of_unity<gl64>(lg).raw(); }

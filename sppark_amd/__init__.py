@@ -8,5 +8,5 @@ HIP libraries; importing this package without them built raises at first use.
 from .ffi import SpparkError, load, lib_path, cuda_available                      # noqa: F401
 from .msm import (multi_scalar_mult, multi_scalar_mult_arkworks, MsmContext,      # noqa: F401
                   jacobian_sum, to_affine, generate_points)
-from .ntt import (NTT, iNTT, coset_NTT, coset_iNTT, compute_ntt,                  # noqa: F401
+from .ntt import (NTT, iNTT, coset_NTT, coset_iNTT, compute_ntt, LDE, LDE_powers, LDE_expand,                  # noqa: F401
                   NTTInputOutputOrder, NTTDirection, NTTType)

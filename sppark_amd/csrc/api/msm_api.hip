@@ -96,6 +96,9 @@ SPPARK_FFI RustError sppark_msm_invoke(sppark_msm_ctx* ctx, void* out, const voi
         store_point(out, r);
     });
 }
+SPPARK_FFI RustError sppark_msm_set_points(sppark_msm_ctx* ctx, const void* points, size_t npoints, size_t ffi_affine_sz)
+{   return guarded([&] { ctx->impl.preload(points, npoints, ffi_affine_sz); });   }
+SPPARK_FFI size_t sppark_msm_preloaded(const sppark_msm_ctx* ctx) { return ctx->impl.preloaded(); }
 SPPARK_FFI RustError sppark_msm_enable_timing(sppark_msm_ctx* ctx, int on)
 {   return guarded([&] { ctx->impl.enable_timing(on != 0); });   }
 SPPARK_FFI float sppark_msm_kernel_ms(const sppark_msm_ctx* ctx, int which) { return ctx->impl.kernel_ms(which); }

@@ -61,6 +61,53 @@ SPPARK_FFI RustError sppark_ntt(size_t device_id, void* inout, uint32_t lg_domai
                                 int ntt_order, int ntt_direction, int ntt_type, void* stream)
 {   return guarded([&] { ntt_any(device_id, inout, lg_domain_size, ntt_order, ntt_direction, ntt_type, (hipStream_t)stream); });   }
 
+// ---- low-degree extension (C++-only in the reference: NTT::LDE / LDE_aux / LDE_powers / LDE_expand) ----
+static void lde_any(size_t device_id, void* inout, uint32_t lg_domain, uint32_t lg_blowup, void* aux_out, hipStream_t stream)
+{
+    const gpu_info& gpu = select_gpu((int)device_id);
+    const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
+    const bool dev = is_device_pointer(inout), aux_dev = aux_out && is_device_pointer(aux_out);
+    // scratch: [tmp: dom][aux: dom, when it has to be staged][ext, when inout is a host buffer]
+    const size_t need = dom + (aux_out && !aux_dev ? dom : 0) + (dev ? 0 : ext);
+    fr_t* scratch = nullptr;
+    HIP_OK(hipMalloc((void**)&scratch, need * sizeof(fr_t)));
+    try {
+        fr_t* d_tmp = scratch;
+        fr_t* d_aux = aux_out ? (aux_dev ? (fr_t*)aux_out : scratch + dom) : nullptr;
+        fr_t* d_ext = dev ? (fr_t*)inout : scratch + need - ext;
+        if (!dev) HIP_OK(hipMemcpyAsync(d_ext, inout, dom * sizeof(fr_t), hipMemcpyHostToDevice, stream));
+        ntt_engine<fr_t>::instance().lde(gpu, d_ext, d_tmp, d_aux, lg_domain, lg_blowup, stream);
+        if (aux_out && !aux_dev) HIP_OK(hipMemcpyAsync(aux_out, d_aux, dom * sizeof(fr_t), hipMemcpyDeviceToHost, stream));
+        if (!dev) HIP_OK(hipMemcpyAsync(inout, d_ext, ext * sizeof(fr_t), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+    } catch (...) { (void)hipFree(scratch); throw; }
+    HIP_OK(hipFree(scratch));
+}
+
+SPPARK_FFI RustError sppark_lde(size_t device_id, void* inout, uint32_t lg_domain_size, uint32_t lg_blowup,
+                                void* aux_out, void* stream)
+{   return guarded([&] { lde_any(device_id, inout, lg_domain_size, lg_blowup, aux_out, (hipStream_t)stream); });   }
+
+SPPARK_FFI RustError sppark_lde_powers(size_t device_id, void* d_inout, uint32_t lg_domain_size, void* stream)
+{
+    return guarded([&] {
+        if (!is_device_pointer(d_inout)) HIP_OK(hipErrorInvalidValue);
+        ntt_engine<fr_t>::instance().lde_powers(select_gpu((int)device_id), (fr_t*)d_inout, lg_domain_size, (hipStream_t)stream);
+        if (stream == nullptr) HIP_OK(hipStreamSynchronize(nullptr));
+    });
+}
+
+SPPARK_FFI RustError sppark_lde_expand(size_t device_id, void* d_out, const void* d_in, uint32_t lg_domain_size,
+                                       uint32_t lg_blowup, void* stream)
+{
+    return guarded([&] {
+        if (!is_device_pointer(d_out) || !is_device_pointer(d_in)) HIP_OK(hipErrorInvalidValue);
+        ntt_engine<fr_t>::instance().lde_spread(select_gpu((int)device_id), (fr_t*)d_out, (const fr_t*)d_in,
+                                                lg_domain_size, lg_blowup, false, (hipStream_t)stream);
+        if (stream == nullptr) HIP_OK(hipStreamSynchronize(nullptr));
+    });
+}
+
 // ---- device test hook: element-wise field ops (tests/test_ntt_gpu.py) -----------
 // op 0: a+b  1: a-b  2: a*b  3: a*2^k (gl64 only; k = b's low byte mod 192)  7/8: fused butterfly sum/difference
 __global__ void k_small_field_op(fr_t* out, const fr_t* a, const fr_t* b, unsigned n, int op)

@@ -94,6 +94,8 @@ private:
     unsigned char* blob = nullptr;
     size_t blob_sz = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned char* pre_points = nullptr;    // points kept on the device by preload() (msm_t ctor with points, pippenger.cuh:351-385)
+    size_t pre_n = 0, pre_stride = 0;
     float last_ms[3] = {0, 0, 0};       // [0] digits+sort, [1] accumulate, [2] whole device part
     bool timing = false;
 
@@ -153,6 +155,7 @@ public:
     {
         (void)hipStreamSynchronize(stream);
         if (blob) (void)hipFree(blob);
+        if (pre_points) (void)hipFree(pre_points);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (own_stream) (void)hipStreamDestroy(stream);
     }
@@ -182,6 +185,24 @@ public:
         reserve(l.total);
     }
 
+    // Keep a copy of |np| points in HBM for later invoke(out, nullptr, n <= np, scalars, ...)
+    // calls: the reference's msm_t(points, np, ffi_affine_sz) + invoke(out, scalars)
+    // (pippenger.cuh:351-385,604-605).  |points| may be a host or a device pointer; np == 0 drops the copy.
+    void preload(const void* points, size_t np, size_t ffi_affine_sz)
+    {
+        HIP_OK(hipSetDevice(gpu->hip_id));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
+        if (np == 0) return;
+        if (points == nullptr || ffi_affine_sz < 2 * FP_BYTES || np > (1u << 31)) HIP_OK(hipErrorInvalidValue);
+        HIP_OK(hipMalloc((void**)&pre_points, np * ffi_affine_sz));
+        HIP_OK(hipMemcpyAsync(pre_points, points, np * ffi_affine_sz,
+                              is_device_pointer(points) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        pre_n = np; pre_stride = ffi_affine_sz;
+    }
+    size_t preloaded() const { return pre_n; }
+
     // out: Jacobian X|Y|Z (Montgomery).  points: stride ffi_affine_sz, flagged
     // format iff ffi_affine_sz > 2*FP_BYTES.  scalars: SCALAR_BYTES each.
     void invoke(point_t& out, const void* points, size_t npoints, const void* scalars,
@@ -191,6 +212,11 @@ public:
         if (npoints == 0) return;
         if (npoints > (1u << 31)) HIP_OK(hipErrorInvalidValue);
         HIP_OK(hipSetDevice(gpu->hip_id));
+        if (points == nullptr) {                    // preloaded points, their own stride
+            if (npoints > pre_n) HIP_OK(hipErrorInvalidValue);
+            points = pre_points; ffi_affine_sz = pre_stride;
+        }
+        if (scalars == nullptr) HIP_OK(hipErrorInvalidValue);
 
         const bool flagged = ffi_affine_sz > 2 * FP_BYTES;
         const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);

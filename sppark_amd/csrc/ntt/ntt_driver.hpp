@@ -163,6 +163,50 @@ public:
             hipLaunchKernelGGL(k_bitrev<F>, dim3(egrid), dim3(256), 0, stream, d, lg);
         HIP_OK(hipGetLastError());
     }
+
+    // d_inout[idx] *= g^(rev(idx))   (NTT::LDE_powers(stream, d_inout, lg), ntt/ntt.cuh:352-356)
+    void lde_powers(const gpu_info& gpu, F* d, unsigned lg, hipStream_t stream)
+    {
+        if (lg > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
+        const table_set& ts = tables(gpu.hip_id, lg, 0, stream);
+        ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale};
+        const size_t n = (size_t)1 << lg;
+        hipLaunchKernelGGL(k_coset<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d, G, 1);
+        HIP_OK(hipGetLastError());
+    }
+
+    // d_out[idx << lg_blowup] = d_in[idx] (* g^rev(idx) when |shift|), zeros elsewhere
+    // (NTT::LDE_expand / LDE_launch, ntt/ntt.cuh:247-281,358-365).  No overlap.
+    void lde_spread(const gpu_info& gpu, F* d_out, const F* d_in, unsigned lg_domain, unsigned lg_blowup,
+                    bool shift, hipStream_t stream)
+    {
+        if (lg_domain + lg_blowup > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
+        const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
+        if ((d_in < d_out + ext) && (d_out < d_in + dom)) HIP_OK(hipErrorInvalidValue);
+        const table_set& ts = tables(gpu.hip_id, lg_domain, 0, stream);
+        ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg_domain, ts.h, ts.scale};
+        hipLaunchKernelGGL(k_lde_spread<F>, dim3((unsigned)((ext + 255) / 256)), dim3(256), 0, stream,
+                           d_out, d_in, G, lg_domain, lg_blowup, (int)shift);
+        HIP_OK(hipGetLastError());
+    }
+
+    // Low-degree extension on the coset g*H' (NTT::LDE_aux, ntt/ntt.cuh:283-336):
+    // iNTT(NR) of the 2^lg_domain evaluations in d_ext[0 .. 2^lg_domain), coset shift +
+    // zero-extension in bit-reversed order, forward NTT(RN) of size 2^(lg_domain+lg_blowup).
+    // d_tmp: 2^lg_domain scratch elements; d_aux (nullable): the coefficients, natural order.
+    void lde(const gpu_info& gpu, F* d_ext, F* d_tmp, F* d_aux, unsigned lg_domain, unsigned lg_blowup, hipStream_t stream)
+    {
+        if (lg_domain + lg_blowup > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
+        const size_t dom = (size_t)1 << lg_domain;
+        HIP_OK(hipMemcpyAsync(d_tmp, d_ext, dom * sizeof(F), hipMemcpyDeviceToDevice, stream));
+        run(gpu, d_tmp, lg_domain, NTT_NR, NTT_INVERSE, NTT_STANDARD, stream);
+        if (d_aux) {
+            hipLaunchKernelGGL(k_bitrev_copy<F>, dim3((unsigned)((dom + 255) / 256)), dim3(256), 0, stream, d_aux, d_tmp, lg_domain);
+            HIP_OK(hipGetLastError());
+        }
+        lde_spread(gpu, d_ext, d_tmp, lg_domain, lg_blowup, true, stream);
+        run(gpu, d_ext, lg_domain + lg_blowup, NTT_RN, NTT_FORWARD, NTT_STANDARD, stream);
+    }
 };
 
 } // namespace sppark_amd

@@ -329,6 +329,44 @@ __global__ __launch_bounds__(256) void k_coset(F* data, ntt_tables<F> G, int bit
     if (i < ((size_t)1 << G.lg_n)) coset_item(data, G, bitrev, i);
 }
 
+// LDE spread (LDE_spread_distribute_powers, ntt/kernels.cu:155-237): the 2^lg_domain
+// inputs are in bit-reversed order; out[idx << lg_blowup] = in[idx] * g^(rev(idx))
+// (the coset shift, when |shift|), every other element of out is zero.  One work
+// item per OUTPUT element so the stores are coalesced; out and in must not overlap.
+template<class F>
+SPPARK_DEVFN void lde_spread_item(F* out, const F* in, const ntt_tables<F>& G, unsigned lg_domain,
+                                  unsigned lg_blowup, int shift, size_t o)
+{
+    const size_t idx = o >> lg_blowup;
+    F r = F();
+    if ((o & (((size_t)1 << lg_blowup) - 1)) == 0) {
+        r = in[idx];
+        if (shift) {
+            size_t e = 0;
+            for (unsigned k = 0; k < lg_domain; k++) e |= ((idx >> k) & 1) << (lg_domain - 1 - k);
+            r = r * ntt_twiddle(G, e);
+        }
+    }
+    out[o] = r;
+}
+template<class F>
+__global__ __launch_bounds__(256)
+void k_lde_spread(F* out, const F* in, ntt_tables<F> G, unsigned lg_domain, unsigned lg_blowup, int shift)
+{
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < ((size_t)1 << (lg_domain + lg_blowup))) lde_spread_item(out, in, G, lg_domain, lg_blowup, shift, o);
+}
+// out[rev(i)] = in[i]  (out-of-place bit reversal: the aux output of LDE_aux, ntt/ntt.cuh:312-315)
+template<class F>
+__global__ __launch_bounds__(256) void k_bitrev_copy(F* out, const F* in, unsigned lg_n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << lg_n)) return;
+    size_t r = 0;
+    for (unsigned k = 0; k < lg_n; k++) r |= ((i >> k) & 1) << (lg_n - 1 - k);
+    out[r] = in[i];
+}
+
 // table generation: lo[k] = base^k (k < 2^h), hi[k] = (base^(2^h))^k (k < 2^(lg_n-h)),
 // inner[(1 << R) + k] = w_{2^R}^k = base^(k << (lg_n - R)) for R <= min(8, lg_n)
 template<class F>

@@ -76,6 +76,10 @@ def load(name):
         L.sppark_msm_reserve.restype = _Error
         L.sppark_msm_invoke.argtypes = [vp, vp, vp, sz, vp, ci, sz]
         L.sppark_msm_invoke.restype = _Error
+        L.sppark_msm_set_points.argtypes = [vp, vp, sz, sz]
+        L.sppark_msm_set_points.restype = _Error
+        L.sppark_msm_preloaded.argtypes = [vp]
+        L.sppark_msm_preloaded.restype = sz
         L.sppark_msm_enable_timing.argtypes = [vp, ci]
         L.sppark_msm_enable_timing.restype = _Error
         L.sppark_msm_kernel_ms.argtypes = [vp, ci]
@@ -101,6 +105,13 @@ def load(name):
         L.compute_ntt.restype = _Error
         L.sppark_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci, vp]
         L.sppark_ntt.restype = _Error
+        u32 = ctypes.c_uint32
+        L.sppark_lde.argtypes = [sz, vp, u32, u32, vp, vp]
+        L.sppark_lde.restype = _Error
+        L.sppark_lde_powers.argtypes = [sz, vp, u32, vp]
+        L.sppark_lde_powers.restype = _Error
+        L.sppark_lde_expand.argtypes = [sz, vp, vp, u32, u32, vp]
+        L.sppark_lde_expand.restype = _Error
         L.sppark_devtest_small_field_op.argtypes = [ci, vp, vp, vp, sz]
         L.sppark_devtest_small_field_op.restype = _Error
     _LIBS[name] = L

@@ -108,10 +108,29 @@ class MsmContext:
         keys = ("window_bits", "windows", "buckets_per_window", "run_length", "partitions", "low_bits", "fan_in", "bucket_chunk")
         return dict(zip(keys, [int(v) for v in out]))
 
-    def invoke(self, points, scalars, npoints=None, mont=False, ffi_affine_sz=None):
+    def set_points(self, points, npoints=None, ffi_affine_sz=None):
+        """Keep a copy of the bases in HBM (msm_t(points, np, ffi_affine_sz),
+        msm/pippenger.cuh:351-385); invoke(None, scalars) then uses them."""
         stride = ffi_affine_sz or 2 * self.fb
+        if points is None:
+            ffi.check(self.L, self.L.sppark_msm_set_points(self.h, None, 0, stride))
+            return
         n = npoints if npoints is not None else _npoints(points, stride)
-        pp, _k1 = ffi.as_pointer(points)
+        pp, _k = ffi.as_pointer(points)
+        ffi.check(self.L, self.L.sppark_msm_set_points(self.h, pp, n, stride))
+
+    def preloaded(self):
+        return int(self.L.sppark_msm_preloaded(self.h))
+
+    def invoke(self, points, scalars, npoints=None, mont=False, ffi_affine_sz=None):
+        """points=None: the preloaded bases (invoke(out, scalars), pippenger.cuh:604-605)."""
+        stride = ffi_affine_sz or 2 * self.fb
+        if points is None:
+            n = npoints if npoints is not None else _npoints(scalars, 32)
+            pp, _k1 = None, None
+        else:
+            n = npoints if npoints is not None else _npoints(points, stride)
+            pp, _k1 = ffi.as_pointer(points)
         sp, _k2 = ffi.as_pointer(scalars)
         out = np.zeros(3 * self.fb, dtype=np.uint8)
         ffi.check(self.L, self.L.sppark_msm_invoke(self.h, out.ctypes.data, pp, n, sp, int(mont), stride))

@@ -59,3 +59,46 @@ def coset_NTT(device_id, inout, order, field="gl64", stream=None):
 
 def coset_iNTT(device_id, inout, order, field="gl64", stream=None):
     return compute_ntt(device_id, inout, order, NTTDirection.Inverse, NTTType.Coset, field, stream)
+
+
+def _nelems(buf, field):
+    nbytes = int(buf.nbytes) if hasattr(buf, "nbytes") else int(buf.numel() * buf.element_size())
+    return nbytes // _ELEM_BYTES[field]
+
+
+def LDE(device_id, inout, lg_domain_size, lg_blowup, field="gl64", aux_out=None, stream=None):
+    """NTT::LDE / LDE_aux (ntt/ntt.cuh:283-340), in place: |inout| (host or device) has
+    2^(lg_domain_size+lg_blowup) elements, the first 2^lg_domain_size hold the evaluations
+    on the small domain; on return: evaluations on the coset of the extended domain, natural
+    order.  aux_out (optional, 2^lg_domain_size elements) receives the coefficients."""
+    L = ffi.load(field)
+    if _nelems(inout, field) != 1 << (lg_domain_size + lg_blowup):
+        raise ValueError("inout must hold 2^(lg_domain_size+lg_blowup) elements")
+    if aux_out is not None and _nelems(aux_out, field) != 1 << lg_domain_size:
+        raise ValueError("aux_out must hold 2^lg_domain_size elements")
+    p, _k = ffi.as_pointer(inout)
+    a, _k2 = ffi.as_pointer(aux_out) if aux_out is not None else (None, None)
+    ffi.check(L, L.sppark_lde(device_id, p, lg_domain_size, lg_blowup, a, stream))
+    return inout
+
+
+def LDE_powers(device_id, d_inout, field="gl64", stream=None):
+    """NTT::LDE_powers(stream, d_inout, lg) (ntt/ntt.cuh:352-356): d_inout[i] *= g^bitrev(i); device buffer."""
+    L = ffi.load(field)
+    n = _nelems(d_inout, field)
+    if n & (n - 1) or n == 0:
+        raise ValueError("length is not power of 2")
+    p, _k = ffi.as_pointer(d_inout)
+    ffi.check(L, L.sppark_lde_powers(device_id, p, n.bit_length() - 1, stream))
+    return d_inout
+
+
+def LDE_expand(device_id, d_out, d_in, lg_domain_size, lg_blowup, field="gl64", stream=None):
+    """NTT::LDE_expand (ntt/ntt.cuh:358-365): d_out[i << lg_blowup] = d_in[i], zeros elsewhere; device buffers."""
+    L = ffi.load(field)
+    if _nelems(d_in, field) != 1 << lg_domain_size or _nelems(d_out, field) != 1 << (lg_domain_size + lg_blowup):
+        raise ValueError("buffer sizes do not match the domain sizes")
+    po, _k = ffi.as_pointer(d_out)
+    pi, _k2 = ffi.as_pointer(d_in)
+    ffi.check(L, L.sppark_lde_expand(device_id, po, pi, lg_domain_size, lg_blowup, stream))
+    return d_out

@@ -96,3 +96,28 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     if (order == 3) for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i);
     return 0;
 }
+
+// ntt_engine::lde() with the kernel bodies run on the host: iNTT(NR) of a copy,
+// lde_spread_item over every output element, NTT(RN) of the extended buffer.
+extern "C" int emu_lde(void* inout, unsigned lg_domain, unsigned lg_blowup, void* aux)
+{
+    F* ext = (F*)inout;
+    const size_t dom = (size_t)1 << lg_domain, n_ext = dom << lg_blowup;
+    std::vector<F> tmp(ext, ext + dom);
+    emu_ntt(tmp.data(), lg_domain, 1, 1, 0, 64);
+    if (aux) {
+        for (size_t i = 0; i < dom; i++) {
+            size_t r = 0;
+            for (unsigned k = 0; k < lg_domain; k++) r |= ((i >> k) & 1) << (lg_domain - 1 - k);
+            ((F*)aux)[r] = tmp[i];
+        }
+    }
+    unsigned h = lg_domain < 12 ? lg_domain : 12;
+    std::vector<F> glo(1u << h), ghi((size_t)1 << (lg_domain - h));
+    for (size_t k = 0; k < std::max(glo.size(), ghi.size()); k++)
+        table_item(glo.data(), ghi.data(), (F*)nullptr, group_gen(), lg_domain, h, k);
+    ntt_tables<F> G{glo.data(), ghi.data(), nullptr, lg_domain, h, F::one()};
+    for (size_t o = 0; o < n_ext; o++) lde_spread_item(ext, tmp.data(), G, lg_domain, lg_blowup, 1, o);
+    emu_ntt(ext, lg_domain + lg_blowup, 2, 0, 0, 64);
+    return 0;
+}

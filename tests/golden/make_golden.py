@@ -125,6 +125,53 @@ def make_ntt():
     print("ntt cases:", len(cases))
 
 
+# ---- LDE (NTT::LDE_aux, ntt/ntt.cuh:283-336), definition level ---------------------
+# coefficients c = inverse DFT of the evaluations; output[k] = sum_j c_j (g * w_ext^k)^j
+def py_lde(x, lg, lgb, p, top_root, two_adicity, gen):
+    n = 1 << lg
+    w = pow(top_root, 1 << (two_adicity - lg), p)
+    winv = pow(w, p - 2, p)
+    ninv = pow(n, p - 2, p)
+    c = [sum(x[k] * pow(winv, j * k, p) for k in range(n)) * ninv % p for j in range(n)]
+    we = pow(top_root, 1 << (two_adicity - lg - lgb), p)
+    out = []
+    for k in range(n << lgb):
+        pt = gen * pow(we, k, p) % p
+        out.append(sum(c[j] * pow(pt, j, p) for j in range(n)) % p)
+    return out, c
+
+
+def make_lde():
+    cases = []
+    R = 1 << 32
+    R256 = 1 << 256
+    for lg, lgb in ((0, 2), (1, 1), (3, 1), (3, 2), (4, 3)):
+        x = recipe.ntt_input("gl64", lg, 0x5eed5eed0004 + lg)
+        y, c = py_lde([int(v) for v in x], lg, lgb, O.GL64_P, 0x185629dcda58878c, 32, 7)
+        cases.append({"field": "gl64", "lg": lg, "lg_blowup": lgb, "input": hexs(x),
+                      "expect": hexs(np.array(y, dtype=np.uint64)), "aux": hexs(np.array(c, dtype=np.uint64))})
+        p = O.BB31_P
+        rinv = pow(R, p - 2, p)
+        x = recipe.ntt_input("bb31", lg, 0x5eed5eed0004 + lg)
+        y, c = py_lde([int(v) * rinv % p for v in x], lg, lgb, p, 0x1ffffedc * rinv % p, 27, 3)
+        cases.append({"field": "bb31", "lg": lg, "lg_blowup": lgb, "input": hexs(x),
+                      "expect": hexs(np.array([v * R % p for v in y], dtype=np.uint32)),
+                      "aux": hexs(np.array([v * R % p for v in c], dtype=np.uint32))})
+        for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28)):
+            p = O.FR_MODULUS[curve]
+            rinv = pow(R256, p - 2, p)
+            x = recipe.ntt_input(field, lg, 0x5eed5eed0005 + lg)
+            xc = [int.from_bytes(row.tobytes(), "little") * rinv % p for row in x]
+            y, c = py_lde(xc, lg, lgb, p, pow(gen, (p - 1) >> S, p), S, gen)
+            tow = lambda vals: np.frombuffer(b"".join((v * R256 % p).to_bytes(32, "little") for v in vals), dtype=np.uint64)
+            cases.append({"field": field, "lg": lg, "lg_blowup": lgb, "input": hexs(x),
+                          "expect": hexs(tow(y)), "aux": hexs(tow(c))})
+    json.dump(cases, open(os.path.join(HERE, "lde_golden.json"), "w"), indent=0)
+    print("lde cases:", len(cases))
+
+
 if __name__ == "__main__":
-    make_msm()
-    make_ntt()
+    if "--lde-only" not in sys.argv:
+        make_msm()
+        make_ntt()
+    make_lde()

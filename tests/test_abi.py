@@ -25,11 +25,11 @@ def test_header_symbols_exported(libs):
     common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message", "cuda_func",
               "sppark_gpu_ptr_alloc", "sppark_gpu_ptr_get"}
     msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1")}
-    ntt_only = {"compute_ntt", "sppark_ntt"}
+    ntt_only = {"compute_ntt", "sppark_ntt", "sppark_lde", "sppark_lde_powers", "sppark_lde_expand"}
     assert set(syms) == common | msm_only | ntt_only
     for name, path in libs.items():
         L = ctypes.CDLL(path)
-        want = common | (msm_only if name in ("bls12_381", "bn254") else ntt_only)
+        want = common | ntt_only | (msm_only if name in ("bls12_381", "bn254") else set())   # curve libs: NTT over Fr too
         for s in want:
             assert hasattr(L, s), (name, s)
 

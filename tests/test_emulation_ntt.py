@@ -24,6 +24,7 @@ def _emu(feature):
                                "-DFEATURE_" + feature, "-o", so, src])
     L = ctypes.CDLL(so)
     L.emu_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+    L.emu_lde.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
     return L
 
 
@@ -47,3 +48,21 @@ def test_ntt_kernels_on_host(oracle, field, feature):
                     y = x.copy()
                     L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 10 else 256)
                     assert (y == f(x, order, direction, typ)).all(), (field, lg, order, direction, typ)
+
+
+@pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR"),
+                                           ("bls12_381", "BLS12_381"), ("bn254", "BN254")])
+def test_lde_kernels_on_host(oracle, field, feature):
+    """ntt_engine::lde()'s kernel sequence (inverse NR passes, lde_spread_item, forward RN
+    passes) executed on the host against the oracle's restatement of NTT::LDE_aux."""
+    O = oracle
+    L = _emu(feature)
+    w = 4 if field in ("bls12_381", "bn254") else 1
+    for lg, lgb in ((1, 1), (3, 2), (6, 1), (9, 2), (11, 3) if w == 1 else (8, 3)):
+        x = recipe.ntt_input(field, lg, 300 + lg)
+        exp, aux_exp = O.lde(field, x, lgb, want_aux=True)
+        buf = np.zeros(((1 << (lg + lgb)), w), dtype=x.dtype); buf[:1 << lg] = x.reshape(-1, w)
+        aux = np.zeros((1 << lg, w), dtype=x.dtype)
+        L.emu_lde(buf.ctypes.data, lg, lgb, aux.ctypes.data)
+        assert (buf.reshape(exp.shape) == exp).all(), (field, lg, lgb)
+        assert (aux.reshape(aux_exp.shape) == aux_exp).all(), (field, lg, lgb)

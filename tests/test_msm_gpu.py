@@ -207,6 +207,39 @@ def test_msm_montgomery_scalars_and_device_pointers(oracle, libs):
     ctx.close()
 
 
+def test_msm_preloaded_points(oracle, libs):
+    """msm_t(points, np, ffi_affine_sz) + invoke(out, scalars) (pippenger.cuh:351-385,604-605):
+    bases copied once into HBM, then MSMs over the first n <= np of them."""
+    import torch
+    import sppark_amd
+    from sppark_amd import ffi
+    O = oracle
+    n = 3000
+    pts, sc = recipe.msm_inputs(0, n, 21, ndistinct=300, flagged=True)
+    ctx = sppark_amd.MsmContext("bls12_381")
+    with pytest.raises(ffi.SpparkError):                        # nothing preloaded yet
+        ctx.invoke(None, sc, ffi_affine_sz=104)
+    ctx.set_points(pts, ffi_affine_sz=104)
+    assert ctx.preloaded() == n
+    assert (sppark_amd.to_affine(ctx.invoke(None, sc)) == O.msm_affine(0, pts, sc, algo=0, param=8)).all()
+    sc2 = sc[::-1].copy()
+    assert (sppark_amd.to_affine(ctx.invoke(None, sc2)) == O.msm_affine(0, pts, sc2, algo=0, param=8)).all()
+    m = 1000                                                    # a prefix, device-resident scalars
+    d_sc = torch.from_numpy(sc[:m].copy()).cuda()
+    assert (sppark_amd.to_affine(ctx.invoke(None, d_sc)) == O.msm_affine(0, pts[:m], sc[:m], algo=0, param=8)).all()
+    with pytest.raises(ffi.SpparkError):                        # more scalars than preloaded points
+        ctx.invoke(None, np.concatenate([sc, sc]))
+    # replace the set from a DEVICE buffer in the unflagged 96-byte layout
+    pts96 = np.ascontiguousarray(pts[:, :96])
+    inf = pts[:, 96] != 0
+    pts96[inf] = 0
+    ctx.set_points(torch.from_numpy(pts96).cuda(), ffi_affine_sz=96)
+    assert (sppark_amd.to_affine(ctx.invoke(None, sc)) == O.msm_affine(0, pts, sc, algo=0, param=8)).all()
+    ctx.set_points(None)
+    assert ctx.preloaded() == 0
+    ctx.close()
+
+
 def test_msm_large_linearity(oracle, libs):
     """2^20 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b mod r) and the 2^16
     prefix equals the oracle -- size-independent properties at a size the

@@ -161,3 +161,81 @@ def test_ntt_lg0_noop_and_errors(libs):
         sppark_amd.NTT(0, np.zeros(3, dtype=np.uint64), sppark_amd.NTTInputOutputOrder.NN)
     with pytest.raises(ffi.SpparkError):                     # bad device id -> error, not a crash
         sppark_amd.NTT(99, np.zeros(8, dtype=np.uint64), sppark_amd.NTTInputOutputOrder.NN)
+
+
+def _field_views(field):
+    dt = np.uint32 if field == "bb31" else np.uint64
+    w = 4 if field in ("bls12_381", "bn254") else 1
+    return dt, w
+
+
+def test_lde_golden_vectors(oracle, libs):
+    """sppark_lde (NTT::LDE_aux) through the C ABI against the committed big-int vectors,
+    host buffers and device buffers, with and without the aux output."""
+    import torch
+    import sppark_amd
+    for c in json.load(open(os.path.join(HERE, "golden", "lde_golden.json"))):
+        dt, w = _field_views(c["field"])
+        x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt)
+        exp = np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)
+        aux_exp = np.frombuffer(bytes.fromhex(c["aux"]), dtype=dt)
+        buf = np.zeros(exp.size, dtype=dt); buf[:x.size] = x
+        aux = np.zeros(x.size, dtype=dt)
+        sppark_amd.LDE(0, buf, c["lg"], c["lg_blowup"], c["field"], aux_out=aux)
+        assert (buf == exp).all(), (c["field"], c["lg"], c["lg_blowup"])
+        assert (aux == aux_exp).all(), (c["field"], c["lg"], c["lg_blowup"])
+        tdt = torch.int32 if dt == np.uint32 else torch.int64
+        d = torch.zeros(exp.size, dtype=tdt, device="cuda")
+        d[:x.size] = torch.from_numpy(x.view(np.int32 if dt == np.uint32 else np.int64).copy()).cuda()
+        sppark_amd.LDE(0, d, c["lg"], c["lg_blowup"], c["field"], stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (d.cpu().numpy().view(dt) == exp).all(), (c["field"], c["lg"], c["lg_blowup"], "device")
+
+
+@pytest.mark.parametrize("field,lg,lgb", [("gl64", 10, 2), ("gl64", 15, 1), ("bb31", 12, 3), ("bls12_381", 9, 2), ("bn254", 11, 1)])
+def test_lde_vs_oracle(oracle, libs, field, lg, lgb):
+    import torch
+    import sppark_amd
+    O = oracle
+    dt, w = _field_views(field)
+    x = recipe.ntt_input(field, lg, 77 + lg)
+    exp, aux_exp = O.lde(field, x, lgb, want_aux=True)
+    buf = np.zeros(((1 << (lg + lgb)), w), dtype=dt); buf[:1 << lg] = x.reshape(-1, w)
+    aux = np.zeros((1 << lg, w), dtype=dt)
+    sppark_amd.LDE(0, buf, lg, lgb, field, aux_out=aux)
+    assert (buf.reshape(exp.shape) == exp).all()
+    assert (aux.reshape(aux_exp.shape) == aux_exp).all()
+    # LDE_powers / LDE_expand on device buffers
+    tdt = torch.int32 if dt == np.uint32 else torch.int64
+    sdt = np.int32 if dt == np.uint32 else np.int64
+    d_in = torch.from_numpy(np.ascontiguousarray(x).view(sdt).reshape(-1).copy()).cuda()
+    d_out = torch.empty(d_in.numel() << lgb, dtype=tdt, device="cuda")
+    sppark_amd.LDE_expand(0, d_out, d_in, lg, lgb, field)
+    assert (d_out.cpu().numpy().view(dt).reshape(-1, w) == O.lde_expand(field, x, lgb).reshape(-1, w)).all()
+    sppark_amd.LDE_powers(0, d_in, field)
+    assert (d_in.cpu().numpy().view(dt).reshape(-1, w) == O.lde_powers(field, x).reshape(-1, w)).all()
+    from sppark_amd import ffi
+    with pytest.raises(ffi.SpparkError):                        # overlapping expand is refused
+        sppark_amd.LDE_expand(0, d_out, d_out[:d_in.numel()], lg, lgb, field)
+
+
+def test_lde_large_properties(libs):
+    """2^20 -> 2^22 Goldilocks: the extension restricted to every 4th coset point is the coset
+    NTT of the original polynomial, and iNTT(coset) of the whole extension returns the padded
+    coefficients -- size-independent checks at a size the oracle is too slow for."""
+    import torch
+    import sppark_amd
+    from sppark_amd import NTTInputOutputOrder as Ord
+    lg, lgb = 20, 2
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x = (torch.randint(0, 2**62, (1 << lg,), dtype=torch.int64, device="cuda", generator=g))
+    ext = torch.zeros(1 << (lg + lgb), dtype=torch.int64, device="cuda"); ext[:1 << lg] = x
+    aux = torch.zeros(1 << lg, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    sppark_amd.LDE(0, ext, lg, lgb, "gl64", aux_out=aux, stream=s)
+    coef = x.clone(); sppark_amd.iNTT(0, coef, Ord.NN, "gl64", stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(coef, aux)
+    back = ext.clone(); sppark_amd.coset_iNTT(0, back, Ord.NN, "gl64", stream=s)
+    torch.cuda.synchronize()
+    assert torch.equal(back[:1 << lg], coef) and int(back[1 << lg:].abs().sum()) == 0

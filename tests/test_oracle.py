@@ -127,6 +127,29 @@ def test_ntt_golden(oracle):
         assert (got == e).all(), c
 
 
+def test_lde_golden(oracle):
+    """oracle LDE (restating NTT::LDE_aux, ntt/ntt.cuh:283-336) against the definition-level
+    big-int vectors: coset evaluations of the interpolating polynomial + its coefficients;
+    and the reference's reading of LDE as iNTT -> coset NTT on the zero-padded coefficients."""
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "lde_golden.json"))):
+        dt = np.uint32 if c["field"] == "bb31" else np.uint64
+        w = 4 if c["field"] in ("bls12_381", "bn254") else 1
+        x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt).reshape(-1, w)
+        got, aux = O.lde(c["field"], x, c["lg_blowup"], want_aux=True)
+        assert (got.reshape(-1) == np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)).all(), c
+        assert (aux.reshape(-1) == np.frombuffer(bytes.fromhex(c["aux"]), dtype=dt)).all(), c
+        # same thing through the plain transforms: pad the coefficients, coset NTT NN
+        if c["lg"] + c["lg_blowup"] > 0 and w == 1:
+            pad = np.zeros(x.shape[0] << c["lg_blowup"], dtype=dt)
+            pad[:x.shape[0]] = aux
+            f = O.ntt_gl64 if c["field"] == "gl64" else O.ntt_bb31
+            assert (f(pad, O.NN, O.FORWARD, O.COSET) == got).all()
+        # expand / powers helpers
+        e = O.lde_expand(c["field"], x, c["lg_blowup"]).reshape(-1, w)
+        assert (e[::1 << c["lg_blowup"]] == x).all() and int((e != 0).sum()) == int((x != 0).sum())
+
+
 def test_wide_ntt_roots_match_reference_tables(oracle):
     """forward_roots_of_unity[k] of ntt/parameters/{bls12_381,alt_bn128}.h, every k
     (the tables are read here, in the build container, only; nothing is copied)."""

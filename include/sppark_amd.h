@@ -5,8 +5,10 @@
  * -DFEATURE_* (rust/src/build.rs ccmd(), poc/{msm,ntt}-cuda/build.rs):
  *
  *   libsppark_bls12_381.so  mult_pippenger_inf, mult_pippenger          (BLS12-381 G1)
+ *                           mult_pippenger_fp2_inf                      (BLS12-381 G2)
  *                           compute_ntt                                 (BLS12-381 Fr, 2-adicity 32)
  *   libsppark_bn254.so      mult_pippenger_inf, mult_pippenger          (alt_bn128 G1)
+ *                           mult_pippenger_fp2_inf                      (alt_bn128 G2)
  *                           compute_ntt                                 (alt_bn128 Fr, 2-adicity 28)
  *   libsppark_gl64.so       compute_ntt                                 (Goldilocks)
  *   libsppark_bb31.so       compute_ntt                                 (BabyBear)
@@ -49,6 +51,14 @@ typedef struct { int code; char *message; } SppError;
  * Montgomery form; out: Jacobian X|Y|Z (144 B / 96 B).  On error out = infinity. */
 SppError mult_pippenger_inf(void *out, const void *points, size_t npoints,
                             const void *scalars, size_t ffi_affine_sz);
+
+/* poc/msm-cuda/cuda/pippenger_inf.cu:41-47.  The same over G2: coordinates are Fp2 elements
+ * c0 | c1 (ff/bls12-381-fp2.hpp:33-34), so points are X(2 fp) | Y(2 fp) | flag byte with stride
+ * ffi_affine_sz (200 for arkworks BLS12-381 G2Affine, 136 for bn254) and out is 3 Fp2
+ * coordinates (288 B / 192 B).  Called by multi_scalar_mult_fp2_arkworks
+ * (poc/msm-cuda/src/lib.rs:84-119). */
+SppError mult_pippenger_fp2_inf(void *out, const void *points, size_t npoints,
+                                const void *scalars, size_t ffi_affine_sz);
 
 /* poc/msm-cuda/cuda/pippenger.cu:20-25.  points: Affine_t (X | Y, infinity
  * encoded as all-zero), stride 2*sizeof(fp); same scalars/out as above. */
@@ -113,6 +123,9 @@ void     sppark_msm_plan(const sppark_msm_ctx *ctx, size_t npoints, unsigned out
  * multi-GPU combine step and by callers that want affine results. */
 void sppark_g1_jacobian_sum(void *out, const void *points, size_t n);
 void sppark_g1_to_affine(void *out_xy, const void *jacobian);
+/* the same for G2 points (Jacobian X|Y|Z, each coordinate c0 | c1) */
+void sppark_g2_jacobian_sum(void *out, const void *points, size_t n);
+void sppark_g2_to_affine(void *out_xy, const void *jacobian);
 /* P_i = k_i * G for i < n on the DEVICE, k_i = splitmix64(seed) stream, 253-bit;
  * out: affine, stride bytes apart (flag byte written when stride > 2*sizeof(fp)).
  * out may be a host or device pointer.  Synthetic-input generator for benches. */

@@ -16,12 +16,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 BLS12_381, BN254 = 0, 1
+BLS12_381_G2, BN254_G2 = 2, 3          # same curves, group G2 (coordinates in Fp2 = c0 | c1)
 FIELD_BLS_FP, FIELD_BLS_FR, FIELD_BN_FP, FIELD_BN_FR = 0, 1, 2, 3
 NN, NR, RN, RR = 0, 1, 2, 3
 FORWARD, INVERSE = 0, 1
 STANDARD, COSET = 0, 1
 
-FP_BYTES = {BLS12_381: 48, BN254: 32}
+FP_BYTES = {BLS12_381: 48, BN254: 32, BLS12_381_G2: 96, BN254_G2: 64}      # bytes per coordinate
 FR_MODULUS = {
     BLS12_381: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
     BN254: int("30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", 16),
@@ -30,6 +31,8 @@ FP_MODULUS = {
     BLS12_381: int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16),
     BN254: int("30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47", 16),
 }
+FR_MODULUS[BLS12_381_G2] = FR_MODULUS[BLS12_381]; FR_MODULUS[BN254_G2] = FR_MODULUS[BN254]
+FP_MODULUS[BLS12_381_G2] = FP_MODULUS[BLS12_381]; FP_MODULUS[BN254_G2] = FP_MODULUS[BN254]
 GL64_P = 0xffffffff00000001
 BB31_P = 0x78000001
 

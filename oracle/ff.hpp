@@ -338,9 +338,58 @@ template<class F> static inline F fpow(F b, uint64_t e)
     return r;
 }
 
+// ---------------------------------------------------------------------------
+// Fp2 = Fp[u]/(u^2 + 1): coordinate field of G2 for BLS12-381 and alt_bn128.  Memory image
+// c0 | c1 (fp_mont x[2], ff/bls12-381-fp2.hpp:33-34).  The reference's host-side Fp2 is blst's
+// (not vendored); this class offers the same interface mont_t does, so that the reference's
+// point templates (and this oracle's) instantiate over it.  Schoolbook products on purpose
+// (the device code uses Karatsuba).
+template<class FP> class fp2_t {
+public:
+    static const unsigned int degree = 2;
+    using mem_t = fp2_t;
+    FP c0, c1;
+
+    fp2_t() = default;
+    fp2_t(const FP& a, const FP& b) : c0(a), c1(b) {}
+    static fp2_t one(bool or_zero = false) { fp2_t r; r.c0 = FP::one(or_zero); r.c1.zero(); return r; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    void zero() { c0.zero(); c1.zero(); }
+    friend bool operator==(const fp2_t& a, const fp2_t& b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+    friend bool operator!=(const fp2_t& a, const fp2_t& b) { return !(a == b); }
+
+    fp2_t& operator+=(const fp2_t& b) { c0 += b.c0; c1 += b.c1; return *this; }
+    fp2_t& operator-=(const fp2_t& b) { c0 -= b.c0; c1 -= b.c1; return *this; }
+    fp2_t& operator*=(const fp2_t& b)
+    {
+        FP r0 = c0 * b.c0 - c1 * b.c1, r1 = c0 * b.c1 + c1 * b.c0;
+        c0 = r0; c1 = r1;
+        return *this;
+    }
+    friend fp2_t operator+(fp2_t a, const fp2_t& b) { return a += b; }
+    friend fp2_t operator-(fp2_t a, const fp2_t& b) { return a -= b; }
+    friend fp2_t operator*(fp2_t a, const fp2_t& b) { return a *= b; }
+    fp2_t& operator^=(int p) { (void)p; return *this *= *this; }       // only ^2 is used
+    friend fp2_t operator^(fp2_t a, int p) { return a ^= p; }
+    fp2_t& operator<<=(unsigned l) { c0 <<= l; c1 <<= l; return *this; }
+    friend fp2_t operator<<(fp2_t a, unsigned l) { return a <<= l; }
+    fp2_t& cneg(bool flag) { c0.cneg(flag); c1.cneg(flag); return *this; }
+    friend fp2_t czero(const fp2_t& a, int set_z) { fp2_t r; r.c0 = czero(a.c0, set_z); r.c1 = czero(a.c1, set_z); return r; }
+    // 1/(a0 + a1 u) = (a0 - a1 u)/(a0^2 + a1^2)
+    fp2_t reciprocal() const
+    {
+        FP n = (c0 * c0 + c1 * c1).reciprocal();
+        fp2_t r; r.c0 = c0 * n; r.c1 = c1 * n; r.c1.cneg(true);
+        return r;
+    }
+    friend fp2_t operator/(int one_, const fp2_t& a) { (void)one_; return a.reciprocal(); }
+};
+
 typedef mont_t<bls12_381_fp_params> bls12_381_fp;
 typedef mont_t<bls12_381_fr_params> bls12_381_fr;
 typedef mont_t<alt_bn128_fp_params> alt_bn128_fp;
 typedef mont_t<alt_bn128_fr_params> alt_bn128_fr;
+typedef fp2_t<bls12_381_fp> bls12_381_fp2;
+typedef fp2_t<alt_bn128_fp> alt_bn128_fp2;
 
 } // namespace oracle

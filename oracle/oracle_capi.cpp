@@ -69,7 +69,7 @@ template<class FP, class FR> struct curve_t {
     static affine<FP> load_affine(const unsigned char* p, size_t stride)
     {
         affine<FP> a;
-        memcpy(a.X.v, p, fp_bytes); memcpy(a.Y.v, p + fp_bytes, fp_bytes);
+        memcpy((void*)&a.X, p, fp_bytes); memcpy((void*)&a.Y, p + fp_bytes, fp_bytes);
         // flagged wire format (ec/affine_t.hpp:64-122, Affine_inf_t): the byte
         // after Y is the infinity flag; the plain format encodes inf as X=Y=0.
         if (stride > 2 * fp_bytes && (p[2 * fp_bytes] & 1)) a.set_inf();
@@ -78,20 +78,20 @@ template<class FP, class FR> struct curve_t {
     static void store_affine(unsigned char* p, const affine<FP>& a, size_t stride)
     {
         memset(p, 0, stride);
-        memcpy(p, a.X.v, fp_bytes); memcpy(p + fp_bytes, a.Y.v, fp_bytes);
+        memcpy(p, &a.X, fp_bytes); memcpy(p + fp_bytes, &a.Y, fp_bytes);
         if (stride > 2 * fp_bytes) p[2 * fp_bytes] = a.is_inf();
     }
     static jacobian<FP> load_jac(const unsigned char* p)
     {
         jacobian<FP> j;
-        memcpy(j.X.v, p, fp_bytes); memcpy(j.Y.v, p + fp_bytes, fp_bytes);
-        memcpy(j.Z.v, p + 2 * fp_bytes, fp_bytes);
+        memcpy((void*)&j.X, p, fp_bytes); memcpy((void*)&j.Y, p + fp_bytes, fp_bytes);
+        memcpy((void*)&j.Z, p + 2 * fp_bytes, fp_bytes);
         return j;
     }
     static void store_jac(unsigned char* p, const jacobian<FP>& j)
     {
-        memcpy(p, j.X.v, fp_bytes); memcpy(p + fp_bytes, j.Y.v, fp_bytes);
-        memcpy(p + 2 * fp_bytes, j.Z.v, fp_bytes);
+        memcpy(p, &j.X, fp_bytes); memcpy(p + fp_bytes, &j.Y, fp_bytes);
+        memcpy(p + 2 * fp_bytes, &j.Z, fp_bytes);
     }
 };
 
@@ -110,6 +110,37 @@ struct alt_bn128_g1 : curve_t<alt_bn128_fp, alt_bn128_fr> {
     static affine<fp> generator()
     {   affine<fp> g; g.X = from_hex<fp>("1"); g.Y = from_hex<fp>("2"); return g;   }
     static fp b() { return from_hex<fp>("3"); }
+};
+
+// G2: the twists over Fp2 = Fp[u]/(u^2 + 1).  Standard generators (checked on-curve by
+// tests/test_oracle.py and, independently, with Python big-ints in tests/golden/make_golden.py)
+template<class FP2, class FP> static FP2 fp2_hex(const char* c0, const char* c1)
+{   FP2 r; r.c0 = from_hex<FP>(c0); r.c1 = from_hex<FP>(c1); return r;   }
+struct bls12_381_g2 : curve_t<bls12_381_fp2, bls12_381_fr> {
+    static affine<fp> generator()
+    {
+        affine<fp> g;
+        g.X = fp2_hex<fp, bls12_381_fp>("024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8",
+                                        "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e");
+        g.Y = fp2_hex<fp, bls12_381_fp>("0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801",
+                                        "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be");
+        return g;
+    }
+    static fp b() { return fp2_hex<fp, bls12_381_fp>("4", "4"); }                 // y^2 = x^3 + 4(1 + u)
+};
+struct alt_bn128_g2 : curve_t<alt_bn128_fp2, alt_bn128_fr> {
+    static affine<fp> generator()
+    {
+        affine<fp> g;
+        g.X = fp2_hex<fp, alt_bn128_fp>("1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed",
+                                        "198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2");
+        g.Y = fp2_hex<fp, alt_bn128_fp>("12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa",
+                                        "090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b");
+        return g;
+    }
+    static fp b()                                                               // y^2 = x^3 + 3/(9 + u)
+    {   return fp2_hex<fp, alt_bn128_fp>("2b149d40ceb8aaae81be18991be06ac3b5b4c5e559dbefa33267e6dc24a138e5",
+                                         "009713b03af0fed4cd2cafadeed8fdf4a74fa084e52d1852e4a2bd0685c315d2");   }
 };
 
 template<class C>
@@ -165,8 +196,8 @@ template<class C> void xyzz_to_affine_impl(unsigned char* out, const unsigned ch
 {
     xyzz<typename C::fp> p;
     const size_t fb = C::fp_bytes;
-    memcpy(p.X.v, in, fb); memcpy(p.Y.v, in + fb, fb);
-    memcpy(p.ZZZ.v, in + 2 * fb, fb); memcpy(p.ZZ.v, in + 3 * fb, fb);
+    memcpy((void*)&p.X, in, fb); memcpy((void*)&p.Y, in + fb, fb);
+    memcpy((void*)&p.ZZZ, in + 2 * fb, fb); memcpy((void*)&p.ZZ, in + 3 * fb, fb);
     C::store_affine(out, p.to_affine(), stride);
 }
 
@@ -198,12 +229,24 @@ int msm_dispatch(int algo, unsigned char* out_jac, const unsigned char* points, 
     return 0;
 }
 
+template<class C> void store_generator(unsigned char* out, size_t stride)
+{   C::store_affine(out, C::generator(), stride);   }
+
 } // namespace
 
-#define CURVE_DISPATCH(curve, call_bls, call_bn) \
-    switch (curve) { case 0: call_bls; break; case 1: call_bn; break; default: return -1; }
-#define CURVE_RETURN(curve, call_bls, call_bn) \
-    switch (curve) { case 0: return call_bls; case 1: return call_bn; default: return -1; }
+// curve: 0 BLS12-381 G1, 1 alt_bn128 G1, 2 BLS12-381 G2, 3 alt_bn128 G2
+#define CURVE_DO(curve, FN, ...)                                                         \
+    switch (curve) {                                                                     \
+        case 0: FN<bls12_381_g1>(__VA_ARGS__); break; case 1: FN<alt_bn128_g1>(__VA_ARGS__); break; \
+        case 2: FN<bls12_381_g2>(__VA_ARGS__); break; case 3: FN<alt_bn128_g2>(__VA_ARGS__); break; \
+        default: return -1;                                                              \
+    }
+#define CURVE_RET(curve, FN, ...)                                                        \
+    switch (curve) {                                                                     \
+        case 0: return FN<bls12_381_g1>(__VA_ARGS__); case 1: return FN<alt_bn128_g1>(__VA_ARGS__); \
+        case 2: return FN<bls12_381_g2>(__VA_ARGS__); case 3: return FN<alt_bn128_g2>(__VA_ARGS__); \
+        default: return -1;                                                              \
+    }
 
 extern "C" {
 
@@ -221,71 +264,40 @@ int oracle_field_op(int field, int op, uint64_t* out, const uint64_t* a, const u
 }
 
 int oracle_g1_generator(int curve, unsigned char* out, size_t stride)
-{
-    CURVE_DISPATCH(curve,
-        bls12_381_g1::store_affine(out, bls12_381_g1::generator(), stride),
-        alt_bn128_g1::store_affine(out, alt_bn128_g1::generator(), stride));
-    return 0;
-}
+{   CURVE_DO(curve, store_generator, out, stride); return 0;   }
 
 // P_i = k_i * G with k_i from splitmix64(seed), 253-bit
 int oracle_g1_gen_points(int curve, unsigned char* out, size_t stride, size_t n, uint64_t seed)
-{
-    CURVE_DISPATCH(curve, gen_points<bls12_381_g1>(out, stride, n, seed),
-                          gen_points<alt_bn128_g1>(out, stride, n, seed));
-    return 0;
-}
+{   CURVE_DO(curve, gen_points, out, stride, n, seed); return 0;   }
 
 int oracle_g1_mul(int curve, unsigned char* out, const unsigned char* in, size_t stride, const unsigned char* scalar_le)
-{
-    CURVE_DISPATCH(curve, g1_mul<bls12_381_g1>(out, in, stride, scalar_le),
-                          g1_mul<alt_bn128_g1>(out, in, stride, scalar_le));
-    return 0;
-}
+{   CURVE_DO(curve, g1_mul, out, in, stride, scalar_le); return 0;   }
 
 int oracle_g1_on_curve(int curve, const unsigned char* in, size_t stride)
-{   CURVE_RETURN(curve, on_curve_impl<bls12_381_g1>(in, stride), on_curve_impl<alt_bn128_g1>(in, stride));   }
+{   CURVE_RET(curve, on_curve_impl, in, stride);   }
 
 int oracle_jac_to_affine(int curve, unsigned char* out, const unsigned char* in_jac, size_t stride)
-{
-    CURVE_DISPATCH(curve, jac_to_affine_impl<bls12_381_g1>(out, in_jac, stride),
-                          jac_to_affine_impl<alt_bn128_g1>(out, in_jac, stride));
-    return 0;
-}
+{   CURVE_DO(curve, jac_to_affine_impl, out, in_jac, stride); return 0;   }
 
 int oracle_xyzz_to_affine(int curve, unsigned char* out, const unsigned char* in_xyzz, size_t stride)
-{
-    CURVE_DISPATCH(curve, xyzz_to_affine_impl<bls12_381_g1>(out, in_xyzz, stride),
-                          xyzz_to_affine_impl<alt_bn128_g1>(out, in_xyzz, stride));
-    return 0;
-}
+{   CURVE_DO(curve, xyzz_to_affine_impl, out, in_xyzz, stride); return 0;   }
 
 int oracle_jac_add(int curve, unsigned char* out, const unsigned char* a, const unsigned char* b)
-{
-    CURVE_DISPATCH(curve, jac_add_impl<bls12_381_g1>(out, a, b), jac_add_impl<alt_bn128_g1>(out, a, b));
-    return 0;
-}
+{   CURVE_DO(curve, jac_add_impl, out, a, b); return 0;   }
 
 int oracle_jac_dbl(int curve, unsigned char* out, const unsigned char* a)
-{
-    CURVE_DISPATCH(curve, jac_dbl_impl<bls12_381_g1>(out, a), jac_dbl_impl<alt_bn128_g1>(out, a));
-    return 0;
-}
+{   CURVE_DO(curve, jac_dbl_impl, out, a); return 0;   }
 
 int oracle_jac_eq(int curve, const unsigned char* a, const unsigned char* b)
-{   CURVE_RETURN(curve, jac_eq_impl<bls12_381_g1>(a, b), jac_eq_impl<alt_bn128_g1>(a, b));   }
+{   CURVE_RET(curve, jac_eq_impl, a, b);   }
 
 // algo 0: restated msm/pippenger.hpp with |param| = ncpus (0/1 -> serial path)
 // algo 1: naive sum of double-and-add
 // algo 2: signed-window model of the GPU semantics with |param| = window bits
-// out_jac: X|Y|Z Montgomery limbs (144 B BLS12-381, 96 B alt_bn128)
+// out_jac: X|Y|Z Montgomery limbs (144 B BLS12-381 G1, 96 B alt_bn128 G1, 288 / 192 B for G2)
 int oracle_msm(int curve, int algo, unsigned char* out_jac, const unsigned char* points,
                size_t stride, size_t npoints, const unsigned char* scalars, int mont, size_t param)
-{
-    CURVE_RETURN(curve,
-        msm_dispatch<bls12_381_g1>(algo, out_jac, points, stride, npoints, scalars, mont, param),
-        msm_dispatch<alt_bn128_g1>(algo, out_jac, points, stride, npoints, scalars, mont, param));
-}
+{   CURVE_RET(curve, msm_dispatch, algo, out_jac, points, stride, npoints, scalars, mont, param);   }
 
 void oracle_ntt_gl64(uint64_t* inout, unsigned lg, int order, int direction, int type)
 {   ntt(reinterpret_cast<gl64*>(inout), lg, order, direction, type);   }

@@ -34,8 +34,8 @@ int ref_msm(unsigned char* out_affine, const unsigned char* points, size_t strid
     pts.reserve(npoints);
     for (size_t i = 0; i < npoints; i++) {
         FP x, y;
-        memcpy(x.v, points + i * stride, fb);
-        memcpy(y.v, points + i * stride + fb, fb);
+        memcpy((void*)&x, points + i * stride, fb);
+        memcpy((void*)&y, points + i * stride + fb, fb);
         if (stride > 2 * fb && (points[i * stride + 2 * fb] & 1)) { x.zero(); y.zero(); }
         pts.push_back(affine_t{x, y});
     }
@@ -67,6 +67,10 @@ int ref_mult_pippenger(int curve, unsigned char* out_affine, const unsigned char
     switch (curve) {
         case 0: return ref_msm<bls12_381_fp, bls12_381_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
         case 1: return ref_msm<alt_bn128_fp, alt_bn128_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
+        // G2: the same reference templates over the oracle's Fp2 (jacobian_t<fp2_t>, xyzz_t<fp2_t>,
+        // as poc/msm-cuda/cuda/pippenger_inf.cu:36-47 instantiates them on the device)
+        case 2: return ref_msm<bls12_381_fp2, bls12_381_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
+        case 3: return ref_msm<alt_bn128_fp2, alt_bn128_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
     }
     return -1;
 }

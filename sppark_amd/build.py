@@ -22,8 +22,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 
 MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
            "msm/k_bucket1.hip", "msm/k_bucketN.hip", "api/devtest_api.hip",
-           "api/ntt_api.hip:SPPARK_NTT_WITH_MSM"]          # compute_ntt over the curve's scalar field
-NTT_TUS = ["api/ntt_api.hip"]
+           "msm/k_accumulate.hip:SPPARK_G2", "msm/k_reduce.hip:SPPARK_G2",       # the same kernels over Fp2 (G2)
+           "msm/k_bucket1.hip:SPPARK_G2", "msm/k_bucketN.hip:SPPARK_G2",
+           "api/ntt_api.hip:SPPARK_NTT_WITH_MSM",          # compute_ntt over the curve's scalar field
+           "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0"]
+NTT_TUS = ["api/ntt_api.hip", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0"]
 
 TARGETS = {
     "bls12_381": ("FEATURE_BLS12_381", MSM_TUS),
@@ -71,7 +74,7 @@ def build(only=None, force=False, verbose=True, jobs=None):
             continue
         objs = []
         for s in tus:
-            obj = os.path.join(OBJDIR, "%s__%s.o" % (n, s.split(":")[0].replace("/", "_")))
+            obj = os.path.join(OBJDIR, "%s__%s.o" % (n, s.replace(":", "__").replace("/", "_")))
             objs.append(obj)
             todo.append((s, obj, feature))
         links[n] = objs

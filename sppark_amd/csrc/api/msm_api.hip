@@ -18,16 +18,30 @@ extern template __global__ void k_reduce_runs<fp_d>(bucket_m*, u32*, bucket_m*, 
 extern template __global__ void k_bucket_level1<fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_levelN<fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
+// ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)
+extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
+                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
+                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
+                                                     unsigned, unsigned, unsigned, int);
+extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
+                                                       unsigned, unsigned, unsigned, unsigned);
 }
 
+#include "../ff/fp2_host.hpp"
 #include "../msm/msm_driver.hpp"
 #include "common_api.hpp"
 
 using namespace sppark_amd;
 
-typedef msm_t<curve_p::fp, curve_p::fr> msm_impl;
+typedef msm_t<fp_d, mont_host<curve_p::fp>, curve_p::fr> msm_impl;
 typedef msm_impl::point_t point_t;
 typedef msm_impl::fp_h fp_h;
+typedef msm_t<fp2_d, fp2_host<curve_p::fp>, curve_p::fr> msm2_impl;       // G2
+typedef msm2_impl::point_t point2_t;
+typedef msm2_impl::fp_h fp2_h;
 
 struct sppark_msm_ctx { msm_impl impl; sppark_msm_ctx(int id, hipStream_t s) : impl(id, s) {} };
 
@@ -62,6 +76,19 @@ SPPARK_FFI RustError mult_pippenger_inf(void* out, const void* points, size_t np
 
 SPPARK_FFI RustError mult_pippenger(void* out, const void* points, size_t npoints, const void* scalars)
 {   return one_shot(out, points, npoints, scalars, false, 2 * sizeof(fp_d));   }
+
+// poc/msm-cuda/cuda/pippenger_inf.cu:41-47: the same over G2 (coordinates in Fp2)
+SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_t npoints,
+                                            const void* scalars, size_t ffi_affine_sz)
+{
+    memset(out, 0, sizeof(point2_t));
+    return guarded([&] {
+        msm2_impl msm(-1);
+        point2_t r;
+        msm.invoke(r, points, npoints, scalars, false, ffi_affine_sz);
+        memcpy(out, &r, sizeof(r));
+    });
+}
 
 SPPARK_FFI RustError sppark_msm_create(sppark_msm_ctx** ctx, int device_id, void* stream)
 {
@@ -125,6 +152,24 @@ SPPARK_FFI void sppark_g1_to_affine(void* out_xy, const void* jacobian)
 {
     point_t p; memcpy(&p, jacobian, sizeof(p));
     fp_h xy[2];
+    p.to_affine(xy[0], xy[1]);
+    memcpy(out_xy, xy, sizeof(xy));
+}
+
+// G2 twins of the host helpers
+SPPARK_FFI void sppark_g2_jacobian_sum(void* out, const void* points, size_t n)
+{
+    point2_t acc; acc.set_inf();
+    for (size_t i = 0; i < n; i++) {
+        point2_t p; memcpy(&p, (const char*)points + i * sizeof(point2_t), sizeof(p));
+        acc.add(p);
+    }
+    memcpy(out, &acc, sizeof(acc));
+}
+SPPARK_FFI void sppark_g2_to_affine(void* out_xy, const void* jacobian)
+{
+    point2_t p; memcpy(&p, jacobian, sizeof(p));
+    fp2_h xy[2];
     p.to_affine(xy[0], xy[1]);
     memcpy(out_xy, xy, sizeof(xy));
 }

@@ -1,7 +1,15 @@
 // C-ABI of the NTT library (one .so per field: -DFEATURE_GOLDILOCKS /
 // -DFEATURE_BABY_BEAR, as poc/ntt-cuda/build.rs selects them).  Declarations +
 // reference citations: include/sppark_amd.h.
-#include "../ff/params.hpp"
+#include "../ntt/field_select.hpp"
+namespace sppark_amd {
+#define SPPARK_NTT_EXTERN(DIF, INV, R1, R2) \
+    extern template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, false)
+#if !defined(FEATURE_BLS12_381) && !defined(FEATURE_BN254)
+SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, false)
+#endif
+}
 #include "../ntt/ntt_driver.hpp"
 #ifdef SPPARK_NTT_WITH_MSM            // same .so as msm_api.hip, which already defines the common symbols
 # define SPPARK_FFI extern "C" __attribute__((visibility("default")))
@@ -10,18 +18,7 @@
 #endif
 
 using namespace sppark_amd;
-
-#if defined(FEATURE_GOLDILOCKS)
-typedef gl64_dev fr_t;
-#elif defined(FEATURE_BABY_BEAR)
-typedef bb31_dev fr_t;
-#elif defined(FEATURE_BLS12_381)       // poc/ntt-cuda/cuda/ntt_api.cu:7-8 -> ff/bls12-381.hpp fr_t
-typedef fr256_dev<bls12_381_fr_p> fr_t;
-#elif defined(FEATURE_BN254)           // ntt_api.cu:15-16 -> ff/alt_bn128.hpp fr_t
-typedef fr256_dev<alt_bn128_fr_p> fr_t;
-#else
-# error "no FEATURE"
-#endif
+typedef ntt_fr_t fr_t;
 
 template<class Fn> static RustError guarded(Fn&& fn)
 {

@@ -4,6 +4,7 @@
 #include "../ff/params.hpp"
 #include "../ff/mont_dev.hpp"
 #include "../ff/mont30_dev.hpp"
+#include "../ff/fp2_dev.hpp"
 #include "../ec/xyzz_dev.hpp"
 
 namespace sppark_amd {
@@ -28,4 +29,15 @@ typedef fp_class<curve_p::fp> fp_d;
 typedef mont_dev<curve_p::fr> fr_d;
 typedef xyzz_dev<fp_d> bucket_d;           // register type
 typedef bucket_d::mem_t bucket_m;           // memory image (wire format)
+// G2: same pipeline over the quadratic extension (ff/fp2_dev.hpp).  The kernel
+// translation units are compiled a second time with -DSPPARK_G2 to instantiate it.
+typedef fp2_dev<curve_p::fp> fp2_d;
+typedef xyzz_dev<fp2_d> bucket2_d;
+typedef bucket2_d::mem_t bucket2_m;
+#ifdef SPPARK_G2
+typedef fp2_d inst_fp;
+#else
+typedef fp_d inst_fp;
+#endif
+typedef xyzz_dev<inst_fp>::mem_t inst_m;    // what the k_*.hip units instantiate
 }

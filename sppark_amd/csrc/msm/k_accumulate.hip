@@ -3,8 +3,8 @@
 #include "curve_select.hpp"
 #include "msm_kernels.hpp"
 namespace sppark_amd {
-template __global__ void k_accumulate<fp_d, false>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
+template __global__ void k_accumulate<inst_fp, false>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
                                                    const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
-template __global__ void k_accumulate<fp_d, true>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
+template __global__ void k_accumulate<inst_fp, true>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
                                                   const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
 }

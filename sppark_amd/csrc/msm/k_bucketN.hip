@@ -1,6 +1,6 @@
 #include "curve_select.hpp"
 #include "msm_kernels.hpp"
 namespace sppark_amd {
-template __global__ void k_bucket_levelN<fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
+template __global__ void k_bucket_levelN<inst_fp>(inst_m*, inst_m*, const inst_m*, const inst_m*,
                                                unsigned, unsigned, unsigned, unsigned);
 }

@@ -1,6 +1,6 @@
 #include "curve_select.hpp"
 #include "msm_kernels.hpp"
 namespace sppark_amd {
-template __global__ void k_reduce_runs<fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
+template __global__ void k_reduce_runs<inst_fp>(inst_m*, u32*, inst_m*, const u32*, const inst_m*,
                                              unsigned, unsigned, unsigned, int);
 }

@@ -76,15 +76,18 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     return p;
 }
 
-template<class FPp, class FRp>
+// FD: device coordinate field (fp_class<P> for G1, fp2_dev<P> for G2), FH: its host
+// twin with the same memory image (mont_host<P> / fp2_host<P>), FRp: scalar field.
+template<class FD, class FH, class FRp>
 class msm_t {
 public:
-    typedef fp_class<FPp> fp_d;
+    typedef FD fp_d;
     typedef mont_dev<FRp> fr_d;
-    typedef mont_host<FPp> fp_h;
+    typedef FH fp_h;
     typedef typename xyzz_dev<fp_d>::mem_t bucket_t;       // memory image: wire format
     typedef jacobian_host<fp_h> point_t;
-    static constexpr size_t FP_BYTES = 4 * FPp::N;
+    static constexpr size_t FP_BYTES = 4 * FD::N;
+    static_assert(sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
 
 private:

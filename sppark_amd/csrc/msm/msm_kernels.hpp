@@ -235,6 +235,22 @@ void k_reduce_runs(xyzz_mem<FP::N>* __restrict__ buckets,
 // bucket reduction, level 1: work item = (window, chunk of K buckets)
 //   A[u]  = sum_j B[uK+j]          Wt[u] = sum_j (j+1) * B[uK+j]
 // (running-sum trick of msm/pippenger.hpp:40-56 / pippenger.cuh:225-296)
+// Full additions in the bucket-sum levels.  Over Fp2 (G2) one inlined add is ~70 base-field
+// product bodies; the five call sites of bucket_levelN_item would be a 0.9 MB kernel that
+// takes minutes to compile, for a phase that is a few percent of an MSM.  Wide coordinate
+// fields therefore call ONE outlined copy (operands travel through scratch memory).
+#if defined(SPPARK_HOST_EMULATION)
+# define SPPARK_OUTLINED inline
+#else
+# define SPPARK_OUTLINED __device__ __noinline__
+#endif
+template<class FP> SPPARK_OUTLINED void xyzz_add_outlined(xyzz_dev<FP>& a, const xyzz_dev<FP>& b) { a.add(b); }
+template<class FP> SPPARK_OUTLINED void xyzz_dbl_outlined(xyzz_dev<FP>& a) { a.dbl(); }
+template<class FP> SPPARK_DEVFN void bucket_add(xyzz_dev<FP>& a, const xyzz_dev<FP>& b)
+{   if constexpr (FP::N > 12) xyzz_add_outlined<FP>(a, b); else a.add(b);   }
+template<class FP> SPPARK_DEVFN void bucket_dbl(xyzz_dev<FP>& a)
+{   if constexpr (FP::N > 12) xyzz_dbl_outlined<FP>(a); else a.dbl();   }
+
 // ---------------------------------------------------------------------------
 template<class FP>
 SPPARK_DEVFN void bucket_level1_item(xyzz_mem<FP::N>* A, xyzz_mem<FP::N>* Wt, const xyzz_mem<FP::N>* buckets,
@@ -246,8 +262,8 @@ SPPARK_DEVFN void bucket_level1_item(xyzz_mem<FP::N>* A, xyzz_mem<FP::N>* Wt, co
     const xyzz_mem<FP::N>* row = buckets + (size_t)w * NB + (size_t)u * K;
     xyzz_dev<FP> acc = xyzz_dev<FP>::load(&row[K - 1]), ret = acc;
     for (unsigned j = K - 1; j--;) {
-        acc.add(xyzz_dev<FP>::load(&row[j]));
-        ret.add(acc);
+        bucket_add<FP>(acc, xyzz_dev<FP>::load(&row[j]));
+        bucket_add<FP>(ret, acc);
     }
     acc.store(&A[id]); ret.store(&Wt[id]);
 }
@@ -273,13 +289,13 @@ SPPARK_DEVFN void bucket_levelN_item(xyzz_mem<FP::N>* A2, xyzz_mem<FP::N>* Wt2,
     acc.set_inf(); r.set_inf();
     sw = xyzz_dev<FP>::load(&Wt1[base]);
     for (unsigned j = K - 1; j >= 1; j--) {
-        acc.add(xyzz_dev<FP>::load(&A1[base + j]));
-        r.add(acc);
-        sw.add(xyzz_dev<FP>::load(&Wt1[base + j]));
+        bucket_add<FP>(acc, xyzz_dev<FP>::load(&A1[base + j]));
+        bucket_add<FP>(r, acc);
+        bucket_add<FP>(sw, xyzz_dev<FP>::load(&Wt1[base + j]));
     }
-    acc.add(xyzz_dev<FP>::load(&A1[base]));
-    for (unsigned k = 0; k < lgG; k++) r.dbl();
-    sw.add(r);
+    bucket_add<FP>(acc, xyzz_dev<FP>::load(&A1[base]));
+    for (unsigned k = 0; k < lgG; k++) bucket_dbl<FP>(r);
+    bucket_add<FP>(sw, r);
     acc.store(&A2[id]); sw.store(&Wt2[id]);
 }
 

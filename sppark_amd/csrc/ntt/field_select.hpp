@@ -1,0 +1,32 @@
+// NTT element type by -DFEATURE_* (poc/ntt-cuda/cuda/ntt_api.cu:7-21 selects the field header
+// the same way).  The curve features pick the curve's SCALAR field (256-bit, Montgomery).
+#pragma once
+#include "../ff/params.hpp"
+#include "../ff/small_fields_dev.hpp"
+#include "../ff/fr256_dev.hpp"
+#include "ntt_kernels.hpp"
+
+namespace sppark_amd {
+#if defined(FEATURE_GOLDILOCKS)
+typedef gl64_dev ntt_fr_t;
+#elif defined(FEATURE_BABY_BEAR)
+typedef bb31_dev ntt_fr_t;
+#elif defined(FEATURE_BLS12_381)       // ntt_api.cu:7-8 -> ff/bls12-381.hpp fr_t
+typedef fr256_dev<bls12_381_fr_p> ntt_fr_t;
+#elif defined(FEATURE_BN254)           // ntt_api.cu:15-16 -> ff/alt_bn128.hpp fr_t
+typedef fr256_dev<alt_bn128_fr_p> ntt_fr_t;
+#else
+# error "no FEATURE"
+#endif
+
+// The pass kernels are instantiated in their own translation units (ntt/k_ntt_pass.hip,
+// compiled once with -DSPPARK_NTT_DIF=1 and once with =0) so that the library builds in
+// parallel: for the 256-bit fields one unit with all of them takes minutes.
+#define SPPARK_NTT_PASS_SET(X, DIF, INV)                                                          \
+    X(DIF, INV, 1, 0) X(DIF, INV, 1, 1) X(DIF, INV, 2, 1) X(DIF, INV, 2, 2) X(DIF, INV, 3, 2) X(DIF, INV, 3, 3)
+#define SPPARK_NTT_PASS_SET_BIG(X, DIF, INV) X(DIF, INV, 4, 3) X(DIF, INV, 4, 4)
+#define SPPARK_NTT_PASS_ALL(X, DIF)                                                               \
+    SPPARK_NTT_PASS_SET(X, DIF, false) SPPARK_NTT_PASS_SET(X, DIF, true)
+#define SPPARK_NTT_PASS_ALL_BIG(X, DIF)                                                           \
+    SPPARK_NTT_PASS_SET_BIG(X, DIF, false) SPPARK_NTT_PASS_SET_BIG(X, DIF, true)
+}

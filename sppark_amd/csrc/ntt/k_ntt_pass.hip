@@ -1,0 +1,14 @@
+// Explicit instantiation of the NTT pass kernels for one direction of the butterfly
+// network (-DSPPARK_NTT_DIF=1: GS/DIF passes, =0: CT/DIT passes); see field_select.hpp.
+#include "field_select.hpp"
+#ifndef SPPARK_NTT_DIF
+# error "compile with -DSPPARK_NTT_DIF=0 or 1"
+#endif
+namespace sppark_amd {
+#define SPPARK_NTT_DEFINE(DIF, INV, R1, R2) \
+    template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+SPPARK_NTT_PASS_ALL(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
+#if !defined(FEATURE_BLS12_381) && !defined(FEATURE_BN254)      // wide fields stop at 6 stages per pass
+SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
+#endif
+}

@@ -76,9 +76,9 @@ class ntt_engine {
     static constexpr unsigned LG_LINE = sizeof(F) == 4 ? 5 : sizeof(F) == 8 ? 4 : 2;
     static constexpr unsigned LG_TILE = sizeof(F) == 4 ? 13 : sizeof(F) == 8 ? 12 : 10;
     // stages per pass.  For 256-bit elements hipcc keeps the 16-element arrays of a radix-16
-    // round in scratch memory (528 B/lane); fewer stages per pass avoid that but cost more
-    // passes and measured slower at 2^20..2^24 (7-14 ms vs 8 ms), so 8 stays for now.
-    static constexpr unsigned S_MAX = 8;
+    // round in scratch memory (528 B/lane) and the radix-16 instantiations dominate the
+    // library's compile time, so wide fields stop at radix-8 rounds (6 stages per pass).
+    static constexpr unsigned S_MAX = sizeof(F) > 8 ? 6 : 8;
 
     const table_set& tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
     {
@@ -130,7 +130,7 @@ public:
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
 
         unsigned smax = S_MAX;
-        if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) smax = v; }   // tuning knob
+        if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= S_MAX) smax = v; }   // tuning knob
         unsigned lgc = LG_LINE, lgt = LG_TILE;
         if (const char* e = getenv("SPPARK_NTT_LGC")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) lgc = v; }
         if (const char* e = getenv("SPPARK_NTT_LGTILE")) { unsigned v = (unsigned)atoi(e); if (v >= 8 && v <= 14) lgt = v; }
@@ -154,7 +154,8 @@ public:
                 else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, false, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);  \
                           else         hipLaunchKernelGGL((k_ntt_pass<F, false, false, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P); } \
             } while (0)
-            SPPARK_NTT_DISPATCH_S(P.S, SPPARK_NTT_LAUNCH);
+            if constexpr (S_MAX >= 8) { SPPARK_NTT_DISPATCH_S(P.S, SPPARK_NTT_LAUNCH); }
+            else                      { SPPARK_NTT_DISPATCH_S6(P.S, SPPARK_NTT_LAUNCH); }
 #undef SPPARK_NTT_LAUNCH
         }
         if (inverse && type == NTT_COSET)

@@ -290,6 +290,14 @@ void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
         case 7: CALL(4, 3); break; default: CALL(4, 4); break;          \
     }
 
+// the same for at most 6 stages per pass (wide fields)
+#define SPPARK_NTT_DISPATCH_S6(S, CALL)                                 \
+    switch (S) {                                                        \
+        case 1: CALL(1, 0); break; case 2: CALL(1, 1); break;           \
+        case 3: CALL(2, 1); break; case 4: CALL(2, 2); break;           \
+        case 5: CALL(3, 2); break; default: CALL(3, 3); break;          \
+    }
+
 // LDS elements a tile needs (with the pad words of ntt_lds_index)
 static inline size_t ntt_lds_elems(const ntt_pass& P)
 {

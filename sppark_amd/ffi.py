@@ -61,6 +61,12 @@ def load(name):
     if name in CURVES:
         L.mult_pippenger_inf.argtypes = [vp, vp, sz, vp, sz]
         L.mult_pippenger_inf.restype = _Error
+        L.mult_pippenger_fp2_inf.argtypes = [vp, vp, sz, vp, sz]
+        L.mult_pippenger_fp2_inf.restype = _Error
+        L.sppark_g2_jacobian_sum.argtypes = [vp, vp, sz]
+        L.sppark_g2_jacobian_sum.restype = None
+        L.sppark_g2_to_affine.argtypes = [vp, vp]
+        L.sppark_g2_to_affine.restype = None
         L.mult_pippenger.argtypes = [vp, vp, sz, vp]
         L.mult_pippenger.restype = _Error
         L.sppark_msm_create.argtypes = [ctypes.POINTER(vp), ci, vp]

@@ -137,6 +137,41 @@ class MsmContext:
         return out
 
 
+def multi_scalar_mult_fp2_arkworks(points, scalars, curve="bls12_381", ffi_affine_sz=None):
+    """mult_pippenger_fp2_inf (poc/msm-cuda/src/lib.rs:84-119): MSM over G2.
+
+    points : Affine_inf_t records over Fp2: X.c0|X.c1|Y.c0|Y.c1|infinity flag, stride
+             ffi_affine_sz (default 4*sizeof(fp) + 8, the arkworks G2Affine layout)
+    returns: Jacobian X|Y|Z, each an Fp2 element (288 B BLS12-381, 192 B bn254)"""
+    L = ffi.load(curve)
+    fb = FP_BYTES[curve]
+    stride = ffi_affine_sz or 4 * fb + 8
+    n = _npoints(points, stride)
+    if _nbytes(scalars) != 32 * n:
+        raise ValueError("length mismatch")
+    pp, _k1 = ffi.as_pointer(points)
+    sp, _k2 = ffi.as_pointer(scalars)
+    out = np.zeros(6 * fb, dtype=np.uint8)
+    ffi.check(L, L.mult_pippenger_fp2_inf(out.ctypes.data, pp, n, sp, stride))
+    return out
+
+
+def jacobian_sum_g2(points, curve="bls12_381"):
+    L = ffi.load(curve)
+    pts = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 6 * FP_BYTES[curve])
+    out = np.zeros(6 * FP_BYTES[curve], dtype=np.uint8)
+    L.sppark_g2_jacobian_sum(out.ctypes.data, pts.ctypes.data, pts.shape[0])
+    return out
+
+
+def to_affine_g2(jacobian, curve="bls12_381"):
+    L = ffi.load(curve)
+    j = np.ascontiguousarray(jacobian, dtype=np.uint8)
+    out = np.zeros(4 * FP_BYTES[curve], dtype=np.uint8)
+    L.sppark_g2_to_affine(out.ctypes.data, j.ctypes.data)
+    return out
+
+
 def jacobian_sum(points, curve="bls12_381"):
     """Sum of Jacobian points (host arithmetic; the multi-GPU combine step)."""
     L = ffi.load(curve)

@@ -11,6 +11,7 @@
 #include "../../sppark_amd/csrc/msm/curve_select.hpp"
 #include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
 #include "../../sppark_amd/csrc/ec/jacobian_host.hpp"
+#include "../../sppark_amd/csrc/ff/fp2_host.hpp"
 #include <vector>
 #include <algorithm>
 #include <cstring>
@@ -58,7 +59,11 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
                        const unsigned char* scalars, int mont,
                        unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs)
 {
+#ifdef SPPARK_G2                                 // the same pipeline over Fp2 (G2)
+    typedef fp2_host<curve_p::fp> fp_h;
+#else
     typedef mont_host<curve_p::fp> fp_h;
+#endif
     typedef jacobian_host<fp_h> point_t;
     point_t out; out.set_inf();
     if (npoints == 0) { memcpy(out_jac, &out, sizeof(out)); return 0; }
@@ -79,7 +84,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
     p.F = std::max(4u, F ? F : 32u);
     p.K = std::min(K ? K : 8u, p.NB);
-    const bool flagged = stride > 8 * fp_d::N;
+    const bool flagged = stride > 8 * inst_fp::N;
 
     // ---- breakdown (k_breakdown) ----
     std::vector<u32> digits((size_t)p.nwins * p.n), sorted((size_t)p.nwins * p.n);
@@ -136,30 +141,30 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         }
 
     // ---- accumulate + record levels ----
-    std::vector<bucket_m> buckets((size_t)p.nwins * p.NB);
-    memset(buckets.data(), 0, buckets.size() * sizeof(bucket_m));
+    std::vector<inst_m> buckets((size_t)p.nwins * p.NB);
+    memset(buckets.data(), 0, buckets.size() * sizeof(inst_m));
     size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win, nrecB = 2 * ((nrecA + p.F - 1) / p.F);
     std::vector<u32> keyA(nrecA), keyB(nrecB);
-    std::vector<bucket_m> ptA(nrecA), ptB(nrecB);
+    std::vector<inst_m> ptA(nrecA), ptB(nrecB);
     // the device gather may read up to the padded stride; copy points into an 8-byte aligned buffer
     std::vector<uint64_t> pts_al((npoints * stride + 15) / 8);
     memcpy(pts_al.data(), points, npoints * stride);
     const unsigned char* pts = (const unsigned char*)pts_al.data();
     for (unsigned w = 0; w < p.nwins; w++)
         for (unsigned chunk = 0; chunk < ((p.chunks_per_win + 255) / 256) * 256; chunk++) {
-            if (flagged) accumulate_chunk<fp_d, true>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
+            if (flagged) accumulate_chunk<inst_fp, true>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
                                                       sorted.data(), off.data(), p.n, p.NB, p.L, p.chunks_per_win, chunk, w);
-            else         accumulate_chunk<fp_d, false>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
+            else         accumulate_chunk<inst_fp, false>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
                                                        sorted.data(), off.data(), p.n, p.NB, p.L, p.chunks_per_win, chunk, w);
         }
     {
         size_t nrec = nrecA;
-        u32 *ik = keyA.data(), *ok = keyB.data(); bucket_m *ip = ptA.data(), *op = ptB.data();
+        u32 *ik = keyA.data(), *ok = keyB.data(); inst_m *ip = ptA.data(), *op = ptB.data();
         for (;;) {
             unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
             int last = nthreads == 1;
             for (unsigned t = 0; t < ((nthreads + 255) / 256) * 256; t++)
-                reduce_runs_chunk<fp_d>(buckets.data(), ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last, t);
+                reduce_runs_chunk<inst_fp>(buckets.data(), ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last, t);
             if (last) break;
             nrec = (size_t)2 * nthreads;
             std::swap(ik, ok); std::swap(ip, op);
@@ -168,15 +173,15 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
 
     // ---- bucket sums ----
     size_t n1 = (size_t)p.nwins * (p.NB / p.K);
-    std::vector<bucket_m> A1(n1), W1(n1), A2(n1), W2(n1);
+    std::vector<inst_m> A1(n1), W1(n1), A2(n1), W2(n1);
     unsigned nitems = p.NB / p.K;
-    for (size_t id = 0; id < n1; id++) bucket_level1_item<fp_d>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id);
+    for (size_t id = 0; id < n1; id++) bucket_level1_item<inst_fp>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id);
     unsigned lgG = lg2_floor(p.K);
-    bucket_m *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
+    inst_m *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
     while (nitems > 1) {
         unsigned Kc = std::min(p.K, nitems);
         size_t nthr = (size_t)p.nwins * (nitems / Kc);
-        for (size_t id = 0; id < nthr; id++) bucket_levelN_item<fp_d>(oa, ow, ia, iw, nitems, Kc, lgG, p.nwins, id);
+        for (size_t id = 0; id < nthr; id++) bucket_levelN_item<inst_fp>(oa, ow, ia, iw, nitems, Kc, lgG, p.nwins, id);
         nitems /= Kc; lgG += lg2_floor(Kc);
         std::swap(ia, oa); std::swap(iw, ow);
     }

@@ -69,7 +69,7 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     if (!inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)bitrev, i);
 
 #ifndef EMU_SMAX
-#define EMU_SMAX 8
+#define EMU_SMAX (sizeof(F) > 8 ? 6 : 8)        // as ntt_engine<F>::S_MAX
 #endif
     ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
     for (unsigned i = 0; i < pl.npass; i++) {

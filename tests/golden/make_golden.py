@@ -54,6 +54,82 @@ def make_msm():
     print("msm cases:", len(cases))
 
 
+# ---- G2 (coordinates in Fp2 = Fp[u]/(u^2+1)) ------------------------------------------
+# independent Python big-int group law on the twist, used for the KAT sum i*(i*G2) = 30*G2
+def fp2_mul(a, b, p): return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+def fp2_sub(a, b, p): return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
+def fp2_inv(a, p):
+    n = pow((a[0] * a[0] + a[1] * a[1]) % p, p - 2, p)
+    return (a[0] * n % p, -a[1] * n % p)
+
+
+def g2_add(P, Q, p):                                       # affine, None = infinity
+    if P is None: return Q
+    if Q is None: return P
+    if P[0] == Q[0]:
+        if P[1] != Q[1] or P[1] == (0, 0): return None
+        xx = fp2_mul(P[0], P[0], p)
+        lam = fp2_mul(((3 * xx[0]) % p, (3 * xx[1]) % p), fp2_inv(((2 * P[1][0]) % p, (2 * P[1][1]) % p), p), p)
+    else:
+        lam = fp2_mul(fp2_sub(Q[1], P[1], p), fp2_inv(fp2_sub(Q[0], P[0], p), p), p)
+    x3 = fp2_sub(fp2_sub(fp2_mul(lam, lam, p), P[0], p), Q[0], p)
+    return (x3, fp2_sub(fp2_mul(lam, fp2_sub(P[0], x3, p), p), P[1], p))
+
+
+def g2_mul(P, k, p):
+    R = None
+    while k:
+        if k & 1: R = g2_add(R, P, p)
+        P = g2_add(P, P, p); k >>= 1
+    return R
+
+
+G2_GEN = {
+    "bls12_381": ((0x024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8,
+                   0x13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e),
+                  (0x0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801,
+                   0x0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be)),
+    "bn254": ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+               11559732032986387107991004021392285783925812861821192530917403151452391805634),
+              (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+               4082367875863433681332203403145435568316851327593401208105741076214120093531)),
+}
+
+
+def g2_wire(P, p, base):
+    """affine point -> X.c0|X.c1|Y.c0|Y.c1 Montgomery limbs (R = 2^(8*base))"""
+    R = 1 << (8 * base)
+    vals = (0, 0, 0, 0) if P is None else (P[0][0], P[0][1], P[1][0], P[1][1])
+    return np.frombuffer(b"".join((v * R % p).to_bytes(base, "little") for v in vals), dtype=np.uint8)
+
+
+def make_msm_g2():
+    assert O.ref_available(), "oracle/_ref not built (needs /root/reference)"
+    cases = []
+    for curve, cname, base in ((O.BLS12_381_G2, "bls12_381", 48), (O.BN254_G2, "bn254", 32)):
+        p = O.FP_MODULUS[curve]
+        assert (O.g1_generator(curve) == g2_wire(G2_GEN[cname], p, base)).all()
+        for n, flagged in ((1, True), (2, False), (31, True), (33, True), (1000, True), (4096, False)):
+            seed = 0x5eed5eed0101 + n
+            pts, sc = recipe.msm_inputs(curve, n, seed, ndistinct=64, flagged=flagged)
+            e1 = O.ref_msm_affine(curve, pts, sc, nthreads=0)
+            e8 = O.ref_msm_affine(curve, pts, sc, nthreads=8)
+            assert (e1 == e8).all()
+            case = {"curve": cname, "n": n, "seed": seed, "flagged": flagged, "ndistinct": 64, "expect_affine": hexs(e1)}
+            if n <= 33:
+                case["points"] = hexs(pts); case["scalars"] = hexs(sc)
+            cases.append(case)
+        # KAT by the independent Python group law: sum_{i=1..4} i*(i*G2) = 30*G2
+        pts = np.stack([g2_wire(g2_mul(G2_GEN[cname], i, p), p, base) for i in range(1, 5)])
+        sc = np.stack([np.frombuffer(int(i).to_bytes(32, "little"), dtype=np.uint8) for i in range(1, 5)])
+        e = g2_wire(g2_mul(G2_GEN[cname], 30, p), p, base)
+        assert (O.ref_msm_affine(curve, pts, sc, nthreads=0) == e).all()
+        cases.append({"curve": cname, "n": 4, "kat": "30*G2 (Python big-int group law)", "points": hexs(pts),
+                      "scalars": hexs(sc), "flagged": False, "expect_affine": hexs(e)})
+    json.dump(cases, open(os.path.join(HERE, "msm_g2_golden.json"), "w"), indent=0)
+    print("msm g2 cases:", len(cases))
+
+
 # ---- independent big-int NTT (definition level) -----------------------------
 def bitrev(i, lg):
     return int(format(i, "0%db" % lg)[::-1], 2) if lg else 0
@@ -171,7 +247,12 @@ def make_lde():
 
 
 if __name__ == "__main__":
-    if "--lde-only" not in sys.argv:
+    if "--g2-only" in sys.argv:
+        make_msm_g2()
+    elif "--lde-only" in sys.argv:
+        make_lde()
+    else:
         make_msm()
+        make_msm_g2()
         make_ntt()
-    make_lde()
+        make_lde()

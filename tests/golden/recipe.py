@@ -30,9 +30,11 @@ def msm_inputs(curve, n, seed, ndistinct=64, flagged=False, edge=True):
         sc[11] = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
         # P and -P with the same scalar cancel
         p = O.FP_MODULUS[curve]
-        y = int.from_bytes(pts[1, fb:2 * fb].tobytes(), "little")
         pts[12] = pts[1]
-        pts[12, fb:2 * fb] = np.frombuffer(((p - y) % p).to_bytes(fb, "little"), dtype=np.uint8)
+        base = (p.bit_length() + 63) // 64 * 8              # bytes of one base-field element (G2: two per coordinate)
+        for o in range(fb, 2 * fb, base):
+            y = int.from_bytes(pts[1, o:o + base].tobytes(), "little")
+            pts[12, o:o + base] = np.frombuffer(((p - y) % p).to_bytes(base, "little"), dtype=np.uint8)
         sc[12] = sc[1]
     return pts, sc
 

@@ -24,7 +24,7 @@ def test_header_symbols_exported(libs):
     assert "mult_pippenger_inf" in syms and "compute_ntt" in syms and "cuda_available" in syms
     common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message", "cuda_func",
               "sppark_gpu_ptr_alloc", "sppark_gpu_ptr_get"}
-    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1")}
+    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1") or s.startswith("sppark_g2")}
     ntt_only = {"compute_ntt", "sppark_ntt", "sppark_lde", "sppark_lde_powers", "sppark_lde_expand"}
     assert set(syms) == common | msm_only | ntt_only
     for name, path in libs.items():

@@ -18,8 +18,8 @@ EMU = os.path.join(HERE, "emu")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-def _emu(feature):
-    so = os.path.join(EMU, "libemu_%s.so" % feature)
+def _emu(feature, g2=False):
+    so = os.path.join(EMU, "libemu_%s%s.so" % (feature, "_G2" if g2 else ""))
     src = os.path.join(EMU, "emu_msm.cpp")
     csrc = os.path.join(os.path.dirname(HERE), "sppark_amd", "csrc")
     newest = max(os.stat(os.path.join(r, f)).st_mtime for r, _, fs in os.walk(csrc) for f in fs)
@@ -28,7 +28,7 @@ def _emu(feature):
         if not os.path.exists(HIPCC):
             pytest.skip("hipcc not available")
         subprocess.check_call([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
-                               "-DFEATURE_" + feature, "-o", so, src])
+                               "-DFEATURE_" + feature] + (["-DSPPARK_G2"] if g2 else []) + ["-o", so, src])
     L = ctypes.CDLL(so)
     vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
     L.emu_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
@@ -76,6 +76,28 @@ def test_msm_pipeline_on_host(oracle, curve):
         out = np.zeros(3 * fb, dtype=np.uint8)
         L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
+
+
+@pytest.mark.parametrize("curve", [2, 3])
+def test_msm_g2_pipeline_on_host(oracle, curve):
+    """the same kernel bodies instantiated over Fp2 (fp2_dev.hpp): G2 MSM on the host"""
+    O = oracle
+    L = _emu("BLS12_381" if curve == 2 else "BN254", g2=True)
+    fb = O.FP_BYTES[curve]
+    for n, wb, LL, F, K, ns, flagged in ((1, 0, 0, 0, 0, 0, True), (33, 0, 0, 0, 0, 0, False), (600, 0, 0, 0, 0, 0, True),
+                                         (500, 7, 4, 4, 2, 3, False), (300, 11, 16, 8, 4, 2, True)):
+        pts, sc = recipe.msm_inputs(curve, n, 4321 + n + wb, flagged=flagged)
+        out = np.zeros(3 * fb, dtype=np.uint8)
+        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns)
+        assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
+    # all points equal (doubling branch) and all scalars equal
+    pts, sc = recipe.msm_inputs(curve, 400, 5, edge=False, flagged=True)
+    same = pts.copy(); same[:] = pts[0]
+    s_eq = sc.copy(); s_eq[:] = sc[0]
+    for p_, s_ in ((same, sc), (pts, s_eq)):
+        out = np.zeros(3 * fb, dtype=np.uint8)
+        L.emu_msm(P(out), P(p_), p_.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2)
+        assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, p_, s_, algo=0, param=4)).all()
 
 
 def test_msm_skewed_scalars_on_host(oracle):

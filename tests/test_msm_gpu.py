@@ -304,3 +304,91 @@ def test_go_bridge_smoke_and_gpu_ptr(libs):
     L.drop_gpu_ptr_t(ctypes.byref(a))
     assert a.value is None and L.sppark_gpu_ptr_get(ctypes.byref(b))      # still alive through the clone
     L.drop_gpu_ptr_t(ctypes.byref(b))
+
+
+# ------------------------------------------------------------------- G2 --------
+G2 = [("bls12_381", 2), ("bn254", 3)]
+
+
+def test_msm_g2_golden_vectors(oracle, libs):
+    """mult_pippenger_fp2_inf against the vectors produced by the reference's own templates
+    over Fp2 and the 30*G2 KAT of an independent Python group law."""
+    import sppark_amd
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "msm_g2_golden.json"))):
+        curve = O.BLS12_381_G2 if c["curve"] == "bls12_381" else O.BN254_G2
+        fb = O.FP_BYTES[curve]
+        stride = 2 * fb + 8 if c["flagged"] else 2 * fb
+        if "points" in c:
+            pts = np.frombuffer(bytes.fromhex(c["points"]), dtype=np.uint8).reshape(c["n"], stride).copy()
+            sc = np.frombuffer(bytes.fromhex(c["scalars"]), dtype=np.uint8).reshape(c["n"], 32).copy()
+        else:
+            pts, sc = recipe.msm_inputs(curve, c["n"], c["seed"], c["ndistinct"], c["flagged"])
+        exp = np.frombuffer(bytes.fromhex(c["expect_affine"]), dtype=np.uint8)
+        out = sppark_amd.multi_scalar_mult_fp2_arkworks(pts, sc, c["curve"], ffi_affine_sz=stride)
+        assert (sppark_amd.to_affine_g2(out, c["curve"]) == exp).all(), (c["curve"], c["n"])
+        assert (O.jac_to_affine(curve, out) == exp).all()
+
+
+@pytest.mark.parametrize("name,curve", G2)
+@pytest.mark.parametrize("n", [1, 3, 64, 65, 1000, 4097, 1 << 14])
+def test_msm_g2_vs_oracle(oracle, libs, name, curve, n):
+    """the shape of poc/msm-cuda/tests/msm.rs:41-63 (G2 against a CPU MSM) + ragged sizes"""
+    import sppark_amd
+    O = oracle
+    pts, sc = recipe.msm_inputs(curve, n, 4242 + n, ndistinct=512, flagged=True)
+    out = sppark_amd.multi_scalar_mult_fp2_arkworks(pts, sc, name)
+    assert (sppark_amd.to_affine_g2(out, name) == O.msm_affine(curve, pts, sc, algo=0, param=8)).all(), (name, n)
+
+
+def test_msm_g2_edge_cases(oracle, libs):
+    import torch
+    import sppark_amd
+    O = oracle
+    curve, name = O.BLS12_381_G2, "bls12_381"
+    n = 2000
+    pts, sc = recipe.msm_inputs(curve, n, 606, ndistinct=128, flagged=True)
+    # empty / all infinity / all-zero scalars
+    assert (sppark_amd.multi_scalar_mult_fp2_arkworks(pts[:0], sc[:0], name)[192:] == 0).all()
+    inf = pts.copy(); inf[:, 192] = 1
+    assert (sppark_amd.multi_scalar_mult_fp2_arkworks(inf, sc, name)[192:] == 0).all()
+    assert (sppark_amd.multi_scalar_mult_fp2_arkworks(pts, np.zeros_like(sc), name)[192:] == 0).all()
+    # skew: all scalars equal, all points equal (doubling path), device-resident inputs
+    s_eq = sc.copy(); s_eq[:] = sc[0]
+    same = pts.copy(); same[:] = pts[0]
+    for p_, s_ in ((pts, s_eq), (same, sc), (same, s_eq)):
+        out = sppark_amd.multi_scalar_mult_fp2_arkworks(p_, s_, name)
+        assert (sppark_amd.to_affine_g2(out, name) == O.msm_affine(curve, p_, s_, algo=0, param=8)).all()
+    out = sppark_amd.multi_scalar_mult_fp2_arkworks(torch.from_numpy(pts).cuda(), torch.from_numpy(sc).cuda(), name)
+    exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
+    assert (sppark_amd.to_affine_g2(out, name) == exp).all()
+    # host combine helper: sum of two halves == whole
+    a = sppark_amd.multi_scalar_mult_fp2_arkworks(pts[:n // 2], sc[:n // 2], name)
+    b = sppark_amd.multi_scalar_mult_fp2_arkworks(pts[n // 2:], sc[n // 2:], name)
+    assert (sppark_amd.to_affine_g2(sppark_amd.jacobian_sum_g2(np.stack([a, b]), name), name) == exp).all()
+
+
+def test_msm_g2_large_linearity(oracle, libs):
+    """2^18 G2 points: MSM(P, a) + MSM(P, b) == MSM(P, a + b mod r); the 2^12 prefix equals the oracle."""
+    import sppark_amd
+    O = oracle
+    curve, name = O.BN254_G2, "bn254"
+    n = 1 << 18
+    base, sc = recipe.msm_inputs(curve, 1 << 12, 99, ndistinct=1024, flagged=True, edge=False)
+    pts = base[np.arange(n) % base.shape[0]]
+    rng = np.random.default_rng(17)
+    r = O.FR_MODULUS[curve]
+    a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); a[:, 31] &= 0x1f
+    b = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); b[:, 31] &= 0x0f
+    ai = a.view(np.uint64).astype(object); bi = b.view(np.uint64).astype(object)
+    c = np.zeros_like(a)
+    for i in range(n):
+        va = sum(int(ai[i, k]) << (64 * k) for k in range(4)); vb = sum(int(bi[i, k]) << (64 * k) for k in range(4))
+        c[i] = np.frombuffer(((va + vb) % r).to_bytes(32, "little"), dtype=np.uint8)
+    A = sppark_amd.multi_scalar_mult_fp2_arkworks(pts, a, name)
+    B = sppark_amd.multi_scalar_mult_fp2_arkworks(pts, b, name)
+    C = sppark_amd.multi_scalar_mult_fp2_arkworks(pts, c, name)
+    assert (sppark_amd.to_affine_g2(sppark_amd.jacobian_sum_g2(np.stack([A, B]), name), name) == sppark_amd.to_affine_g2(C, name)).all()
+    m = 1 << 12
+    out = sppark_amd.multi_scalar_mult_fp2_arkworks(pts[:m], a[:m], name)
+    assert (sppark_amd.to_affine_g2(out, name) == O.msm_affine(curve, pts[:m], a[:m], algo=0, param=8)).all()

@@ -107,6 +107,36 @@ def test_msm_vs_reference_build(oracle):
         assert (O.msm_affine(curve, pts, mont, mont=True) == O.msm_affine(curve, pts, sc)).all()
 
 
+def test_msm_g2_golden_and_reference_build(oracle):
+    """G2 (coordinates in Fp2): the restatement against (i) the committed vectors produced by the
+    reference's own templates instantiated over Fp2 (+ the 30*G2 KAT computed by an independent
+    Python big-int group law), (ii) the reference build itself on fresh inputs, (iii) itself
+    through the naive and the signed-window algorithms."""
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "msm_g2_golden.json"))):
+        curve = O.BLS12_381_G2 if c["curve"] == "bls12_381" else O.BN254_G2
+        fb = O.FP_BYTES[curve]
+        stride = 2 * fb + 8 if c["flagged"] else 2 * fb
+        if "points" in c:
+            pts = np.frombuffer(bytes.fromhex(c["points"]), dtype=np.uint8).reshape(c["n"], stride).copy()
+            sc = np.frombuffer(bytes.fromhex(c["scalars"]), dtype=np.uint8).reshape(c["n"], 32).copy()
+        else:
+            pts, sc = recipe.msm_inputs(curve, c["n"], c["seed"], c["ndistinct"], c["flagged"])
+        exp = np.frombuffer(bytes.fromhex(c["expect_affine"]), dtype=np.uint8)
+        assert (O.msm_affine(curve, pts, sc, algo=0, param=0) == exp).all(), (c["curve"], c["n"])
+        if c["n"] <= 1000:
+            assert (O.msm_affine(curve, pts, sc, algo=2, param=7) == exp).all()
+        if c["n"] <= 33:
+            assert (O.msm_affine(curve, pts, sc, algo=1) == exp).all()
+    for curve in (O.BLS12_381_G2, O.BN254_G2):
+        g = O.g1_generator(curve)
+        assert O.g1_on_curve(curve, g)
+        if O.ref_available():
+            for n, thr in ((5, 0), (100, 3), (300, 8)):
+                pts, sc = recipe.msm_inputs(curve, n, 199 + n, flagged=True)
+                assert (O.ref_msm_affine(curve, pts, sc, thr) == O.msm_affine(curve, pts, sc, algo=0, param=thr)).all()
+
+
 def test_msm_empty(oracle):
     O = oracle
     out = O.msm(O.BLS12_381, np.zeros((0, 96), dtype=np.uint8), np.zeros((0, 32), dtype=np.uint8))

@@ -1,0 +1,14 @@
+"""Run the Goldilocks/BabyBear forward NR NTT a few times at 2^LG (for profiling)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, sppark_amd
+from sppark_amd import NTTInputOutputOrder as Ord
+field = sys.argv[1] if len(sys.argv) > 1 else "gl64"
+lg = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+dt = torch.int64 if field == "gl64" else torch.int32
+x = torch.randint(0, 2**30, (1 << lg,), dtype=dt, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(reps):
+    sppark_amd.NTT(0, x, Ord.NR, field, stream=s)
+torch.cuda.synchronize()

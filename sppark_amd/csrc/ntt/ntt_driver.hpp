@@ -101,6 +101,9 @@ class ntt_engine {
         hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.lo, t.hi, t.inner, H::wire(w), lg, t.h);
         hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.glo, t.ghi, (F*)nullptr, H::wire(g), lg, t.h);
         HIP_OK(hipGetLastError());
+        // one-time: the tables are shared by every later call on ANY stream, so they must be
+        // complete before another thread can find them in the cache
+        HIP_OK(hipStreamSynchronize(stream));
         return cache.emplace(key, t).first->second;
     }
 

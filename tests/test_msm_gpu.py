@@ -392,3 +392,44 @@ def test_msm_g2_large_linearity(oracle, libs):
     m = 1 << 12
     out = sppark_amd.multi_scalar_mult_fp2_arkworks(pts[:m], a[:m], name)
     assert (sppark_amd.to_affine_g2(out, name) == O.msm_affine(curve, pts[:m], a[:m], algo=0, param=8)).all()
+
+
+def test_concurrent_contexts_and_ntt(oracle, libs):
+    """Calls are synchronous but independent contexts may run concurrently (the reference is NOT
+    safe for concurrent MSMs on one GPU: device-global work counters, SURVEY 8(b) threading note;
+    here every context owns its scratch and stream).  Three host threads: two MSM contexts of
+    different curves and an NTT, repeated; every result must equal the oracle's."""
+    import threading
+    import sppark_amd
+    from sppark_amd import NTTInputOutputOrder as Ord
+    O = oracle
+    jobs = []
+    for curve, name, n, seed in ((O.BLS12_381, "bls12_381", 6000, 1), (O.BLS12_381, "bls12_381", 3000, 2), (O.BN254, "bn254", 5000, 3)):
+        pts, sc = recipe.msm_inputs(curve, n, 900 + seed, ndistinct=256)
+        jobs.append((curve, name, pts, sc, O.msm_affine(curve, pts, sc, algo=0, param=8)))
+    x = recipe.ntt_input("gl64", 16, 5)
+    x_exp = O.ntt_gl64(x, O.NR, O.FORWARD, O.STANDARD)
+    errors = []
+
+    def msm_worker(curve, name, pts, sc, exp):
+        try:
+            ctx = sppark_amd.MsmContext(name)
+            for _ in range(6):
+                if not (sppark_amd.to_affine(ctx.invoke(pts, sc), name) == exp).all():
+                    errors.append(("msm", name))
+            ctx.close()
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("msm", name, repr(e)))
+
+    def ntt_worker():
+        try:
+            for _ in range(20):
+                if not (sppark_amd.NTT(0, x.copy(), Ord.NR, "gl64") == x_exp).all():
+                    errors.append(("ntt",))
+        except Exception as e:                      # noqa: BLE001
+            errors.append(("ntt", repr(e)))
+
+    threads = [threading.Thread(target=msm_worker, args=j) for j in jobs] + [threading.Thread(target=ntt_worker)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors

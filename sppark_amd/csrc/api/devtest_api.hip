@@ -32,13 +32,13 @@ __global__ void k_field_op(u32* out, const u32* a, const u32* b, unsigned n, int
 }
 
 // op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
-__global__ void k_xyzz_op(bucket_m* out, const bucket_m* a, const unsigned char* b, unsigned n, int op)
+__global__ void k_xyzz_op(wire_bucket_m* out, const wire_bucket_m* a, const unsigned char* b, unsigned n, int op)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    bucket_d p = bucket_d::load(&a[i]);
+    wire_bucket_d p = wire_bucket_d::load(&a[i]);
     if (op == 0) {
-        p.add(bucket_d::load(reinterpret_cast<const bucket_m*>(b) + i));
+        p.add(wire_bucket_d::load(reinterpret_cast<const wire_bucket_m*>(b) + i));
     } else if (op == 3) {
         p.dbl();
     } else {
@@ -83,8 +83,8 @@ SPPARK_FFI RustError sppark_devtest_xyzz_op(int op, void* out, const void* a, co
 {
     return guarded([&] {
         (void)select_gpu(-1);
-        size_t ab = n * sizeof(bucket_m), bb = n * (op == 0 ? sizeof(bucket_m) : 8 * fp_d::N);
-        bucket_m *d_a, *d_o; unsigned char* d_b;
+        size_t ab = n * sizeof(wire_bucket_m), bb = n * (op == 0 ? sizeof(wire_bucket_m) : 8 * fp_d::N);
+        wire_bucket_m *d_a, *d_o; unsigned char* d_b;
         HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_o, ab)); HIP_OK(hipMalloc((void**)&d_b, bb ? bb : 16));
         HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice));
         if (op != 3) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
@@ -229,9 +229,9 @@ __global__ void k_fieldbench(int op, int iters, u32* io)
         }
         if (x.is_zero()) io[0] = 1;
     } else {
-        bucket_d p; p.X = x; p.Y = y; p.ZZ = y; p.ZZZ = x;
+        wire_bucket_d p; p.X = x; p.Y = y; p.ZZ = y; p.ZZZ = x;
         affine_dev<fp_d> q; q.X = y; q.Y = x; q.inf = false;
-        bucket_d r = p; r.X = y;
+        wire_bucket_d r = p; r.X = y;
         for (int it = 0; it < iters; it++) {
             if (op == 3) p.madd(q, it & 1); else p.add(r);
         }

@@ -9,14 +9,14 @@
 // the big kernels are instantiated in their own translation units
 // (msm/k_accumulate.hip, k_reduce.hip, k_bucket1.hip, k_bucketN.hip)
 namespace sppark_amd {
-extern template __global__ void k_accumulate<fp_d, false>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
+extern template __global__ void k_accumulate<msm_fp_d, false>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
-extern template __global__ void k_accumulate<fp_d, true>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
+extern template __global__ void k_accumulate<msm_fp_d, true>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
-extern template __global__ void k_reduce_runs<fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
+extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                     unsigned, unsigned, unsigned, int);
-extern template __global__ void k_bucket_level1<fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
-extern template __global__ void k_bucket_levelN<fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
+extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
 // ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)
 extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
@@ -36,7 +36,7 @@ extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, c
 
 using namespace sppark_amd;
 
-typedef msm_t<fp_d, mont_host<curve_p::fp>, curve_p::fr> msm_impl;
+typedef msm_t<msm_fp_d, mont_host<curve_p::fp>, curve_p::fr> msm_impl;
 typedef msm_impl::point_t point_t;
 typedef msm_impl::fp_h fp_h;
 typedef msm_t<fp2_d, fp2_host<curve_p::fp>, curve_p::fr> msm2_impl;       // G2
@@ -186,7 +186,7 @@ __device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 j)
 }
 
 __global__ __launch_bounds__(64)
-void k_generate(bucket_m* out, unsigned n, u64 seed)
+void k_generate(wire_bucket_m* out, unsigned n, u64 seed)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -218,7 +218,7 @@ SPPARK_FFI RustError sppark_g1_generate(void* out, size_t stride, size_t n, uint
     return guarded([&] {
         if (n == 0) return;
         (void)select_gpu(-1);
-        typedef bucket_m bucket_t;
+        typedef wire_bucket_m bucket_t;
         bucket_t* d_pts;
         HIP_OK(hipMalloc((void**)&d_pts, n * sizeof(bucket_t)));
         hipLaunchKernelGGL(k_generate, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_pts, (unsigned)n, seed);

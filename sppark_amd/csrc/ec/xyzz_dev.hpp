@@ -26,24 +26,30 @@ template<class F> struct affine_dev {
 
 // Load one affine point.  |stride| bytes between points; FLAGGED selects the
 // Affine_inf_t wire format.  Limbs are fetched as 8-byte words so that the
-// 104-byte arkworks stride (8-byte aligned only) is legal.
+// 104-byte arkworks stride (8-byte aligned only) is legal.  affine_loader<F> is
+// the customisation point (ec/xyzzx_dev.hpp loads pre-converted records instead).
+template<class F> struct affine_loader {
+    template<bool FLAGGED>
+    SPPARK_DEVFN static affine_dev<F> load(const unsigned char* base, size_t idx, unsigned stride)
+    {
+        constexpr int N = F::N;
+        const unsigned char* p = base + idx * (size_t)stride;
+        const uint2* q = reinterpret_cast<const uint2*>(p);
+        u32 wx[N], wy[N];
+        #pragma unroll
+        for (int i = 0; i < N / 2; i++) { uint2 w = q[i]; wx[2*i] = w.x; wx[2*i+1] = w.y; }
+        #pragma unroll
+        for (int i = 0; i < N / 2; i++) { uint2 w = q[N/2 + i]; wy[2*i] = w.x; wy[2*i+1] = w.y; }
+        affine_dev<F> a;
+        a.X = F::from_wire(wx); a.Y = F::from_wire(wy);
+        if (FLAGGED) a.inf = (p[2 * N * 4] & 1) != 0;
+        else         a.inf = a.X.is_zero() & a.Y.is_zero();
+        return a;
+    }
+};
 template<class F, bool FLAGGED>
 SPPARK_DEVFN affine_dev<F> load_affine(const unsigned char* base, size_t idx, unsigned stride)
-{
-    constexpr int N = F::N;
-    const unsigned char* p = base + idx * (size_t)stride;
-    const uint2* q = reinterpret_cast<const uint2*>(p);
-    u32 wx[N], wy[N];
-    #pragma unroll
-    for (int i = 0; i < N / 2; i++) { uint2 w = q[i]; wx[2*i] = w.x; wx[2*i+1] = w.y; }
-    #pragma unroll
-    for (int i = 0; i < N / 2; i++) { uint2 w = q[N/2 + i]; wy[2*i] = w.x; wy[2*i+1] = w.y; }
-    affine_dev<F> a;
-    a.X = F::from_wire(wx); a.Y = F::from_wire(wy);
-    if (FLAGGED) a.inf = (p[2 * N * 4] & 1) != 0;
-    else         a.inf = a.X.is_zero() & a.Y.is_zero();
-    return a;
-}
+{   return affine_loader<F>::template load<FLAGGED>(base, idx, stride);   }
 
 // Memory image of a bucket: X | Y | ZZZ | ZZ in the wire format (32-bit limbs),
 // i.e. the reference's xyzz_t layout (ec/xyzz_t.hpp:17), whatever limb size the

@@ -1,0 +1,202 @@
+// xyzz_dev / affine loading specialised for the loosely-reduced field (ff/montx_dev.hpp).
+// Same formulas as ec/xyzz_dev.hpp (madd-2008-s, add-2008-s, dbl-2008-s-1, the ones
+// ec/xyzz_t.hpp:117-200,351-429 uses); what changes is the bookkeeping:
+//
+//   value bounds, in multiples of p (rho = 2^RBITS / p ~ 2500; a product of a < ka*p and
+//   b < kb*p is < (ka*kb/rho + 1)*p < 2p for every pair below), and limb sizes
+//   ("n" = normalised, limbs < 2^LB; otherwise the stated multiple of 2^LB):
+//
+//     X   < 10p, limbs <= 5*2^LB        Y   < 5p, limbs <= 3*2^LB
+//     ZZ, ZZZ  < 2p, n                  infinity: every limb of ZZ (and ZZZ) is zero
+//     affine input coordinates: < 2p, n
+//
+//   These hold for every value written to memory, so any kernel can load any bucket.
+//   sub<K, B>(a, b) = a + K*p - b needs b < (K-1)*p and b's limbs <= B*(2^LB - 1);
+//   operator* needs its right operand n and its left operand's limbs < 2^31; sqr() needs n.
+#pragma once
+#include "../ff/montx_dev.hpp"
+#include "xyzz_dev.hpp"
+
+namespace sppark_amd {
+
+// Points converted once per MSM into X | Y internal limbs (2*NL words, 16-byte aligned
+// stride); the infinity flag rides in bit 31 of X's top limb (a value < 2p leaves it free).
+template<class P, int LB> struct affine_loader<montx_dev<P, LB>> {
+    typedef montx_dev<P, LB> F;
+    static constexpr unsigned STRIDE = ((2 * F::NL * 4 + 15) / 16) * 16;
+    template<bool FLAGGED>
+    SPPARK_DEVFN static affine_dev<F> load(const unsigned char* base, size_t idx, unsigned)
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(base + idx * (size_t)STRIDE);
+        u32 w[STRIDE / 4];
+        #pragma unroll
+        for (unsigned i = 0; i < STRIDE / 16; i++) { uint4 v = q[i]; w[4*i] = v.x; w[4*i+1] = v.y; w[4*i+2] = v.z; w[4*i+3] = v.w; }
+        affine_dev<F> a;
+        a.X = F::from_wire(w); a.Y = F::from_wire(w + F::NL);
+        a.inf = (a.X.l[F::NL - 1] >> 31) != 0;
+        a.X.l[F::NL - 1] &= 0x7fffffffu;
+        return a;
+    }
+    // one work item of the conversion pass: standard wire point -> internal record
+    template<bool FLAGGED>
+    SPPARK_DEVFN static void convert(unsigned char* dst, const unsigned char* src, size_t idx, unsigned stride)
+    {
+        typedef mont_dev<P> S;
+        affine_dev<S> p = affine_loader<S>::template load<FLAGGED>(src, idx, stride);
+        u32 wx[S::N], wy[S::N];
+        p.X.to_wire(wx); p.Y.to_wire(wy);
+        F x = F::from_std(wx), y = F::from_std(wy);
+        u32 w[STRIDE / 4] = {};
+        x.to_wire(w); y.to_wire(w + F::NL);
+        if (p.inf) w[F::NL - 1] |= 0x80000000u;
+        uint4* q = reinterpret_cast<uint4*>(dst + idx * (size_t)STRIDE);
+        #pragma unroll
+        for (unsigned i = 0; i < STRIDE / 16; i++) q[i] = make_uint4(w[4*i], w[4*i+1], w[4*i+2], w[4*i+3]);
+    }
+};
+
+template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
+    typedef montx_dev<P, LB> F;
+    F X, Y, ZZZ, ZZ;
+
+    SPPARK_DEVFN bool is_inf() const { return ZZ.limbs_all_zero(); }
+    SPPARK_DEVFN void set_inf() { X = F::zero(); Y = F::zero(); ZZZ = F::zero(); ZZ = F::zero(); }
+
+    SPPARK_DEVFN void set(const affine_dev<F>& p, bool negate)
+    {
+        if (p.inf) { set_inf(); return; }
+        X = p.X; Y = negate ? F::template neg<3>(p.Y) : p.Y;           // < 3p, limbs <= 2*2^LB
+        ZZZ = F::one(); ZZ = F::one();
+    }
+
+    SPPARK_DEVFN void madd(const affine_dev<F>& p, bool negate)
+    {
+        if (p.inf) return;
+        if (is_inf()) { set(p, negate); return; }
+
+        F U2, S2;
+        F::mul2(U2, S2, p.X, ZZ, p.Y, ZZZ);                 // n, < 2p (pairs of products are interleaved)
+        if (negate) S2 = F::template neg<3>(S2);            // < 3p, limbs <= 2*2^LB
+        F Pd = F::template sub<11, 6>(U2, X).norm();        // U2 - X      < 13p, n
+        F Rd = F::template sub<6, 4>(S2, Y).norm();         // +-S2 - Y    < 9p, n
+
+        if (!Pd.template is_zero_mod<13>()) {               // fast path
+            F PP, RR, PPP, Q, M1, M2;
+            F::sqr2(PP, RR, Pd, Rd);                        // n, < 2p
+            F::mul2(PPP, Q, Pd, PP, X, PP);                 // left operand of the second one fat: allowed
+            F T   = PPP + Q + Q;                            // < 6p, limbs <= 3*(2^LB - 1)
+            F X3  = F::template sub<8, 3>(RR, T);           // < 10p, limbs <= 5*2^LB
+            F D   = F::template sub<11, 6>(Q, X3);          // Q - X3      < 13p, limbs < 2^31
+            F::mul2(M1, M2, D, Rd, Y, PPP);
+            Y   = F::template sub<3>(M1, M2);               // < 5p, limbs <= 3*2^LB
+            F::mul2(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);
+            X = X3;
+        } else if (Rd.template is_zero_mod<9>()) {          // same point: 2*p
+            F y2 = negate ? F::template neg<3>(p.Y).norm() : p.Y;       // n, < 3p
+            dbl_affine(p.X, y2);
+        } else {
+            set_inf();
+        }
+    }
+
+    SPPARK_DEVFN void add(const xyzz_dev& q)
+    {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+
+        F U1, S1, U2, S2;
+        F::mul2(U1, S1, X, q.ZZ, Y, q.ZZZ);                 // n, < 2p
+        F::mul2(U2, S2, q.X, ZZ, q.Y, ZZZ);
+        F Pd = F::template sub<3>(U2, U1).norm();           // < 5p, n
+        F Rd = F::template sub<3>(S2, S1).norm();
+
+        if (!Pd.template is_zero_mod<5>()) {
+            F PP, RR, PPP, Q, M1, M2;
+            F::sqr2(PP, RR, Pd, Rd);
+            F::mul2(PPP, Q, Pd, PP, U1, PP);
+            F T   = PPP + Q + Q;
+            F X3  = F::template sub<8, 3>(RR, T);
+            F D   = F::template sub<11, 6>(Q, X3);
+            F::mul2(M1, M2, D, Rd, S1, PPP);
+            Y   = F::template sub<3>(M1, M2);
+            F::mul2(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);
+            F::mul2(ZZ, ZZZ, ZZ, q.ZZ, ZZZ, q.ZZZ);
+            X = X3;
+        } else if (Rd.template is_zero_mod<5>()) {
+            dbl();
+        } else {
+            set_inf();
+        }
+    }
+
+    SPPARK_DEVFN void dbl()
+    {
+        if (is_inf()) return;
+        F Yn = Y.norm(), Xn = X.norm();                     // n, < 5p / < 10p
+        F U = (Yn + Yn).norm();                             // < 10p
+        F V = U.sqr();                                      // < 2p
+        F W = U * V;
+        F S = Xn * V;
+        F M = Xn.sqr();
+        F M3 = (M + M + M).norm();                          // < 6p
+        F X3 = F::template sub<5, 2>(M3.sqr(), S + S);      // < 7p, limbs <= 4*2^LB
+        F D  = F::template sub<8, 4>(S, X3);                // < 10p
+        Y = F::template sub<3>(D * M3, W * Yn);
+        ZZ = ZZ * V; ZZZ = ZZZ * W;
+        X = X3;
+    }
+
+    typedef xyzz_mem<F::N> mem_t;
+
+    SPPARK_DEVFN void store(mem_t* dst) const
+    {
+        constexpr int N = F::N;
+        u32 s[4 * N];
+        X.to_wire(s); Y.to_wire(s + N); ZZZ.to_wire(s + 2 * N); ZZ.to_wire(s + 3 * N);
+        uint4* d = reinterpret_cast<uint4*>(dst);
+        #pragma unroll
+        for (int i = 0; i < N; i++) d[i] = make_uint4(s[4*i], s[4*i+1], s[4*i+2], s[4*i+3]);
+    }
+    SPPARK_DEVFN static xyzz_dev load(const mem_t* src)
+    {
+        constexpr int N = F::N;
+        u32 d[4 * N];
+        const uint4* q = reinterpret_cast<const uint4*>(src);
+        #pragma unroll
+        for (int i = 0; i < N; i++) { uint4 w = q[i]; d[4*i] = w.x; d[4*i+1] = w.y; d[4*i+2] = w.z; d[4*i+3] = w.w; }
+        xyzz_dev r;
+        r.X = F::from_wire(d); r.Y = F::from_wire(d + N); r.ZZZ = F::from_wire(d + 2 * N); r.ZZ = F::from_wire(d + 3 * N);
+        return r;
+    }
+
+    // internal XYZZ -> the reference's image in the standard wire form (ec/xyzz_t.hpp:17),
+    // canonical coordinates; infinity stays all-zero
+    SPPARK_DEVFN void store_std(xyzz_mem<P::N>* dst) const
+    {
+        constexpr int N = P::N;
+        u32 s[4 * N];
+        if (is_inf()) { for (int i = 0; i < 4 * N; i++) s[i] = 0; }
+        else { X.to_std(s); Y.to_std(s + N); ZZZ.to_std(s + 2 * N); ZZ.to_std(s + 3 * N); }
+        uint4* d = reinterpret_cast<uint4*>(dst);
+        #pragma unroll
+        for (int i = 0; i < N; i++) d[i] = make_uint4(s[4*i], s[4*i+1], s[4*i+2], s[4*i+3]);
+    }
+
+private:
+    // this = 2 * (x, y)   (mdbl-2008-s-1); x, y n with x < 2p, y < 3p
+    SPPARK_DEVFN void dbl_affine(const F& x, const F& y)
+    {
+        F U = (y + y).norm();                               // < 6p
+        F V = U.sqr();
+        F W = U * V;
+        F S = x * V;
+        F M = x.sqr();
+        F M3 = (M + M + M).norm();
+        F X3 = F::template sub<5, 2>(M3.sqr(), S + S);
+        F D  = F::template sub<8, 4>(S, X3);
+        Y = F::template sub<3>(D * M3, W * y);
+        X = X3; ZZ = V; ZZZ = W;
+    }
+};
+
+} // namespace sppark_amd

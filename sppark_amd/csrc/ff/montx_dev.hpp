@@ -1,0 +1,375 @@
+// Loosely-reduced, reduced-radix Montgomery field for the MSM bucket kernels (gfx950).
+//
+// Every VALU instruction of a wave64 costs one quad-cycle on CDNA4 (64-bit shifts/adds two),
+// so the currency is the instruction COUNT.  With full 32-bit limbs (mont_dev.hpp) a 12-limb
+// product is 288 mads + 288 carry adds + bookkeeping = ~680 instructions and a modular
+// add/sub ~50.  Here (LB = 28 for a 381-bit modulus: NL = 14 limbs):
+//
+//   * a partial product of normalised limbs is < 2^56 and a whole column of a*b AND m*p
+//     products (28 of them) fits ONE 64-bit accumulator: a column is a pure chain of
+//     v_mad_u64_u32, no carry instructions; between columns the accumulator moves down by
+//     LB bits with two 32-bit instructions;
+//   * the Montgomery radix is 2^(LB*NL) = 2^392, a factor ~2500 above the modulus: values
+//     are only loosely reduced.  A product of inputs < ka*p and < kb*p is
+//     < (ka*kb*p/R + 1)*p; a + b adds the bounds; a - b is a + K*p - b where K*p is written
+//     with "fat" limbs that dominate b's limbs one by one.  No conditional subtraction and
+//     no carry chain on the fast path of a point addition;
+//   * the head-room inside the accumulator (2^64 / (28 * 2^56) = 2^3.2) lets ONE operand of
+//     a product be un-normalised (limbs < 2^30, i.e. the direct result of one lazy add/sub);
+//     norm() (3 instructions per limb) is needed only before squaring such a value or
+//     multiplying two of them.
+//
+// Montgomery domain: x is held as x * 2^(LB*NL) mod p; the reference's wire form is
+// x * 2^(32*N) (ff/bls12-381.hpp:13-33).  from_std()/to_std() convert (one product each).
+// The limb/value bounds are the caller's contract and are stated at every use in
+// ec/xyzzx_dev.hpp.
+#pragma once
+#include "mont_dev.hpp"
+
+namespace sppark_amd {
+
+// acc += a * b (64-bit accumulate; the carry-out is architecturally written but never set: the
+// column bound keeps acc below 2^64).  Inline asm because hipcc, given the C expression,
+// (i) strength-reduces products by the modulus limbs into shift/add sequences and (ii) splits
+// long accumulation chains and re-joins them with 64-bit adds -- both cost more than they save
+// (measured: 6.0e9 vs 7.1e9 mixed additions/s).  b in a VGPR / in an SGPR (modulus limbs).
+SPPARK_DEVFN void macx(u64& acc, u32 a, u32 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+#else
+    acc += (u64)a * b;
+#endif
+}
+SPPARK_DEVFN void macxs(u64& acc, u32 a, u32 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(b) : "vcc");
+#else
+    acc += (u64)a * b;
+#endif
+}
+SPPARK_DEVFN u32 opaque_sgpr(u32 c) { return c; }
+
+#define SPPARK_MODULUS_SGPRS u32 pl[NL]; _Pragma("unroll") for (int j_ = 0; j_ < NL; j_++) pl[j_] = opaque_sgpr(mod_limb(j_))
+
+template<class P, int LB> struct montx_dev {
+    static constexpr int NW = P::N;                         // 32-bit words of the standard wire form
+    static constexpr int NL = (P::NBITS + 8 + LB - 1) / LB; // >= 8 bits of head-room above the modulus
+    static constexpr int N = NL;                            // words of the in-memory image (internal form)
+    static constexpr u32 MASK = (1u << LB) - 1;
+    static constexpr int RBITS = LB * NL;                   // Montgomery radix 2^RBITS
+    static_assert((double)NL * (double)(1ull << 31) * (double)(1ull << LB) + (double)NL * (double)(1ull << LB) * (double)(1ull << LB)
+                  < 18446744073709551616.0, "a column (one fat operand) must fit the 64-bit accumulator");
+    u32 l[NL];
+
+    SPPARK_DEVFN static constexpr u32 limb_of(const u32* w, int j)
+    {
+        const int bit = LB * j, wi = bit >> 5, sh = bit & 31;
+        if (wi >= NW) return 0;
+        u64 two = w[wi];
+        if (wi + 1 < NW) two |= (u64)w[wi + 1] << 32;
+        return (u32)(two >> sh) & MASK;                     // the top limb of a value < 2^(32 NW) is short anyway
+    }
+    SPPARK_DEVFN static constexpr u32 mod_limb(int j) { return limb_of(P::MOD, j); }
+
+    // Compile-time constant tables.  They are static constexpr OBJECTS (not constexpr function
+    // calls in device code, which hipcc would happily evaluate at run time, per limb).
+    struct limbs_t { u32 l[NL]; };
+    // 2^(32*NW + e) mod p, by doubling P::ONE e times, as internal-width limbs
+    SPPARK_DEVFN static constexpr limbs_t make_pow2(int e)
+    {
+        u32 w[NW] = {};
+        for (int i = 0; i < NW; i++) w[i] = P::ONE[i];
+        for (int k = 0; k < e; k++) {
+            u32 c = 0;
+            for (int i = 0; i < NW; i++) { u32 t = (w[i] << 1) | c; c = w[i] >> 31; w[i] = t; }
+            u32 d[NW] = {}; u64 bw = 0;                     // conditional subtraction of p
+            for (int i = 0; i < NW; i++) { u64 t = (u64)w[i] - P::MOD[i] - bw; d[i] = (u32)t; bw = (t >> 63) & 1; }
+            if (c || !bw) for (int i = 0; i < NW; i++) w[i] = d[i];
+        }
+        limbs_t r{};
+        for (int j = 0; j < NL; j++) r.l[j] = limb_of(w, j);
+        return r;
+    }
+    template<int E> struct pow2_tab { static constexpr limbs_t T = make_pow2(E); };
+    // K*p in "fat" form: every limb but the top borrows B*2^LB from the next one, so limb j is
+    // >= B*(2^LB - 1) for j < NL-1 and the value is still exactly K*p.
+    SPPARK_DEVFN static constexpr limbs_t make_fat(int K, int B)
+    {
+        limbs_t r{}; u64 carry = 0;
+        for (int j = 0; j < NL; j++) {
+            u64 v = (u64)K * mod_limb(j) + carry; carry = v >> LB;
+            r.l[j] = j == NL - 1 ? (u32)v : (u32)(v & MASK);
+            if (j < NL - 1) r.l[j] += (u32)B << LB;
+            if (j > 0) r.l[j] -= (u32)B;
+        }
+        return r;
+    }
+    template<int K, int B> struct fat_tab { static constexpr limbs_t T = make_fat(K, B); };
+    // k*p for k < KMAX, normalised limbs (candidates of is_zero_mod)
+    template<int KMAX> struct multiples_t { u32 l[KMAX][NL]; };
+    template<int KMAX> SPPARK_DEVFN static constexpr multiples_t<KMAX> make_multiples()
+    {
+        multiples_t<KMAX> r{};
+        for (int k = 0; k < KMAX; k++) {
+            u64 carry = 0;
+            for (int j = 0; j < NL; j++) {
+                u64 v = (u64)k * mod_limb(j) + carry; carry = v >> LB;
+                r.l[k][j] = j == NL - 1 ? (u32)v : (u32)(v & MASK);
+            }
+        }
+        return r;
+    }
+    template<int KMAX> struct multiples_tab { static constexpr multiples_t<KMAX> T = make_multiples<KMAX>(); };
+
+    // 1 in the internal domain = 2^RBITS mod p
+    SPPARK_DEVFN static montx_dev one()
+    {   montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = pow2_tab<RBITS - 32 * NW>::T.l[j]; return r;   }
+
+    // standard wire form (x * 2^(32 NW), 32-bit words, canonical) -> internal (x * 2^RBITS),
+    // normalised, < 2p:  w * 2^(2*RBITS - 32 NW) / 2^RBITS
+    SPPARK_DEVFN static montx_dev from_std(const u32* w)
+    {
+        montx_dev a, k;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) { a.l[j] = limb_of(w, j); k.l[j] = pow2_tab<2 * (RBITS - 32 * NW)>::T.l[j]; }
+        return a * k;
+    }
+    // internal (any admissible lazy value: limbs < 2^31) -> canonical standard wire words:
+    // v * 2^(32 NW) / 2^RBITS, then the conditional subtraction and re-limbing
+    SPPARK_DEVFN void to_std(u32* w) const
+    {
+        montx_dev k;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) k.l[j] = pow2_tab<0>::T.l[j];
+        montx_dev r = *this * k;                                    // < v*p/2^RBITS + p < 2p
+        // r - p if r >= p, limb-wise with borrow
+        u32 d[NL]; int bw = 0;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) {
+            int v = (int)r.l[j] - (int)mod_limb(j) - bw;
+            d[j] = j == NL - 1 ? (u32)v : ((u32)v & MASK); bw = (v >> 31) & 1;
+        }
+        #pragma unroll
+        for (int j = 0; j < NL; j++) r.l[j] = bw ? r.l[j] : d[j];
+        #pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int bit = 32 * i, j = bit / LB, sh = bit % LB;
+            u64 acc = (u64)r.l[j] >> sh;
+            if (j + 1 < NL) acc |= (u64)r.l[j + 1] << (LB - sh);
+            if (j + 2 < NL && 2 * LB - sh < 32) acc |= (u64)r.l[j + 2] << (2 * LB - sh);
+            w[i] = (u32)acc;
+        }
+    }
+
+    // in-memory image between the MSM kernels = the limbs themselves
+    SPPARK_DEVFN static montx_dev from_wire(const u32* w)
+    {   montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = w[j]; return r;   }
+    SPPARK_DEVFN void to_wire(u32* w) const { for (int j = 0; j < NL; j++) w[j] = l[j]; }
+
+    SPPARK_DEVFN static montx_dev zero() { montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = 0; return r; }
+    SPPARK_DEVFN bool limbs_all_zero() const
+    {   u32 acc = l[0]; for (int j = 1; j < NL; j++) acc |= l[j]; return acc == 0;   }
+
+    // carry propagation: limbs < 2^LB afterwards (the top limb takes what is left; same value)
+    SPPARK_DEVFN montx_dev norm() const
+    {
+        montx_dev r; u32 c = 0;
+        #pragma unroll
+        for (int j = 0; j < NL - 1; j++) { u32 v = l[j] + c; r.l[j] = v & MASK; c = v >> LB; }
+        r.l[NL - 1] = l[NL - 1] + c;
+        return r;
+    }
+
+    // a + b limb-wise, no carries
+    SPPARK_DEVFN friend montx_dev operator+(const montx_dev& a, const montx_dev& b)
+    {
+        montx_dev r;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) r.l[j] = a.l[j] + b.l[j];
+        return r;
+    }
+
+    // a + K*p - b.  Contract: b's limbs <= B*(2^LB - 1) (B = 1: normalised), b < (K-1)*p
+    // (so that the top limbs cannot underflow either), a's limbs + (B+1)*2^LB < 2^32.
+    template<int K, int B = 1> SPPARK_DEVFN static montx_dev sub(const montx_dev& a, const montx_dev& b)
+    {
+        montx_dev r;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) r.l[j] = a.l[j] + (fat_tab<K, B>::T.l[j] - b.l[j]);
+        return r;
+    }
+    // K*p - b, same contract
+    template<int K, int B = 1> SPPARK_DEVFN static montx_dev neg(const montx_dev& b)
+    {
+        montx_dev r;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) r.l[j] = fat_tab<K, B>::T.l[j] - b.l[j];
+        return r;
+    }
+
+    // accumulator >> LB with two 32-bit instructions (a 64-bit shift costs two quad-cycles and
+    // hipcc re-fuses the C spelling into one)
+    SPPARK_DEVFN static u64 shift_down(u64 A)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        u32 lo = (u32)A, hi = (u32)(A >> 32), nlo, nhi;
+        asm("v_alignbit_b32 %0, %2, %3, %4\n\tv_lshrrev_b32 %1, %4, %2"
+            : "=&v"(nlo), "=v"(nhi) : "v"(hi), "v"(lo), "n"(LB));
+        return ((u64)nhi << 32) | nlo;
+#else
+        return A >> LB;
+#endif
+    }
+
+    // Montgomery product a*b / 2^RBITS (mod p).  Contract: b normalised (limbs < 2^LB), a's
+    // limbs < 2^31 (NL*2^(31+LB) + NL*2^(2LB) < 2^64).  Output normalised, value < a*b/2^RBITS + p.
+    SPPARK_DEVFN friend montx_dev operator*(const montx_dev& a, const montx_dev& b)
+    {
+        constexpr u32 PINV = P::M0 & MASK;                  // -1/p mod 2^LB
+        SPPARK_MODULUS_SGPRS;
+        u32 m[NL];
+        montx_dev r;
+        u64 A = 0;
+        #pragma unroll
+        for (int k = 0; k < 2 * NL; k++) {
+            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;    // i range with 0 <= k-i < NL
+            if (k <= 2 * NL - 2) {
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) macx(A, a.l[i], b.l[k - i]);
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) if (i < k) macxs(A, m[i], pl[k - i]);   // m[i] known for i < k
+            }
+            if (k < NL) {
+                m[k] = ((u32)A * PINV) & MASK;
+                macxs(A, m[k], pl[0]);
+            } else {
+                r.l[k - NL] = (u32)A & MASK;
+            }
+            A = shift_down(A);
+        }
+        return r;
+    }
+    // Two independent products with their multiply-add chains interleaved: a v_mad_u64_u32
+    // that feeds the next one through its addend costs an extra wait state (and hipcc pads
+    // it with an s_nop); alternating two accumulators hides it and halves the padding.
+    SPPARK_DEVFN static void mul2(montx_dev& r0, montx_dev& r1,
+                                  const montx_dev& a0, const montx_dev& b0,
+                                  const montx_dev& a1, const montx_dev& b1)
+    {
+        constexpr u32 PINV = P::M0 & MASK;
+        SPPARK_MODULUS_SGPRS;
+        u32 m0[NL], m1[NL];
+        u64 A0 = 0, A1 = 0;
+        #pragma unroll
+        for (int k = 0; k < 2 * NL; k++) {
+            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+            if (k <= 2 * NL - 2) {
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) { macx(A0, a0.l[i], b0.l[k - i]); macx(A1, a1.l[i], b1.l[k - i]); }
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) if (i < k) { macxs(A0, m0[i], pl[k - i]); macxs(A1, m1[i], pl[k - i]); }
+            }
+            if (k < NL) {
+                m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
+                macxs(A0, m0[k], pl[0]); macxs(A1, m1[k], pl[0]);
+            } else {
+                r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
+            }
+            A0 = shift_down(A0); A1 = shift_down(A1);
+        }
+    }
+    // two squares, interleaved likewise (inputs normalised)
+    SPPARK_DEVFN static void sqr2(montx_dev& r0, montx_dev& r1, const montx_dev& a0, const montx_dev& a1)
+    {
+        constexpr u32 PINV = P::M0 & MASK;
+        SPPARK_MODULUS_SGPRS;
+        u32 m0[NL], m1[NL], d0[NL], d1[NL];
+        #pragma unroll
+        for (int j = 0; j < NL; j++) { d0[j] = a0.l[j] << 1; d1[j] = a1.l[j] << 1; }
+        u64 A0 = 0, A1 = 0;
+        #pragma unroll
+        for (int k = 0; k < 2 * NL; k++) {
+            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+            if (k <= 2 * NL - 2) {
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) {
+                    const int j = k - i;
+                    if (i > j) continue;
+                    if (i == j) { macx(A0, a0.l[i], a0.l[i]); macx(A1, a1.l[i], a1.l[i]); }
+                    else        { macx(A0, a0.l[i], d0[j]);   macx(A1, a1.l[i], d1[j]); }
+                }
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) if (i < k) { macxs(A0, m0[i], pl[k - i]); macxs(A1, m1[i], pl[k - i]); }
+            }
+            if (k < NL) {
+                m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
+                macxs(A0, m0[k], pl[0]); macxs(A1, m1[k], pl[0]);
+            } else {
+                r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
+            }
+            A0 = shift_down(A0); A1 = shift_down(A1);
+        }
+    }
+
+    // a^2 / 2^RBITS.  Contract: limbs < 2^(LB+2) (cross products use the doubled operand:
+    // NL/2 of them < 2^(2LB+5) each).
+    SPPARK_DEVFN montx_dev sqr() const
+    {
+        constexpr u32 PINV = P::M0 & MASK;
+        SPPARK_MODULUS_SGPRS;
+        u32 m[NL], d[NL];
+        #pragma unroll
+        for (int j = 0; j < NL; j++) d[j] = l[j] << 1;
+        montx_dev r;
+        u64 A = 0;
+        #pragma unroll
+        for (int k = 0; k < 2 * NL; k++) {
+            if (k <= 2 * NL - 2) {
+                #pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    const int j = k - i;
+                    if (j < 0 || j >= NL || i > j) continue;
+                    if (i == j) macx(A, l[i], l[i]);
+                    else        macx(A, l[i], d[j]);
+                }
+                #pragma unroll
+                for (int i = 0; i < NL; i++) {
+                    const int j = k - i;
+                    if (j < 0 || j >= NL || i >= k) continue;
+                    macxs(A, m[i], pl[j]);
+                }
+            }
+            if (k < NL) {
+                m[k] = ((u32)A * PINV) & MASK;
+                macxs(A, m[k], pl[0]);
+            } else {
+                r.l[k - NL] = (u32)A & MASK;
+            }
+            A = shift_down(A);
+        }
+        return r;
+    }
+
+    // value == 0 (mod p) for a NORMALISED value < KMAX*p: it must be one of 0, p, 2p, ...;
+    // the low limb filters out almost everything before the exact comparison.
+    template<int KMAX> SPPARK_DEVFN bool is_zero_mod() const
+    {
+        bool maybe = false;
+        #pragma unroll
+        for (int k = 0; k < KMAX; k++) maybe |= (l[0] == multiples_tab<KMAX>::T.l[k][0]);
+        if (!maybe) return false;
+        bool hit = false;
+        #pragma unroll 1
+        for (int k = 0; k < KMAX; k++) {                    // rare: keep it small, not unrolled over k
+            u32 diff = 0;
+            #pragma unroll
+            for (int j = 0; j < NL; j++) diff |= multiples_tab<KMAX>::T.l[k][j] ^ l[j];
+            hit |= diff == 0;
+        }
+        return hit;
+    }
+};
+
+} // namespace sppark_amd

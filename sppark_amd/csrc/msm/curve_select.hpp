@@ -6,6 +6,7 @@
 #include "../ff/mont30_dev.hpp"
 #include "../ff/fp2_dev.hpp"
 #include "../ec/xyzz_dev.hpp"
+#include "../ec/xyzzx_dev.hpp"
 
 namespace sppark_amd {
 #if defined(FEATURE_BLS12_381)
@@ -25,10 +26,21 @@ template<class P> using fp_class = mont30_dev<P>;
 #else
 template<class P> using fp_class = mont_dev<P>;
 #endif
-typedef fp_class<curve_p::fp> fp_d;
+typedef fp_class<curve_p::fp> fp_d;          // wire-format field: generators, test hooks, conversions
 typedef mont_dev<curve_p::fr> fr_d;
-typedef xyzz_dev<fp_d> bucket_d;           // register type
-typedef bucket_d::mem_t bucket_m;           // memory image (wire format)
+// coordinate field of the G1 bucket pipeline.  BLS12-381: the loosely-reduced 28-bit-limb
+// class (ff/montx_dev.hpp): its mixed addition runs 1.30x faster than the 32-bit-limb one on
+// MI355X (profiles/r01_montx_vs_mont32.log).  alt_bn128's 254 bits fill eight 32-bit limbs
+// exactly, where the reduced radix gains nothing, so it keeps mont_dev.
+#if defined(FEATURE_BLS12_381) && !defined(SPPARK_FP32LIMB)
+typedef montx_dev<curve_p::fp, 28> msm_fp_d;
+#else
+typedef fp_d msm_fp_d;
+#endif
+typedef xyzz_dev<fp_d> wire_bucket_d;       // XYZZ in the reference's wire form (ec/xyzz_t.hpp:17)
+typedef wire_bucket_d::mem_t wire_bucket_m;
+typedef xyzz_dev<msm_fp_d> bucket_d;       // register type
+typedef bucket_d::mem_t bucket_m;           // memory image between the kernels
 // G2: same pipeline over the quadratic extension (ff/fp2_dev.hpp).  The kernel
 // translation units are compiled a second time with -DSPPARK_G2 to instantiate it.
 typedef fp2_dev<curve_p::fp> fp2_d;
@@ -37,7 +49,7 @@ typedef bucket2_d::mem_t bucket2_m;
 #ifdef SPPARK_G2
 typedef fp2_d inst_fp;
 #else
-typedef fp_d inst_fp;
+typedef msm_fp_d inst_fp;
 #endif
 typedef xyzz_dev<inst_fp>::mem_t inst_m;    // what the k_*.hip units instantiate
 }

@@ -86,8 +86,11 @@ public:
     typedef FH fp_h;
     typedef typename xyzz_dev<fp_d>::mem_t bucket_t;       // memory image: wire format
     typedef jacobian_host<fp_h> point_t;
-    static constexpr size_t FP_BYTES = 4 * FD::N;
-    static_assert(sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
+    static constexpr int STD_WORDS = sizeof(FH) / 4;        // 32-bit words of a coordinate in the reference's wire form
+    static constexpr size_t FP_BYTES = sizeof(FH);
+    static constexpr bool INTERNAL = field_is_internal<FD>::value;      // ff/montx_dev.hpp: own point/bucket records
+    typedef xyzz_mem<STD_WORDS> std_bucket_t;
+    static_assert(INTERNAL || sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
 
 private:
@@ -104,10 +107,14 @@ private:
 
     struct layout {
         size_t points, scalars, digits, sorted, partA, H, tot, offA, off, buckets;
-        size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, total;
+        size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, conv, fin, total;
     };
 
     static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+    static constexpr size_t conv_stride()
+    {
+        if constexpr (INTERNAL) return affine_loader<FD>::STRIDE; else return 0;
+    }
 
     layout make_layout(const msm_plan& p, size_t pts_bytes, size_t sc_bytes) const
     {
@@ -131,6 +138,8 @@ private:
         size_t n2 = n1;
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n2 * sizeof(bucket_t)); l.W2 = take(n2 * sizeof(bucket_t));
+        l.conv = take(INTERNAL ? (size_t)p.n * conv_stride() : 0);        // points in the field's own records
+        l.fin  = take(INTERNAL ? (size_t)p.nwins * sizeof(std_bucket_t) : 0);
         l.total = o;
         return l;
     }
@@ -283,6 +292,17 @@ public:
         }
         HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
 
+        if constexpr (INTERNAL) {           // wire points -> the field's own records (2 products per point, once)
+            unsigned char* conv = blob + l.conv;
+            unsigned grid = (unsigned)((p.n + 255) / 256);
+            if (flagged) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream,
+                                            conv, d_points, p.n, (unsigned)ffi_affine_sz);
+            else         hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, stream,
+                                            conv, d_points, p.n, (unsigned)ffi_affine_sz);
+            HIP_OK(hipGetLastError());
+            d_points = conv;
+        }
+
         if (timing) HIP_OK(hipEventRecord(ev[1], stream));
 
         // ---- bucket accumulation: level 0 + segmented tree ------------------
@@ -342,8 +362,15 @@ public:
         if (timing) HIP_OK(hipEventRecord(ev[3], stream));
 
         // ---- device -> host: one XYZZ per window; Horner on the host --------
-        std::vector<bucket_t> sums(p.nwins);
-        HIP_OK(hipMemcpyAsync(sums.data(), result, p.nwins * sizeof(bucket_t), hipMemcpyDeviceToHost, stream));
+        std::vector<std_bucket_t> sums(p.nwins);
+        if constexpr (INTERNAL) {           // window sums back to the reference's wire image
+            std_bucket_t* fin = (std_bucket_t*)(blob + l.fin);
+            hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((p.nwins + 63) / 64), dim3(64), 0, stream, fin, result, p.nwins);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipMemcpyAsync(sums.data(), fin, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        } else {
+            HIP_OK(hipMemcpyAsync(sums.data(), result, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        }
         HIP_OK(hipStreamSynchronize(stream));
 
         if (timing) {

@@ -28,6 +28,7 @@
 // (pippenger.cuh:157-223), sized for 32-lane warps and <= 100 SMs (sort.cuh:312).
 #pragma once
 #include "../ec/xyzz_dev.hpp"
+#include "../ec/xyzzx_dev.hpp"
 
 namespace sppark_amd {
 
@@ -247,9 +248,9 @@ void k_reduce_runs(xyzz_mem<FP::N>* __restrict__ buckets,
 template<class FP> SPPARK_OUTLINED void xyzz_add_outlined(xyzz_dev<FP>& a, const xyzz_dev<FP>& b) { a.add(b); }
 template<class FP> SPPARK_OUTLINED void xyzz_dbl_outlined(xyzz_dev<FP>& a) { a.dbl(); }
 template<class FP> SPPARK_DEVFN void bucket_add(xyzz_dev<FP>& a, const xyzz_dev<FP>& b)
-{   if constexpr (FP::N > 12) xyzz_add_outlined<FP>(a, b); else a.add(b);   }
+{   if constexpr (FP::N > 16) xyzz_add_outlined<FP>(a, b); else a.add(b);   }
 template<class FP> SPPARK_DEVFN void bucket_dbl(xyzz_dev<FP>& a)
-{   if constexpr (FP::N > 12) xyzz_dbl_outlined<FP>(a); else a.dbl();   }
+{   if constexpr (FP::N > 16) xyzz_dbl_outlined<FP>(a); else a.dbl();   }
 
 // ---------------------------------------------------------------------------
 template<class FP>
@@ -305,5 +306,29 @@ void k_bucket_levelN(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restri
                      const xyzz_mem<FP::N>* __restrict__ A1, const xyzz_mem<FP::N>* __restrict__ Wt1,
                      unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)
 {   bucket_levelN_item<FP>(A2, Wt2, A1, Wt1, nitems, K, lgG, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+
+// ---------------------------------------------------------------------------
+// Coordinate fields with an internal representation (ff/montx_dev.hpp): the points are
+// converted ONCE per MSM (or once per preload) into the field's own records, and the W
+// window sums are converted back to the reference's wire image at the end.
+// ---------------------------------------------------------------------------
+template<class FP> struct field_is_internal { static constexpr bool value = false; };
+template<class P, int LB> struct field_is_internal<montx_dev<P, LB>> { static constexpr bool value = true; };
+
+template<class FP, bool FLAGGED>
+__global__ __launch_bounds__(256)
+void k_convert_points(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, unsigned n, unsigned stride)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) affine_loader<FP>::template convert<FLAGGED>(dst, src, i, stride);
+}
+
+template<class FP, int STD_WORDS>
+__global__ __launch_bounds__(64)
+void k_finalize(xyzz_mem<STD_WORDS>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ in, unsigned count)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) xyzz_dev<FP>::load(&in[i]).store_std(&out[i]);
+}
 
 } // namespace sppark_amd

@@ -44,15 +44,37 @@ extern "C" int emu_field_op(int field, int op, void* out, const void* a, const v
 // op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
 extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size_t n)
 {
-    const bucket_m* pa = (const bucket_m*)a; bucket_m* po = (bucket_m*)out;
+    const wire_bucket_m* pa = (const wire_bucket_m*)a; wire_bucket_m* po = (wire_bucket_m*)out;
     for (size_t i = 0; i < n; i++) {
-        bucket_d p = bucket_d::load(&pa[i]);
-        if (op == 0) p.add(bucket_d::load((const bucket_m*)b + i));
+        wire_bucket_d p = wire_bucket_d::load(&pa[i]);
+        if (op == 0) p.add(wire_bucket_d::load((const wire_bucket_m*)b + i));
         else if (op == 3) p.dbl();
         else { affine_dev<fp_d> q = load_affine<fp_d, false>((const unsigned char*)b, i, 8 * fp_d::N); p.madd(q, op == 2); }
         p.store(&po[i]);
     }
     return 0;
+}
+
+// the two extra steps of fields with their own records (k_convert_points / k_finalize)
+template<class F>
+static const unsigned char* convert_points(std::vector<uint4>& conv, const unsigned char* pts, size_t npoints, size_t stride, bool flagged)
+{
+    if constexpr (field_is_internal<F>::value) {
+        conv.resize((size_t)npoints * affine_loader<F>::STRIDE / 16 + 1);
+        for (size_t i = 0; i < npoints; i++) {
+            if (flagged) affine_loader<F>::template convert<true>((unsigned char*)conv.data(), pts, i, (unsigned)stride);
+            else         affine_loader<F>::template convert<false>((unsigned char*)conv.data(), pts, i, (unsigned)stride);
+        }
+        return (const unsigned char*)conv.data();
+    } else {
+        return pts;
+    }
+}
+template<class F, class M>
+static void finalize_sum(M* out, const xyzz_mem<F::N>* in)
+{
+    if constexpr (field_is_internal<F>::value) xyzz_dev<F>::load(in).store_std(out);
+    else memcpy(out, in, sizeof(*out));
 }
 
 extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
@@ -84,7 +106,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
     p.F = std::max(4u, F ? F : 32u);
     p.K = std::min(K ? K : 8u, p.NB);
-    const bool flagged = stride > 8 * inst_fp::N;
+    const bool flagged = stride > 2 * sizeof(fp_h);
 
     // ---- breakdown (k_breakdown) ----
     std::vector<u32> digits((size_t)p.nwins * p.n), sorted((size_t)p.nwins * p.n);
@@ -150,6 +172,9 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     std::vector<uint64_t> pts_al((npoints * stride + 15) / 8);
     memcpy(pts_al.data(), points, npoints * stride);
     const unsigned char* pts = (const unsigned char*)pts_al.data();
+    // fields with their own records (ff/montx_dev.hpp): k_convert_points first, as msm_driver.hpp does
+    std::vector<uint4> conv;
+    pts = convert_points<inst_fp>(conv, pts, npoints, stride, flagged);
     for (unsigned w = 0; w < p.nwins; w++)
         for (unsigned chunk = 0; chunk < ((p.chunks_per_win + 255) / 256) * 256; chunk++) {
             if (flagged) accumulate_chunk<inst_fp, true>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
@@ -185,9 +210,12 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         nitems /= Kc; lgG += lg2_floor(Kc);
         std::swap(ia, oa); std::swap(iw, ow);
     }
+    // k_finalize: window sums back to the reference's wire image
+    std::vector<xyzz_mem<sizeof(fp_h) / 4>> fin(p.nwins);
+    for (unsigned w = 0; w < p.nwins; w++) finalize_sum<inst_fp>(&fin[w], &iw[w]);
     for (unsigned w = p.nwins; w--;) {
         fp_h c[4];
-        memcpy(c, &iw[w], sizeof(c));
+        memcpy(c, &fin[w], sizeof(c));
         point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
         out.add(s);
         if (w) for (unsigned k = 0; k < window_len(w - 1, p.nwins, p.nbits); k++) out.dbl();

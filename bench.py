@@ -137,6 +137,17 @@ def main():
         extras = {}
         # BASELINE configs[4]: alt_bn128 G1 MSM + BabyBear NTT (multi-field instantiation)
         bpts, bsc = make_msm_inputs(args.lg, 7, "bn254", 32)
+        # bases kept in the context (the reference's msm_t(points) + invoke(out, scalars),
+        # msm/pippenger.cuh:351-385,604-605): the one-time conversion of the points into the
+        # kernels' own records is then outside the call; NOT the headline value, which pays it
+        ctx.set_points(pts)
+        ctx.invoke(None, sc)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(3):
+            ctx.invoke(None, sc)
+        torch.cuda.synchronize()
+        extras["bls12_381_g1_msm_preloaded_bases_points_per_s"] = 3 * n / (time.perf_counter() - t1)
+        ctx.set_points(None)
         bctx = sppark_amd.MsmContext("bn254", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
         bctx.invoke(bpts, bsc)
         torch.cuda.synchronize(); t1 = time.perf_counter()

@@ -104,30 +104,42 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         if (q.is_inf()) return;
         if (is_inf()) { *this = q; return; }
 
-        F U1, S1, U2, S2;
-        F::mul2(U1, S1, X, q.ZZ, Y, q.ZZZ);                 // n, < 2p
-        F::mul2(U2, S2, q.X, ZZ, q.Y, ZZZ);
+        // (single product chains here: the full addition lives in the cold kernels, where the
+        // register footprint of interleaved pairs costs an occupancy step)
+        F U1 = X * q.ZZ;                                    // n, < 2p
+        F S1 = Y * q.ZZZ;
+        F U2 = q.X * ZZ;
+        F S2 = q.Y * ZZZ;
         F Pd = F::template sub<3>(U2, U1).norm();           // < 5p, n
         F Rd = F::template sub<3>(S2, S1).norm();
 
         if (!Pd.template is_zero_mod<5>()) {
-            F PP, RR, PPP, Q, M1, M2;
-            F::sqr2(PP, RR, Pd, Rd);
-            F::mul2(PPP, Q, Pd, PP, U1, PP);
+            F PP  = Pd.sqr();
+            F PPP = Pd * PP;
+            F Q   = U1 * PP;
             F T   = PPP + Q + Q;
-            F X3  = F::template sub<8, 3>(RR, T);
+            F X3  = F::template sub<8, 3>(Rd.sqr(), T);
             F D   = F::template sub<11, 6>(Q, X3);
-            F::mul2(M1, M2, D, Rd, S1, PPP);
-            Y   = F::template sub<3>(M1, M2);
-            F::mul2(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);
-            F::mul2(ZZ, ZZZ, ZZ, q.ZZ, ZZZ, q.ZZZ);
+            Y   = F::template sub<3>(D * Rd, S1 * PPP);
+            ZZ  = (ZZ * PP) * q.ZZ;
+            ZZZ = (ZZZ * PPP) * q.ZZZ;
             X = X3;
         } else if (Rd.template is_zero_mod<5>()) {
-            dbl();
+            // rare (equal points): one out-of-line copy, so that the nine products of a doubling
+            // are not inlined into every addition of the cold kernels
+            xyzz_dev t = *this;
+            dbl_outlined(t);
+            *this = t;
         } else {
             set_inf();
         }
     }
+
+#if defined(SPPARK_HOST_EMULATION)
+    static void dbl_outlined(xyzz_dev& t) { t.dbl(); }
+#else
+    __device__ __noinline__ static void dbl_outlined(xyzz_dev& t) { t.dbl(); }
+#endif
 
     SPPARK_DEVFN void dbl()
     {

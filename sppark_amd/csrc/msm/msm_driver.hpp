@@ -116,7 +116,7 @@ private:
         if constexpr (INTERNAL) return affine_loader<FD>::STRIDE; else return 0;
     }
 
-    layout make_layout(const msm_plan& p, size_t pts_bytes, size_t sc_bytes) const
+    layout make_layout(const msm_plan& p, size_t pts_bytes, size_t sc_bytes, bool convert = true) const
     {
         layout l; size_t o = 0;
         auto take = [&](size_t sz) { size_t r = o; o += align_up(sz); return r; };
@@ -138,7 +138,7 @@ private:
         size_t n2 = n1;
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n2 * sizeof(bucket_t)); l.W2 = take(n2 * sizeof(bucket_t));
-        l.conv = take(INTERNAL ? (size_t)p.n * conv_stride() : 0);        // points in the field's own records
+        l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
         l.fin  = take(INTERNAL ? (size_t)p.nwins * sizeof(std_bucket_t) : 0);
         l.total = o;
         return l;
@@ -207,10 +207,33 @@ public:
         if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
         if (np == 0) return;
         if (points == nullptr || ffi_affine_sz < 2 * FP_BYTES || np > (1u << 31)) HIP_OK(hipErrorInvalidValue);
-        HIP_OK(hipMalloc((void**)&pre_points, np * ffi_affine_sz));
-        HIP_OK(hipMemcpyAsync(pre_points, points, np * ffi_affine_sz,
-                              is_device_pointer(points) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+        if constexpr (INTERNAL) {
+            // bases are constant across invocations: convert them into the field's own records once
+            const unsigned char* src = (const unsigned char*)points;
+            unsigned char* staging = nullptr;
+            if (!is_device_pointer(points)) {
+                HIP_OK(hipMalloc((void**)&staging, np * ffi_affine_sz));
+                HIP_OK(hipMemcpyAsync(staging, points, np * ffi_affine_sz, hipMemcpyHostToDevice, stream));
+                src = staging;
+            }
+            hipError_t e = hipMalloc((void**)&pre_points, np * conv_stride());
+            if (e == hipSuccess) {
+                unsigned grid = (unsigned)((np + 255) / 256);
+                if (ffi_affine_sz > 2 * FP_BYTES)
+                    hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream, pre_points, src, (unsigned)np, (unsigned)ffi_affine_sz);
+                else
+                    hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, stream, pre_points, src, (unsigned)np, (unsigned)ffi_affine_sz);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            }
+            if (staging) (void)hipFree(staging);
+            if (e != hipSuccess) { if (pre_points) { (void)hipFree(pre_points); pre_points = nullptr; } HIP_OK(e); }
+        } else {
+            HIP_OK(hipMalloc((void**)&pre_points, np * ffi_affine_sz));
+            HIP_OK(hipMemcpyAsync(pre_points, points, np * ffi_affine_sz,
+                                  is_device_pointer(points) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+        }
         pre_n = np; pre_stride = ffi_affine_sz;
     }
     size_t preloaded() const { return pre_n; }
@@ -224,6 +247,7 @@ public:
         if (npoints == 0) return;
         if (npoints > (1u << 31)) HIP_OK(hipErrorInvalidValue);
         HIP_OK(hipSetDevice(gpu->hip_id));
+        const bool preconverted = INTERNAL && points == nullptr;      // preload() already converted them
         if (points == nullptr) {                    // preloaded points, their own stride
             if (npoints > pre_n) HIP_OK(hipErrorInvalidValue);
             points = pre_points; ffi_affine_sz = pre_stride;
@@ -234,7 +258,7 @@ public:
         const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);
         const msm_plan p = make_plan(npoints, FRp::NBITS, tune);
         const layout l = make_layout(p, pts_dev ? 0 : npoints * ffi_affine_sz,
-                                        sc_dev ? 0 : npoints * SCALAR_BYTES);
+                                        sc_dev ? 0 : npoints * SCALAR_BYTES, !preconverted);
         reserve(l.total);
 
         const unsigned char* d_points = (const unsigned char*)points;
@@ -292,7 +316,7 @@ public:
         }
         HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
 
-        if constexpr (INTERNAL) {           // wire points -> the field's own records (2 products per point, once)
+        if constexpr (INTERNAL) if (!preconverted) {   // wire points -> the field's own records (2 products per point)
             unsigned char* conv = blob + l.conv;
             unsigned grid = (unsigned)((p.n + 255) / 256);
             if (flagged) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream,

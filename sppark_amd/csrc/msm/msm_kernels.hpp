@@ -150,9 +150,14 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     u32 e = src[p];
     affine_dev<FP> pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);
     acc.set(pt, e >> 31);
+    // the gather of entry p+1 is issued before the addition of entry p: its latency hides
+    // behind ~20k cycles of arithmetic instead of being exposed at the head of every step
+    u32 e_next = 0;
+    affine_dev<FP> pt_next = pt;
+    if (p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
     for (p++; p < end; p++) {
-        e = src[p];
-        pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);
+        e = e_next; pt = pt_next;
+        if (p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
         if (p == next) {                            // bucket boundary: flush
             const u32 key = w * NB + b;
             if (first_run) { acc.store(&rec_pt[rec0]); slot0_key = key; first_run = false; }

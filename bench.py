@@ -215,7 +215,7 @@ def main():
             if pmc.get("lg") == args.lg and pmc.get("curve") == "bls12_381":
                 traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) / 1e9
                 traffic_note = ("; traffic = GB per launch from rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, "
-                                "profiles/r01_pmc_traffic.json): the 96-byte point gathers pull whole 128-byte lines, "
+                                "profiles/r01_pmc_traffic.json): the 112-byte point-record gathers pull whole 128-byte lines, "
                                 "hidden behind the multiplier-bound arithmetic")
         except (OSError, ValueError, KeyError):
             pass
@@ -234,8 +234,9 @@ def main():
                          "algorithmic_gb_per_launch": achieved * a_ms * 1e-3, "kernel": "k_accumulate",
                          "kernel_ms": a_ms,
                          "note": "MSM is integer-multiplier bound, not HBM bound (SURVEY F11): the kernel does "
-                                 "%d mixed additions per launch = %.3e additions/s against a measured "
-                                 "5.14e9/s mixed-addition micro-benchmark" % (nwins * n, nwins * n / (a_ms * 1e-3)) + traffic_note},
+                                 "%d mixed additions per launch = %.3e additions/s against 7.29e9/s for the same "
+                                 "addition chain on registers (profiles/r01_montx_vs_mont32.log)"
+                                 % (nwins * n, nwins * n / (a_ms * 1e-3)) + traffic_note},
             "phases_ms": {"digits_sort": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
             "cpu_baseline": cpu, "ntt": ntt, "extras": extras,
         }

@@ -112,6 +112,10 @@ void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
     }
 }
 
+// coordinate fields with their own point/bucket records (ff/montx_dev.hpp)
+template<class FP> struct field_is_internal { static constexpr bool value = false; };
+template<class P, int LB> struct field_is_internal<montx_dev<P, LB>> { static constexpr bool value = true; };
+
 // ---------------------------------------------------------------------------
 // accumulate (level 0).  Work item (chunk, window) owns entries
 // [chunk*L, chunk*L + L) of window w's grouped list.  Runs that touch the
@@ -150,14 +154,22 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     u32 e = src[p];
     affine_dev<FP> pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);
     acc.set(pt, e >> 31);
-    // the gather of entry p+1 is issued before the addition of entry p: its latency hides
-    // behind ~20k cycles of arithmetic instead of being exposed at the head of every step
+    // PREFETCH: the gather of entry p+1 is issued before the addition of entry p, so its latency
+    // hides behind ~20k cycles of arithmetic.  It costs a second point in registers: worth it for
+    // the reduced-radix field (2 waves/SIMD either way, +2 %), not for alt_bn128 (would drop from
+    // 4 to 3 waves/SIMD: 53 -> 71 ms) or Fp2.
+    constexpr bool PREFETCH = field_is_internal<FP>::value;
     u32 e_next = 0;
     affine_dev<FP> pt_next = pt;
-    if (p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
+    if (PREFETCH && p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
     for (p++; p < end; p++) {
-        e = e_next; pt = pt_next;
-        if (p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
+        if (PREFETCH) {
+            e = e_next; pt = pt_next;
+            if (p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
+        } else {
+            e = src[p];
+            pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);
+        }
         if (p == next) {                            // bucket boundary: flush
             const u32 key = w * NB + b;
             if (first_run) { acc.store(&rec_pt[rec0]); slot0_key = key; first_run = false; }
@@ -317,8 +329,6 @@ void k_bucket_levelN(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restri
 // converted ONCE per MSM (or once per preload) into the field's own records, and the W
 // window sums are converted back to the reference's wire image at the end.
 // ---------------------------------------------------------------------------
-template<class FP> struct field_is_internal { static constexpr bool value = false; };
-template<class P, int LB> struct field_is_internal<montx_dev<P, LB>> { static constexpr bool value = true; };
 
 template<class FP, bool FLAGGED>
 __global__ __launch_bounds__(256)

@@ -50,6 +50,26 @@ SPPARK_DEVFN void macxs(u64& acc, u32 a, u32 b)
 #endif
 }
 SPPARK_DEVFN u32 opaque_sgpr(u32 c) { return c; }
+// two independent multiply-adds in ONE asm statement: hipcc pads every asm statement with an
+// s_nop (it cannot see inside), so pairing halves the padding of the interleaved product pairs
+SPPARK_DEVFN void macx2(u64& acc0, u32 a0, u32 b0, u64& acc1, u32 a1, u32 b1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1"
+        : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+#else
+    acc0 += (u64)a0 * b0; acc1 += (u64)a1 * b1;
+#endif
+}
+SPPARK_DEVFN void macxs2(u64& acc0, u32 a0, u64& acc1, u32 a1, u32 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %4, %0\n\tv_mad_u64_u32 %1, vcc, %3, %4, %1"
+        : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(a1), "s"(b) : "vcc");
+#else
+    acc0 += (u64)a0 * b; acc1 += (u64)a1 * b;
+#endif
+}
 
 #define SPPARK_MODULUS_SGPRS u32 pl[NL]; _Pragma("unroll") for (int j_ = 0; j_ < NL; j_++) pl[j_] = opaque_sgpr(mod_limb(j_))
 
@@ -267,13 +287,13 @@ template<class P, int LB> struct montx_dev {
             const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
             if (k <= 2 * NL - 2) {
                 #pragma unroll
-                for (int i = lo; i <= hi; i++) { macx(A0, a0.l[i], b0.l[k - i]); macx(A1, a1.l[i], b1.l[k - i]); }
+                for (int i = lo; i <= hi; i++) macx2(A0, a0.l[i], b0.l[k - i], A1, a1.l[i], b1.l[k - i]);
                 #pragma unroll
-                for (int i = lo; i <= hi; i++) if (i < k) { macxs(A0, m0[i], pl[k - i]); macxs(A1, m1[i], pl[k - i]); }
+                for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], pl[k - i]);
             }
             if (k < NL) {
                 m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
-                macxs(A0, m0[k], pl[0]); macxs(A1, m1[k], pl[0]);
+                macxs2(A0, m0[k], A1, m1[k], pl[0]);
             } else {
                 r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
             }
@@ -297,15 +317,15 @@ template<class P, int LB> struct montx_dev {
                 for (int i = lo; i <= hi; i++) {
                     const int j = k - i;
                     if (i > j) continue;
-                    if (i == j) { macx(A0, a0.l[i], a0.l[i]); macx(A1, a1.l[i], a1.l[i]); }
-                    else        { macx(A0, a0.l[i], d0[j]);   macx(A1, a1.l[i], d1[j]); }
+                    if (i == j) macx2(A0, a0.l[i], a0.l[i], A1, a1.l[i], a1.l[i]);
+                    else        macx2(A0, a0.l[i], d0[j], A1, a1.l[i], d1[j]);
                 }
                 #pragma unroll
-                for (int i = lo; i <= hi; i++) if (i < k) { macxs(A0, m0[i], pl[k - i]); macxs(A1, m1[i], pl[k - i]); }
+                for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], pl[k - i]);
             }
             if (k < NL) {
                 m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
-                macxs(A0, m0[k], pl[0]); macxs(A1, m1[k], pl[0]);
+                macxs2(A0, m0[k], A1, m1[k], pl[0]);
             } else {
                 r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
             }

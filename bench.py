@@ -166,6 +166,46 @@ def main():
             sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream)
         e1.record(); torch.cuda.synchronize()
         extras["babybear_ntt_elems_per_s"] = 20 * (1 << args.ntt_lg) / (e0.elapsed_time(e1) * 1e-3)
+        # the "next" rows of SURVEY 8(f): G2 MSM, 256-bit-field NTT, low-degree extension
+        try:
+            # input points: the 33 G2 points of a committed golden case (data fixture), replicated
+            with open(os.path.join(ROOT, "tests", "golden", "msm_g2_golden.json")) as f:
+                case = [c for c in json.load(f) if c["curve"] == "bls12_381" and c["n"] == 33 and "points" in c][0]
+            g2 = np.frombuffer(bytes.fromhex(case["points"]), dtype=np.uint8).reshape(33, -1)
+            lg2 = min(args.lg, 22)
+            g2pts = torch.from_numpy(g2[np.arange(1 << lg2) % 33].copy()).cuda()
+            g2sc = sc[:1 << lg2].contiguous()
+            sppark_amd.multi_scalar_mult_fp2_arkworks(g2pts, g2sc)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                sppark_amd.multi_scalar_mult_fp2_arkworks(g2pts, g2sc)
+            torch.cuda.synchronize()
+            extras["bls12_381_g2_msm_2^%d_points_per_s" % lg2] = 3 * (1 << lg2) / (time.perf_counter() - t1)
+            del g2pts, g2sc
+        except Exception as ex:                                 # noqa: BLE001  (extras never fail the bench)
+            extras["bls12_381_g2_msm_error"] = repr(ex)[:200]
+        stream = torch.cuda.current_stream().cuda_stream
+        wlg = min(args.ntt_lg, 22)
+        wx = torch.randint(0, 2**62, ((1 << wlg) * 4,), dtype=torch.int64, device="cuda"); wx[3::4] &= 0x0fffffffffffffff
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            sppark_amd.NTT(0, wx, sppark_amd.NTTInputOutputOrder.NR, "bls12_381", stream=stream)
+        e0.record()
+        for _ in range(5):
+            sppark_amd.NTT(0, wx, sppark_amd.NTTInputOutputOrder.NR, "bls12_381", stream=stream)
+        e1.record(); torch.cuda.synchronize()
+        extras["bls12_381_fr_ntt_2^%d_elems_per_s" % wlg] = 5 * (1 << wlg) / (e0.elapsed_time(e1) * 1e-3)
+        del wx
+        llg = min(args.ntt_lg, 22)
+        ext = torch.randint(0, 2**62, (1 << (llg + 2),), dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            sppark_amd.LDE(0, ext, llg, 2, "gl64", stream=stream)
+        e0.record()
+        for _ in range(5):
+            sppark_amd.LDE(0, ext, llg, 2, "gl64", stream=stream)
+        e1.record(); torch.cuda.synchronize()
+        extras["goldilocks_lde_2^%d_to_2^%d_ms" % (llg, llg + 2)] = e0.elapsed_time(e1) / 5
+        del ext
         # through-the-FFI path with HOST buffers (PCIe inclusive; never the headline value)
         lgh = min(args.lg, 24)
         hp = np.zeros(((1 << lgh), 104), dtype=np.uint8); hp[:, :96] = pts[:1 << lgh].cpu().numpy()

@@ -96,6 +96,101 @@ SPPARK_FFI RustError sppark_devtest_xyzz_op(int op, void* out, const void* a, co
 }
 
 // ---------------------------------------------------------------------------
+// The bucket pipeline's own field (ff/montx_dev.hpp on BLS12-381): element-wise operations on
+// internal limbs, and point operations computed in the loosely-reduced form but fed and read
+// back in the reference's wire form, so that they can be compared bit for bit with the
+// 32-bit-limb class and with the oracle.
+// ---------------------------------------------------------------------------
+template<class F>
+__global__ void k_bucket_field_op(u32* out, const u32* a, const u32* b, unsigned n, int op)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if constexpr (field_is_internal<F>::value) {
+        constexpr int NL = F::NL;
+        F x = F::from_wire(a + (size_t)i * NL), y = F::from_wire(b + (size_t)i * NL), r = F::zero();
+        switch (op) {
+            case 0: r = x * y; break;                               // x may be fat (limbs < 2^31), y normalised
+            case 1: r = x.sqr(); break;                             // x normalised
+            case 2: r = F::template sub<3>(x, y).norm(); break;     // y normalised, < 2p
+            case 3: r = (x + y).norm(); break;
+            case 4: r.l[0] = x.template is_zero_mod<13>(); break;   // x normalised, < 13p
+            case 5: r = F::from_std(a + (size_t)i * NL); break;     // first NW words: a wire-form element
+            default: { u32 w[NL] = {}; x.to_std(w); for (int j = 0; j < NL; j++) r.l[j] = w[j]; } break;
+        }
+        r.to_wire(out + (size_t)i * NL);
+    }
+}
+
+// op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a ; all in wire form
+template<class F>
+__global__ void k_bucket_xyzz_op(wire_bucket_m* out, const wire_bucket_m* a, const unsigned char* b, unsigned n, int op)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if constexpr (field_is_internal<F>::value) {
+        constexpr int NW = fp_d::N;
+        auto to_internal = [](const wire_bucket_m* src) {
+            xyzz_dev<F> r;
+            bool inf = true;
+            for (int k = 2 * NW; k < 4 * NW; k++) inf &= src->w[k] == 0;
+            if (inf) { r.set_inf(); return r; }
+            r.X = F::from_std(src->w); r.Y = F::from_std(src->w + NW);
+            r.ZZZ = F::from_std(src->w + 2 * NW); r.ZZ = F::from_std(src->w + 3 * NW);
+            return r;
+        };
+        xyzz_dev<F> p = to_internal(&a[i]);
+        if (op == 0) p.add(to_internal(reinterpret_cast<const wire_bucket_m*>(b) + i));
+        else if (op == 3) p.dbl();
+        else {
+            affine_dev<fp_d> qs = load_affine<fp_d, false>(b, i, 8 * NW);
+            u32 wx[NW], wy[NW];
+            qs.X.to_wire(wx); qs.Y.to_wire(wy);
+            affine_dev<F> q; q.X = F::from_std(wx); q.Y = F::from_std(wy); q.inf = qs.inf;
+            p.madd(q, op == 2);
+        }
+        p.store_std(&out[i]);
+    }
+}
+
+// element size: NL words for ops on internal limbs (see k_bucket_field_op)
+SPPARK_FFI RustError sppark_devtest_bucket_field_op(int op, void* out, const void* a, const void* b, size_t n)
+{
+    return guarded([&] {
+        if (!field_is_internal<msm_fp_d>::value) HIP_OK(hipErrorNotSupported);
+        (void)select_gpu(-1);
+        size_t bytes = n * msm_fp_d::N * 4;
+        u32 *d_a, *d_b, *d_o;
+        HIP_OK(hipMalloc((void**)&d_a, bytes)); HIP_OK(hipMalloc((void**)&d_b, bytes)); HIP_OK(hipMalloc((void**)&d_o, bytes));
+        HIP_OK(hipMemcpy(d_a, a, bytes, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_b, b ? b : a, bytes, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_bucket_field_op<msm_fp_d>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost));
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+    });
+}
+SPPARK_FFI int sppark_devtest_bucket_field_limbs(void)
+{   return field_is_internal<msm_fp_d>::value ? (int)msm_fp_d::N : 0;   }
+
+SPPARK_FFI RustError sppark_devtest_bucket_xyzz_op(int op, void* out, const void* a, const void* b, size_t n)
+{
+    return guarded([&] {
+        if (!field_is_internal<msm_fp_d>::value) HIP_OK(hipErrorNotSupported);
+        (void)select_gpu(-1);
+        size_t ab = n * sizeof(wire_bucket_m), bb = n * (op == 0 ? sizeof(wire_bucket_m) : 8 * fp_d::N);
+        wire_bucket_m *d_a, *d_o; unsigned char* d_b;
+        HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_o, ab)); HIP_OK(hipMalloc((void**)&d_b, bb ? bb : 16));
+        HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice));
+        if (op != 3) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_bucket_xyzz_op<msm_fp_d>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpy(out, d_o, ab, hipMemcpyDeviceToHost));
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
+    });
+}
+
+// ---------------------------------------------------------------------------
 // micro-benchmarks: every wave runs |iters| iterations of a fixed instruction
 // block and reports its own s_memtime delta; the host also times the launch.
 // ---------------------------------------------------------------------------

@@ -112,10 +112,6 @@ void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
     }
 }
 
-// coordinate fields with their own point/bucket records (ff/montx_dev.hpp)
-template<class FP> struct field_is_internal { static constexpr bool value = false; };
-template<class P, int LB> struct field_is_internal<montx_dev<P, LB>> { static constexpr bool value = true; };
-
 // ---------------------------------------------------------------------------
 // accumulate (level 0).  Work item (chunk, window) owns entries
 // [chunk*L, chunk*L + L) of window w's grouped list.  Runs that touch the

@@ -99,6 +99,12 @@ def load(name):
         L.sppark_g1_generate.restype = _Error
         L.sppark_devtest_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
         L.sppark_devtest_field_op.restype = _Error
+        L.sppark_devtest_bucket_field_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_bucket_field_op.restype = _Error
+        L.sppark_devtest_bucket_field_limbs.argtypes = []
+        L.sppark_devtest_bucket_field_limbs.restype = ci
+        L.sppark_devtest_bucket_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_bucket_xyzz_op.restype = _Error
         L.sppark_devtest_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
         L.sppark_devtest_xyzz_op.restype = _Error
         L.sppark_devtest_ubench.argtypes = [ci, ci, cu, cu, ctypes.POINTER(ctypes.c_float),

@@ -95,6 +95,102 @@ def test_device_point_ops(oracle, libs, curve, name):
             assert (O.xyzz_to_affine(curve, out[i]) == O.jac_to_affine(curve, e)).all(), (name, op, i)
 
 
+def test_bucket_field_ops(libs):
+    """ff/montx_dev.hpp (the BLS12-381 bucket pipeline's loosely-reduced 28-bit-limb field),
+    element-wise on the GPU against Python big-ints: products with normalised and with fat
+    operands, squares, lazy subtraction with fat multiples of p, carry propagation, the exact
+    zero test on loosely reduced values, and both conversions from/to the wire form."""
+    import random
+    from sppark_amd import ffi
+    L = ffi.load("bls12_381")
+    NL = L.sppark_devtest_bucket_field_limbs()
+    assert NL == 14
+    Pm = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    LB = 28; MASK = (1 << LB) - 1; R = 1 << (LB * NL); Rinv = pow(R, Pm - 2, Pm)
+    limbs = lambda v: [(v >> (LB * j)) & MASK if j < NL - 1 else v >> (LB * j) for j in range(NL)]
+    val = lambda l: sum(int(x) << (LB * j) for j, x in enumerate(l))
+    random.seed(7)
+    n = 2048
+
+    def rnd(k):
+        return random.choice([0, 1, Pm - 1, Pm, Pm + 1, 2 * Pm, k * Pm - 1]) if random.random() < 0.06 else random.randrange(k * Pm)
+    A = [rnd(3) for _ in range(n)]; B = [rnd(3) for _ in range(n)]
+    a = np.array([limbs(v) for v in A], dtype=np.uint32); b = np.array([limbs(v) for v in B], dtype=np.uint32)
+    out = np.zeros_like(a)
+
+    def run(op, a_, b_):
+        ffi.check(L, L.sppark_devtest_bucket_field_op(op, P(out), P(a_), P(b_), n))
+        return [val(r) for r in out], out.copy()
+    got, raw = run(0, a, b)
+    assert all(g % Pm == x * y * Rinv % Pm and g <= x * y // R + Pm for g, x, y in zip(got, A, B))
+    assert (raw[:, :NL - 1] <= MASK).all()
+    got, _ = run(1, a, b)
+    assert all(g % Pm == x * x * Rinv % Pm for g, x in zip(got, A))
+
+    def fat(K, Bw):
+        pl = limbs(K * Pm)
+        return [pl[j] + ((Bw << LB) if j < NL - 1 else 0) - (Bw if j > 0 else 0) for j in range(NL)]
+    F = fat(12, 6)
+    C = [random.randrange(11 * Pm) for _ in range(n)]
+    a_fat = np.array([[x + f - y for x, f, y in zip(limbs(A[i]), F, limbs(C[i]))] for i in range(n)], dtype=np.uint32)
+    assert int(a_fat.max()) < (1 << 31)
+    AF = [val(r) for r in a_fat]
+    got, _ = run(0, a_fat, b)                                  # fat left operand
+    assert all(g % Pm == x * y * Rinv % Pm for g, x, y in zip(got, AF, B))
+    B2 = [v % (2 * Pm) for v in B]; b2 = np.array([limbs(v) for v in B2], dtype=np.uint32)
+    got, raw = run(2, a, b2)
+    assert all(g == x + 3 * Pm - y for g, x, y in zip(got, A, B2)) and (raw[:, :NL - 1] <= MASK).all()
+    got, raw = run(3, a, b)
+    assert all(g == x + y for g, x, y in zip(got, A, B)) and (raw[:, :NL - 1] <= MASK).all()
+    Z = [random.choice([0, Pm, 2 * Pm, 5 * Pm, 12 * Pm, 7 * Pm + 1, Pm - 1, random.randrange(13 * Pm),
+                        (random.randrange(13 * Pm) & ~MASK) | ((k * Pm) & MASK)]) for k in range(n)]
+    z = np.array([limbs(v) for v in Z], dtype=np.uint32)
+    _, raw = run(4, z, b)
+    assert all(int(raw[i, 0]) == (1 if Z[i] % Pm == 0 else 0) for i in range(n))
+    # wire form (x * 2^384, 12 words, canonical) <-> internal (x * 2^392)
+    W = [random.choice([0, 1, Pm - 1]) if random.random() < 0.05 else random.randrange(Pm) for _ in range(n)]
+    w = np.zeros((n, NL), dtype=np.uint32)
+    for i, v in enumerate(W):
+        w[i, :12] = [(v >> (32 * k)) & 0xffffffff for k in range(12)]
+    got, raw = run(5, w, b)
+    assert all(g % Pm == v * 256 % Pm and g < 2 * Pm for g, v in zip(got, W)) and (raw[:, :NL - 1] <= MASK).all()
+    _, raw = run(6, a_fat, b)                                  # any admissible lazy value -> canonical wire words
+    inv256 = pow(256, Pm - 2, Pm)
+    for i in range(n):
+        assert sum(int(raw[i, k]) << (32 * k) for k in range(12)) == AF[i] * inv256 % Pm
+
+
+def test_bucket_point_ops_bit_exact_with_wire_class(oracle, libs):
+    """The loosely-reduced XYZZ formulas (ec/xyzzx_dev.hpp), fed and read back in the wire form,
+    give the SAME coordinates bit for bit as the canonical 32-bit-limb class (same formulas,
+    same field elements), including equal, opposite and infinite operands."""
+    from sppark_amd import ffi
+    O = oracle
+    L = ffi.load("bls12_381")
+    curve, fb, n = 0, 48, 96
+    A = O.g1_gen_points(curve, n, 11); B = O.g1_gen_points(curve, n, 12)
+    B[0] = A[0]
+    pmod = O.FP_MODULUS[curve]
+    y = int.from_bytes(A[1, fb:].tobytes(), "little")
+    B[1] = A[1]; B[1, fb:] = np.frombuffer(((pmod - y) % pmod).to_bytes(fb, "little"), dtype=np.uint8)
+    B[2] = 0
+    one = O.field_op(O.FIELD_BLS_FP, 4, O.int_to_limbs(1, fb)).view(np.uint8)
+    xa = np.zeros((n, 4 * fb), dtype=np.uint8); xa[:, :2 * fb] = A; xa[:, 2 * fb:3 * fb] = one; xa[:, 3 * fb:] = one
+    xa[3] = 0
+    # make the accumulators non-trivial (ZZ, ZZZ != 1): a few additions with the wire class first
+    tmp = np.zeros_like(xa)
+    ffi.check(L, L.sppark_devtest_xyzz_op(1, P(tmp), P(xa), P(O.g1_gen_points(curve, n, 13)), n)); xa = tmp.copy()
+    xb = np.zeros_like(xa)
+    ffi.check(L, L.sppark_devtest_xyzz_op(1, P(xb), P(xa), P(O.g1_gen_points(curve, n, 14)), n))
+    xb[0] = xa[0]                                            # equal XYZZ operands -> doubling inside add
+    for op, operand in ((0, xb), (1, B), (2, B), (3, None)):
+        ref = np.zeros_like(xa); got = np.zeros_like(xa)
+        ptr = P(operand) if operand is not None else 0
+        ffi.check(L, L.sppark_devtest_xyzz_op(op, P(ref), P(xa), ptr, n))
+        ffi.check(L, L.sppark_devtest_bucket_xyzz_op(op, P(got), P(xa), ptr, n))
+        assert (got == ref).all(), op
+
+
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_generate_points_matches_oracle(oracle, libs, curve, name):
     """sppark_g1_generate (device double-and-add + host batch normalisation)."""

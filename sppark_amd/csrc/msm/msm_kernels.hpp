@@ -155,13 +155,15 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     // the reduced-radix field (2 waves/SIMD either way, +2 %), not for alt_bn128 (would drop from
     // 4 to 3 waves/SIMD: 53 -> 71 ms) or Fp2.
     constexpr bool PREFETCH = field_is_internal<FP>::value;
-    u32 e_next = 0;
-    affine_dev<FP> pt_next = pt;
+    u32 e_next = 0, e_next2 = 0;                    // the index list runs two entries ahead, so that the
+    affine_dev<FP> pt_next = pt;                    // gather's address never waits for its own load
     if (PREFETCH && p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
+    if (PREFETCH && p + 2 < end) e_next2 = src[p + 2];
     for (p++; p < end; p++) {
         if (PREFETCH) {
             e = e_next; pt = pt_next;
-            if (p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
+            if (p + 1 < end) { e_next = e_next2; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
+            if (p + 2 < end) e_next2 = src[p + 2];
         } else {
             e = src[p];
             pt = load_affine<FP, FLAGGED>(points, e & 0x7fffffffu, stride);

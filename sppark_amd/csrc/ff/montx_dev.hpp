@@ -49,7 +49,6 @@ SPPARK_DEVFN void macxs(u64& acc, u32 a, u32 b)
     acc += (u64)a * b;
 #endif
 }
-SPPARK_DEVFN u32 opaque_sgpr(u32 c) { return c; }
 // two independent multiply-adds in ONE asm statement: hipcc pads every asm statement with an
 // s_nop (it cannot see inside), so pairing halves the padding of the interleaved product pairs
 SPPARK_DEVFN void macx2(u64& acc0, u32 a0, u32 b0, u64& acc1, u32 a1, u32 b1)
@@ -70,8 +69,6 @@ SPPARK_DEVFN void macxs2(u64& acc0, u32 a0, u64& acc1, u32 a1, u32 b)
     acc0 += (u64)a0 * b; acc1 += (u64)a1 * b;
 #endif
 }
-
-#define SPPARK_MODULUS_SGPRS u32 pl[NL]; _Pragma("unroll") for (int j_ = 0; j_ < NL; j_++) pl[j_] = opaque_sgpr(mod_limb(j_))
 
 template<class P, int LB> struct montx_dev {
     static constexpr int NW = P::N;                         // 32-bit words of the standard wire form
@@ -248,7 +245,6 @@ template<class P, int LB> struct montx_dev {
     SPPARK_DEVFN friend montx_dev operator*(const montx_dev& a, const montx_dev& b)
     {
         constexpr u32 PINV = P::M0 & MASK;                  // -1/p mod 2^LB
-        SPPARK_MODULUS_SGPRS;
         u32 m[NL];
         montx_dev r;
         u64 A = 0;
@@ -259,11 +255,11 @@ template<class P, int LB> struct montx_dev {
                 #pragma unroll
                 for (int i = lo; i <= hi; i++) macx(A, a.l[i], b.l[k - i]);
                 #pragma unroll
-                for (int i = lo; i <= hi; i++) if (i < k) macxs(A, m[i], pl[k - i]);   // m[i] known for i < k
+                for (int i = lo; i <= hi; i++) if (i < k) macxs(A, m[i], mod_limb(k - i));   // m[i] known for i < k
             }
             if (k < NL) {
                 m[k] = ((u32)A * PINV) & MASK;
-                macxs(A, m[k], pl[0]);
+                macxs(A, m[k], mod_limb(0));
             } else {
                 r.l[k - NL] = (u32)A & MASK;
             }
@@ -279,7 +275,6 @@ template<class P, int LB> struct montx_dev {
                                   const montx_dev& a1, const montx_dev& b1)
     {
         constexpr u32 PINV = P::M0 & MASK;
-        SPPARK_MODULUS_SGPRS;
         u32 m0[NL], m1[NL];
         u64 A0 = 0, A1 = 0;
         #pragma unroll
@@ -289,11 +284,11 @@ template<class P, int LB> struct montx_dev {
                 #pragma unroll
                 for (int i = lo; i <= hi; i++) macx2(A0, a0.l[i], b0.l[k - i], A1, a1.l[i], b1.l[k - i]);
                 #pragma unroll
-                for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], pl[k - i]);
+                for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], mod_limb(k - i));
             }
             if (k < NL) {
                 m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
-                macxs2(A0, m0[k], A1, m1[k], pl[0]);
+                macxs2(A0, m0[k], A1, m1[k], mod_limb(0));
             } else {
                 r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
             }
@@ -304,7 +299,6 @@ template<class P, int LB> struct montx_dev {
     SPPARK_DEVFN static void sqr2(montx_dev& r0, montx_dev& r1, const montx_dev& a0, const montx_dev& a1)
     {
         constexpr u32 PINV = P::M0 & MASK;
-        SPPARK_MODULUS_SGPRS;
         u32 m0[NL], m1[NL], d0[NL], d1[NL];
         #pragma unroll
         for (int j = 0; j < NL; j++) { d0[j] = a0.l[j] << 1; d1[j] = a1.l[j] << 1; }
@@ -321,11 +315,11 @@ template<class P, int LB> struct montx_dev {
                     else        macx2(A0, a0.l[i], d0[j], A1, a1.l[i], d1[j]);
                 }
                 #pragma unroll
-                for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], pl[k - i]);
+                for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], mod_limb(k - i));
             }
             if (k < NL) {
                 m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
-                macxs2(A0, m0[k], A1, m1[k], pl[0]);
+                macxs2(A0, m0[k], A1, m1[k], mod_limb(0));
             } else {
                 r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
             }
@@ -338,7 +332,6 @@ template<class P, int LB> struct montx_dev {
     SPPARK_DEVFN montx_dev sqr() const
     {
         constexpr u32 PINV = P::M0 & MASK;
-        SPPARK_MODULUS_SGPRS;
         u32 m[NL], d[NL];
         #pragma unroll
         for (int j = 0; j < NL; j++) d[j] = l[j] << 1;
@@ -358,12 +351,12 @@ template<class P, int LB> struct montx_dev {
                 for (int i = 0; i < NL; i++) {
                     const int j = k - i;
                     if (j < 0 || j >= NL || i >= k) continue;
-                    macxs(A, m[i], pl[j]);
+                    macxs(A, m[i], mod_limb(j));
                 }
             }
             if (k < NL) {
                 m[k] = ((u32)A * PINV) & MASK;
-                macxs(A, m[k], pl[0]);
+                macxs(A, m[k], mod_limb(0));
             } else {
                 r.l[k - NL] = (u32)A & MASK;
             }

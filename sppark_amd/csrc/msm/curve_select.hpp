@@ -3,7 +3,6 @@
 #pragma once
 #include "../ff/params.hpp"
 #include "../ff/mont_dev.hpp"
-#include "../ff/mont30_dev.hpp"
 #include "../ff/fp2_dev.hpp"
 #include "../ec/xyzz_dev.hpp"
 #include "../ec/xyzzx_dev.hpp"
@@ -16,16 +15,7 @@ typedef alt_bn128_g1_p curve_p;
 #else
 # error "no FEATURE"
 #endif
-// base-field register class of the bucket kernels: 32-bit limbs (mont_dev.hpp).
-// -DSPPARK_FP30LIMB selects the reduced-radix class (mont30_dev.hpp), kept for A/B
-// measurements: on MI355X it multiplies 5 % faster and squares 34 % faster but its
-// carry-free additions cost more, and the mixed addition comes out 2 % SLOWER
-// (profiles/r01_mont30_vs_mont32.log), so it is not the default.
-#ifdef SPPARK_FP30LIMB
-template<class P> using fp_class = mont30_dev<P>;
-#else
 template<class P> using fp_class = mont_dev<P>;
-#endif
 typedef fp_class<curve_p::fp> fp_d;          // wire-format field: generators, test hooks, conversions
 typedef mont_dev<curve_p::fr> fr_d;
 // coordinate field of the G1 bucket pipeline.  BLS12-381: the loosely-reduced 28-bit-limb

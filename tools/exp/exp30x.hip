@@ -1,4 +1,4 @@
-// Experiment harness for ff/mont30x_dev.hpp (not part of the product libraries).
+// Experiment harness for ff/montx_dev.hpp (not part of the product libraries; results: profiles/r01_montx_vs_mont32.log).
 #include "ff/params.hpp"
 #include "ff/mont_dev.hpp"
 #include "ff/montx_dev.hpp"

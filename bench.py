@@ -275,7 +275,9 @@ def main():
                          "kernel_ms": a_ms,
                          "note": "MSM is integer-multiplier bound, not HBM bound (SURVEY F11): the kernel does "
                                  "%d mixed additions per launch = %.3e additions/s against 7.29e9/s for the same "
-                                 "addition chain on registers (profiles/r01_montx_vs_mont32.log)"
+                                 "addition chain on registers (profiles/r01_montx_vs_mont32.log); rocprofv3 PMC: the vector ALU "
+                                 "issues 83 %% of the kernel's cycles, instruction-cache hit rate > 99.999 %% "
+                                 "(profiles/r01_accumulate_pmc.txt)"
                                  % (nwins * n, nwins * n / (a_ms * 1e-3)) + traffic_note},
             "phases_ms": {"digits_sort": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
             "cpu_baseline": cpu, "ntt": ntt, "extras": extras,

@@ -529,3 +529,35 @@ def test_concurrent_contexts_and_ntt(oracle, libs):
     for t in threads: t.start()
     for t in threads: t.join()
     assert not errors, errors
+
+
+def test_msm_randomised_plans_and_inputs(oracle, libs):
+    """Randomised stress of the whole pipeline (sort split, run length, fan-in, bucket chunking,
+    window width) on inputs with repeated points, repeated scalars, zeros, r-1 and infinities:
+    every result must equal the oracle's.  Exercises the loosely-reduced field's bounds on many
+    different addition orders."""
+    import sppark_amd
+    O = oracle
+    rng = np.random.default_rng(2024)
+    ctxs = {name: sppark_amd.MsmContext(name) for _, name in CURVES}
+    for it in range(60):
+        curve, name = CURVES[it % 2]
+        n = int(rng.choice([1, 2, 5, 33, 100, 257, 1000, 3000, 6000]))
+        nd = int(rng.choice([1, 2, 7, 64, 512]))
+        flagged = bool(rng.integers(0, 2))
+        pts, sc = recipe.msm_inputs(curve, n, 5000 + it, ndistinct=nd, flagged=flagged, edge=bool(rng.integers(0, 2)))
+        mode = int(rng.integers(0, 5))
+        if mode == 1: sc[:] = sc[0]
+        elif mode == 2: sc[rng.integers(0, 2, size=n).astype(bool)] = 0
+        elif mode == 3: sc[:, 2:] = 0
+        elif mode == 4 and n > 4: sc[: n // 2] = sc[n // 2: 2 * (n // 2)]
+        ctx = ctxs[name]
+        wb = int(rng.choice([0, 0, 3, 6, 9, 13, 17, 21]))
+        ctx.tune(wbits=wb, L=int(rng.choice([0, 4, 16, 64])), F=int(rng.choice([0, 4, 8, 32])),
+                 K=int(rng.choice([0, 2, 8])), nslabs=int(rng.choice([0, 1, 3])))
+        ctx.tune_sort(int(rng.choice([0, 0, 1, 4])))
+        out = ctx.invoke(pts, sc, ffi_affine_sz=pts.shape[1])
+        exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
+        assert (sppark_amd.to_affine(out, name) == exp).all(), (it, name, n, nd, flagged, mode, wb)
+    for c in ctxs.values():
+        c.close()

@@ -189,163 +189,3 @@ SPPARK_FFI RustError sppark_devtest_bucket_xyzz_op(int op, void* out, const void
         (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);
     });
 }
-
-// ---------------------------------------------------------------------------
-// micro-benchmarks: every wave runs |iters| iterations of a fixed instruction
-// block and reports its own s_memtime delta; the host also times the launch.
-// ---------------------------------------------------------------------------
-#define UB_REP8(x) x x x x x x x x
-
-// WHICH is a template parameter so that the timed loop contains nothing but the
-// instruction block (a runtime switch inside the loop dominated the first version).
-template<int WHICH>
-__global__ void k_ub(int iters, u64* clocks, u32* sink)
-{
-    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 977u;
-    u64 acc0 = a, acc1 = b, acc2 = a ^ b, acc3 = a + b, acc4 = 1, acc5 = 2, acc6 = 3, acc7 = 4;
-    u32 c0 = 0, c1 = 0, c2 = 1, c3 = 2;
-    double f0 = a, f1 = b, f2 = 1.0000001, f3 = 3, f4 = 5, f5 = 7, f6 = 9, f7 = 11;
-    u64 t0 = __builtin_readcyclecounter();
-    #pragma unroll 1
-    for (int i = 0; i < iters; i++) {
-        if (WHICH == 0)         // 8 independent v_mad_u64_u32, each with its own carry SGPR pair
-            asm volatile(
-                "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n\tv_mad_u64_u32 %1, s[22:23], %8, %9, %1\n\t"
-                "v_mad_u64_u32 %2, s[24:25], %8, %9, %2\n\tv_mad_u64_u32 %3, s[26:27], %8, %9, %3\n\t"
-                "v_mad_u64_u32 %4, s[20:21], %8, %9, %4\n\tv_mad_u64_u32 %5, s[22:23], %8, %9, %5\n\t"
-                "v_mad_u64_u32 %6, s[24:25], %8, %9, %6\n\tv_mad_u64_u32 %7, s[26:27], %8, %9, %7"
-                : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(acc4), "+v"(acc5), "+v"(acc6), "+v"(acc7)
-                : "v"(a), "v"(b) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
-        else if (WHICH == 1)    // 8 dependent v_mad_u64_u32
-            asm volatile(UB_REP8("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t") : "+v"(acc0) : "v"(a), "v"(b) : "vcc");
-        else if (WHICH == 2)    // 8 dependent mad + addc pairs (the mac96 primitive)
-            asm volatile(UB_REP8("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t")
-                         : "+v"(acc0), "+v"(c0) : "v"(a), "v"(b) : "vcc");
-        else if (WHICH == 3)    // 4 independent mad + addc chains x 2
-            asm volatile(
-                "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
-                "v_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
-                "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
-                "v_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
-                "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
-                "v_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_addc_co_u32 %5, vcc, 0, %5, vcc\n\t"
-                "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
-                "v_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_addc_co_u32 %7, vcc, 0, %7, vcc"
-                : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-                : "v"(a), "v"(b) : "vcc");
-        else if (WHICH == 4)    // 8 dependent v_mul_lo_u32
-            asm volatile(UB_REP8("v_mul_lo_u32 %0, %0, %1\n\t") : "+v"(c0) : "v"(a));
-        else if (WHICH == 5)    // 8 independent v_mul_lo_u32 (4 chains x 2)
-            asm volatile(
-                "v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4\n\t"
-                "v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4"
-                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a));
-        else if (WHICH == 6)    // 8 independent v_mad_u32_u24 (4 chains x 2)
-            asm volatile(
-                "v_mad_u32_u24 %0, %0, %4, %0\n\tv_mad_u32_u24 %1, %1, %4, %1\n\tv_mad_u32_u24 %2, %2, %4, %2\n\tv_mad_u32_u24 %3, %3, %4, %3\n\t"
-                "v_mad_u32_u24 %0, %0, %4, %0\n\tv_mad_u32_u24 %1, %1, %4, %1\n\tv_mad_u32_u24 %2, %2, %4, %2\n\tv_mad_u32_u24 %3, %3, %4, %3"
-                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a));
-        else if (WHICH == 7)    // 8 independent v_add_u32 (4 chains x 2)
-            asm volatile(
-                "v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t"
-                "v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4"
-                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a));
-        else if (WHICH == 8)    // 8 dependent v_add_u32
-            asm volatile(UB_REP8("v_add_u32 %0, %0, %1\n\t") : "+v"(c0) : "v"(a));
-        else if (WHICH == 9)    // 8 independent v_fma_f64
-            asm volatile(
-                "v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t"
-                "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9"
-                : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(1.0000001), "v"(0.5));
-        else if (WHICH == 10)   // 8 dependent v_fma_f64
-            asm volatile(UB_REP8("v_fma_f64 %0, %0, %1, %2\n\t") : "+v"(f0) : "v"(1.0000001), "v"(0.5));
-        else if (WHICH == 11)   // 8 independent v_lshl_add_u64
-            asm volatile(
-                "v_lshl_add_u64 %0, %0, 0, %4\n\tv_lshl_add_u64 %1, %1, 0, %4\n\tv_lshl_add_u64 %2, %2, 0, %4\n\tv_lshl_add_u64 %3, %3, 0, %4\n\t"
-                "v_lshl_add_u64 %0, %0, 0, %4\n\tv_lshl_add_u64 %1, %1, 0, %4\n\tv_lshl_add_u64 %2, %2, 0, %4\n\tv_lshl_add_u64 %3, %3, 0, %4"
-                : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : "v"(acc4));
-        else if (WHICH == 12)   // 8 independent add_co+addc pairs (64-bit adds, 4 chains x 2)
-            asm volatile(
-                "v_add_co_u32 %0, vcc, %0, %4\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_add_co_u32 %2, vcc, %2, %4\n\tv_addc_co_u32 %3, vcc, %3, %4, vcc\n\t"
-                "v_add_co_u32 %0, vcc, %0, %4\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_add_co_u32 %2, vcc, %2, %4\n\tv_addc_co_u32 %3, vcc, %3, %4, vcc"
-                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a) : "vcc");
-        else if (WHICH == 13)   // 8 independent v_mul_hi_u32
-            asm volatile(
-                "v_mul_hi_u32 %0, %0, %4\n\tv_mul_hi_u32 %1, %1, %4\n\tv_mul_hi_u32 %2, %2, %4\n\tv_mul_hi_u32 %3, %3, %4\n\t"
-                "v_mul_hi_u32 %0, %0, %4\n\tv_mul_hi_u32 %1, %1, %4\n\tv_mul_hi_u32 %2, %2, %4\n\tv_mul_hi_u32 %3, %3, %4"
-                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a));
-    }
-    u64 t1 = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
-    u64 s = acc0 ^ acc1 ^ acc2 ^ acc3 ^ acc4 ^ acc5 ^ acc6 ^ acc7 ^ c0 ^ c1 ^ c2 ^ c3 ^ (u64)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
-    if (s == 0x123456789abcdefULL) sink[0] = (u32)s;
-}
-
-typedef void (*ub_fn)(int, u64*, u32*);
-static ub_fn ub_table[] = { k_ub<0>, k_ub<1>, k_ub<2>, k_ub<3>, k_ub<4>, k_ub<5>, k_ub<6>, k_ub<7>, k_ub<8>,
-                            k_ub<9>, k_ub<10>, k_ub<11>, k_ub<12>, k_ub<13> };
-
-// returns elapsed ms; *cycles_per_iter = mean cycle-counter delta per iteration over waves
-SPPARK_FFI RustError sppark_devtest_ubench(int which, int iters, unsigned blocks, unsigned threads,
-                                           float* ms, double* cycles_per_iter)
-{
-    return guarded([&] {
-        (void)select_gpu(-1);
-        if (which < 0 || which >= (int)(sizeof(ub_table) / sizeof(ub_table[0]))) HIP_OK(hipErrorInvalidValue);
-        size_t nw = (size_t)blocks * threads / 64;
-        u64* d_clk; u32* d_sink;
-        HIP_OK(hipMalloc((void**)&d_clk, nw * 8)); HIP_OK(hipMalloc((void**)&d_sink, 64));
-        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(ub_table[which], dim3(blocks), dim3(threads), 0, 0, 16, d_clk, d_sink);   // warm-up
-        HIP_OK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(ub_table[which], dim3(blocks), dim3(threads), 0, 0, iters, d_clk, d_sink);
-        HIP_OK(hipEventRecord(e1, 0));
-        HIP_OK(hipEventSynchronize(e1));
-        HIP_OK(hipEventElapsedTime(ms, e0, e1));
-        std::vector<u64> clk(nw);
-        HIP_OK(hipMemcpy(clk.data(), d_clk, nw * 8, hipMemcpyDeviceToHost));
-        double sum = 0; for (auto c : clk) sum += (double)c;
-        *cycles_per_iter = sum / nw / iters;
-        (void)hipFree(d_clk); (void)hipFree(d_sink); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    });
-}
-
-// field-level throughput: x = x*y (op 0), x = x.sqr() (1), x = x+y (2), xyzz madd (3), xyzz add (4)
-__global__ void k_fieldbench(int op, int iters, u32* io)
-{
-    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 wx[fp_d::N], wy[fp_d::N];
-    for (int k = 0; k < fp_d::N; k++) { wx[k] = io[k] ^ (i * 2654435761u >> 3); wy[k] = io[k + fp_d::N] + i; }
-    wx[fp_d::N - 1] &= 0x0fffffff; wy[fp_d::N - 1] &= 0x0fffffff;
-    fp_d x = fp_d::from_wire(wx), y = fp_d::from_wire(wy);
-    if (op <= 2) {
-        for (int it = 0; it < iters; it++) {
-            if (op == 0) x = x * y; else if (op == 1) x = x.sqr(); else x = x + y;
-        }
-        if (x.is_zero()) io[0] = 1;
-    } else {
-        wire_bucket_d p; p.X = x; p.Y = y; p.ZZ = y; p.ZZZ = x;
-        affine_dev<fp_d> q; q.X = y; q.Y = x; q.inf = false;
-        wire_bucket_d r = p; r.X = y;
-        for (int it = 0; it < iters; it++) {
-            if (op == 3) p.madd(q, it & 1); else p.add(r);
-        }
-        if (p.X.is_zero()) io[0] = 1;
-    }
-}
-
-SPPARK_FFI RustError sppark_devtest_fieldbench(int op, int iters, unsigned blocks, unsigned threads, float* ms)
-{
-    return guarded([&] {
-        (void)select_gpu(-1);
-        u32* d_io; HIP_OK(hipMalloc((void**)&d_io, 4096)); HIP_OK(hipMemset(d_io, 0x5a, 4096));
-        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k_fieldbench, dim3(blocks), dim3(threads), 0, 0, op, 2, d_io);
-        HIP_OK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_fieldbench, dim3(blocks), dim3(threads), 0, 0, op, iters, d_io);
-        HIP_OK(hipEventRecord(e1, 0));
-        HIP_OK(hipEventSynchronize(e1));
-        HIP_OK(hipEventElapsedTime(ms, e0, e1));
-        (void)hipFree(d_io); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    });
-}

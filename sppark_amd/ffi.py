@@ -107,11 +107,6 @@ def load(name):
         L.sppark_devtest_bucket_xyzz_op.restype = _Error
         L.sppark_devtest_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
         L.sppark_devtest_xyzz_op.restype = _Error
-        L.sppark_devtest_ubench.argtypes = [ci, ci, cu, cu, ctypes.POINTER(ctypes.c_float),
-                                            ctypes.POINTER(ctypes.c_double)]
-        L.sppark_devtest_ubench.restype = _Error
-        L.sppark_devtest_fieldbench.argtypes = [ci, ci, cu, cu, ctypes.POINTER(ctypes.c_float)]
-        L.sppark_devtest_fieldbench.restype = _Error
     if name in NTT_FIELDS or name in CURVES:
         L.compute_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci]
         L.compute_ntt.restype = _Error

@@ -140,12 +140,14 @@ SPPARK_DEVFN ntt_tile_geom ntt_geom(const ntt_pass& P, size_t tile_id)
     }
     return g;
 }
-// LDS index of tile row gm (= g*2^S + mid), column c.  One pad row (C elements
-// = 32 banks) per 2^R2 rows: in the strided round two consecutive values of `a`
-// then land on opposite halves of the 64 banks instead of on the same ones.
+// LDS index of tile row gm (= g*2^S + mid), column c.  Adjacent rows are swapped when bit R2 of
+// the row number is set: in the strided round two consecutive values of `a` then land on
+// opposite halves of the 64 banks instead of on the same ones, without the pad rows that an
+// offset-based scheme needs -- a 2^12-element Goldilocks tile is exactly 32 KB, so five
+// work-groups (instead of four) share a CU's 160 KB.
 template<unsigned R2>
 SPPARK_DEVFN unsigned ntt_lds_index(unsigned gm, unsigned c, unsigned lgC)
-{   return ((gm + (gm >> R2)) << lgC) + c;   }
+{   return ((gm ^ ((gm >> R2) & 1u)) << lgC) + c;   }
 
 // A work group of the HIGH-bits round: fixed (g, b, c), the 2^R1 values of a.
 // A work group of the LOW-bits round:  fixed (g, a, c), the 2^R2 values of b.
@@ -298,13 +300,12 @@ void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
         case 5: CALL(3, 2); break; default: CALL(3, 3); break;          \
     }
 
-// LDS elements a tile needs (with the pad words of ntt_lds_index)
+// LDS elements a tile needs
 static inline size_t ntt_lds_elems(const ntt_pass& P)
 {
     unsigned R2 = P.S / 2;
     if (R2 == 0) return 0;
-    size_t rows = (size_t)1 << (P.lgG + P.S);
-    return (rows + (rows >> R2)) << P.lgC;
+    return (size_t)1 << (P.lgG + P.S + P.lgC);
 }
 
 // bit-reversal permutation in place (NN and RR orders; ntt/ntt.cuh:44-79)

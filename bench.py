@@ -123,8 +123,13 @@ def main():
             e2.record(); torch.cuda.synchronize()
             fwd += e0.elapsed_time(e1); inv += e1.elapsed_time(e2)
         fwd /= reps; inv /= reps
+        e0.record()
+        for _ in range(reps):
+            sppark_amd.NTT(0, x, Ord.NN, "gl64", stream=stream)      # natural in, natural out (adds the bit reversal)
+        e1.record(); torch.cuda.synchronize()
+        fwd_nn = e0.elapsed_time(e1) / reps
         ntt = {"metric": "Goldilocks NTT 2^%d elements/s (forward NR / inverse RN, device-resident)" % lg,
-               "forward_ms": fwd, "inverse_ms": inv,
+               "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
                "forward_elems_per_s": (1 << lg) / (fwd * 1e-3), "inverse_elems_per_s": (1 << lg) / (inv * 1e-3),
                "pair_elems_per_s": (1 << lg) / ((fwd + inv) * 1e-3),
                "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9,

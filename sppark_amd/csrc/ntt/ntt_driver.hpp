@@ -123,7 +123,7 @@ public:
 
         bool bitrev, gs;
         switch (order) {
-            case NTT_NN: hipLaunchKernelGGL(k_bitrev<F>, dim3(egrid), dim3(256), 0, stream, d, lg);
+            case NTT_NN: bit_reverse(d, lg, stream);
                          bitrev = true;  gs = false; break;
             case NTT_NR: bitrev = false; gs = true;  break;
             case NTT_RN: bitrev = true;  gs = false; break;
@@ -164,8 +164,21 @@ public:
         if (inverse && type == NTT_COSET)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)!bitrev);
         if (order == NTT_RR)
-            hipLaunchKernelGGL(k_bitrev<F>, dim3(egrid), dim3(256), 0, stream, d, lg);
+            bit_reverse(d, lg, stream);
         HIP_OK(hipGetLastError());
+    }
+
+    // in-place bit-reversal permutation (NN and RR orders; ntt/ntt.cuh:44-79)
+    static void bit_reverse(F* d, unsigned lg, hipStream_t stream)
+    {
+        constexpr unsigned TB = bitrev_tile_bits<F>::value;
+        const size_t n = (size_t)1 << lg;
+        if (lg >= 2 * TB + 1) {
+            size_t lds = 2 * (((size_t)(1u << TB) + 1) << TB) * sizeof(F);
+            hipLaunchKernelGGL((k_bitrev_tiled<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
+        } else {
+            hipLaunchKernelGGL(k_bitrev<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d, lg);
+        }
     }
 
     // d_inout[idx] *= g^(rev(idx))   (NTT::LDE_powers(stream, d_inout, lg), ntt/ntt.cuh:352-356)

@@ -323,6 +323,52 @@ __global__ __launch_bounds__(256) void k_bitrev(F* data, unsigned lg_n)
     if (i < ((size_t)1 << lg_n)) bitrev_item(data, lg_n, i);
 }
 
+// Tiled in-place bit reversal.  Index = (hi | mid | lo) with TB bits of hi and lo; its
+// reversal is (rev lo | rev mid | rev hi), so the 2^TB x 2^TB tile of one `mid` maps onto the
+// tile of rev(mid) with rows and columns exchanged: both tiles are read and written as rows of
+// 2^TB consecutive elements (coalesced), the transposition happens in LDS.  One work-group per
+// pair {mid, rev mid} (the larger one of a pair returns immediately).  The element-wise kernel
+// above reads and writes single elements at bit-reversed addresses and costs as much as the
+// whole transform at 2^24.
+template<unsigned TB> SPPARK_DEVFN unsigned bitrev_lds_index(unsigned row, unsigned col)
+{   return row * ((1u << TB) + 1) + col;   }          // one pad element per row: column reads spread over banks
+
+template<class F, unsigned TB>
+SPPARK_DEVFN void bitrev_tile_item(F* data, F* ldsA, F* ldsB, unsigned lg_n, size_t mid, unsigned tid, unsigned nt, int phase)
+{
+    const unsigned lg_mid = lg_n - 2 * TB, T = 1u << TB;
+    size_t rmid = 0;
+    for (unsigned k = 0; k < lg_mid; k++) rmid |= ((mid >> k) & 1) << (lg_mid - 1 - k);
+    if (mid > rmid) return;
+    const bool pair = mid != rmid;
+    if (phase == 0) {                                   // rows of the two tiles -> LDS
+        for (unsigned e = tid; e < T * T; e += nt) {
+            const unsigned hi = e >> TB, lo = e & (T - 1);
+            ldsA[bitrev_lds_index<TB>(hi, lo)] = data[((size_t)hi << (lg_n - TB)) | (mid << TB) | lo];
+            if (pair) ldsB[bitrev_lds_index<TB>(hi, lo)] = data[((size_t)hi << (lg_n - TB)) | (rmid << TB) | lo];
+        }
+    } else {                                            // LDS -> rows of the partner tile, transposed + reversed
+        for (unsigned e = tid; e < T * T; e += nt) {
+            const unsigned r = e >> TB, q = e & (T - 1);                        // destination row / column
+            const unsigned lo = bit_rev32(r, TB), hi = bit_rev32(q, TB);        // source coordinates
+            data[((size_t)r << (lg_n - TB)) | (rmid << TB) | q] = ldsA[bitrev_lds_index<TB>(hi, lo)];
+            if (pair) data[((size_t)r << (lg_n - TB)) | (mid << TB) | q] = ldsB[bitrev_lds_index<TB>(hi, lo)];
+        }
+    }
+}
+template<class F, unsigned TB>
+__global__ __launch_bounds__(256) void k_bitrev_tiled(F* data, unsigned lg_n)
+{
+    extern __shared__ unsigned char bitrev_lds[];
+    F* ldsA = reinterpret_cast<F*>(bitrev_lds);
+    F* ldsB = ldsA + (((1u << TB) + 1) << TB);
+    bitrev_tile_item<F, TB>(data, ldsA, ldsB, lg_n, blockIdx.x, threadIdx.x, blockDim.x, 0);
+    __syncthreads();
+    bitrev_tile_item<F, TB>(data, ldsA, ldsB, lg_n, blockIdx.x, threadIdx.x, blockDim.x, 1);
+}
+// tile edge (bits): rows of >= 256 bytes, two tiles within 64 KB of LDS
+template<class F> struct bitrev_tile_bits { static constexpr unsigned value = sizeof(F) <= 4 ? 6 : sizeof(F) <= 8 ? 5 : 4; };
+
 // coset scaling a[i] *= g^(bitrev ? rev(i) : i)   (LDE_distribute_powers, ntt/kernels.cu:131-153)
 template<class F>
 SPPARK_DEVFN void coset_item(F* data, const ntt_tables<F>& G, int bitrev, size_t i)

@@ -40,6 +40,22 @@ static F group_gen() { F g = F::one(); F one = F::one(); for (unsigned i = 1; i 
 static F top_root() { uint64_t e[4]; for (int i = 0; i < 4; i++) e[i] = FRP::MOD64[i]; e[0] -= 1; return pow_big(group_gen(), e, FRP::TWO_ADICITY); }
 #endif
 
+// ntt_engine::bit_reverse with the tile kernel's two phases run on the host
+static void emu_bitrev(F* d, unsigned lg)
+{
+    constexpr unsigned TB = bitrev_tile_bits<F>::value;
+    const size_t n = (size_t)1 << lg;
+    if (lg >= 2 * TB + 1) {
+        std::vector<F> lds(2 * (((size_t)(1u << TB) + 1) << TB));
+        F* A = lds.data(); F* B = A + (((1u << TB) + 1) << TB);
+        for (size_t mid = 0; mid < (n >> (2 * TB)); mid++)
+            for (int phase = 0; phase < 2; phase++)
+                for (unsigned tid = 0; tid < 256; tid++) bitrev_tile_item<F, TB>(d, A, B, lg, mid, tid, 256, phase);
+    } else {
+        for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i);
+    }
+}
+
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
     if (lg == 0) return 0;
@@ -61,7 +77,7 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
 
     bool bitrev, gs;
     switch (order) {
-        case 0: for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i); bitrev = true; gs = false; break;
+        case 0: emu_bitrev(d, lg); bitrev = true; gs = false; break;
         case 1: bitrev = false; gs = true; break;
         case 2: bitrev = true; gs = false; break;
         default: bitrev = true; gs = true; break;
@@ -93,7 +109,7 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
         }
     }
     if (inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)!bitrev, i);
-    if (order == 3) for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i);
+    if (order == 3) emu_bitrev(d, lg);
     return 0;
 }
 

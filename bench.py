@@ -116,13 +116,16 @@ def main():
         assert torch.equal(x, ref), "NTT round trip failed"
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         reps = 20
-        fwd = inv = 0.0
+        # forward NR transforms back to back, then inverse RN ones (HIP events on the launch stream);
+        # x goes through reps forward + reps inverse transforms and ends where it started
+        e0.record()
         for _ in range(reps):
-            e0.record(); sppark_amd.NTT(0, x, Ord.NR, "gl64", stream=stream)
-            e1.record(); sppark_amd.iNTT(0, x, Ord.RN, "gl64", stream=stream)
-            e2.record(); torch.cuda.synchronize()
-            fwd += e0.elapsed_time(e1); inv += e1.elapsed_time(e2)
-        fwd /= reps; inv /= reps
+            sppark_amd.NTT(0, x, Ord.NR, "gl64", stream=stream)
+        e1.record()
+        for _ in range(reps):
+            sppark_amd.iNTT(0, x, Ord.RN, "gl64", stream=stream)
+        e2.record(); torch.cuda.synchronize()
+        fwd = e0.elapsed_time(e1) / reps; inv = e1.elapsed_time(e2) / reps
         e0.record()
         for _ in range(reps):
             sppark_amd.NTT(0, x, Ord.NN, "gl64", stream=stream)      # natural in, natural out (adds the bit reversal)

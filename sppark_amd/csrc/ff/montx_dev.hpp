@@ -14,8 +14,8 @@
 //     < (ka*kb*p/R + 1)*p; a + b adds the bounds; a - b is a + K*p - b where K*p is written
 //     with "fat" limbs that dominate b's limbs one by one.  No conditional subtraction and
 //     no carry chain on the fast path of a point addition;
-//   * the head-room inside the accumulator (2^64 / (28 * 2^56) = 2^3.2) lets ONE operand of
-//     a product be un-normalised (limbs < 2^30, i.e. the direct result of one lazy add/sub);
+//   * the head-room inside the accumulator (2^64 / (28 * 2^56) = 2^3.2) lets the LEFT operand
+//     of a product be un-normalised (limbs < 2^31, i.e. the direct result of a lazy add/sub);
 //     norm() (3 instructions per limb) is needed only before squaring such a value or
 //     multiplying two of them.
 //

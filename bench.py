@@ -118,20 +118,23 @@ def main():
         reps = 20
         # forward NR transforms back to back, then inverse RN ones (HIP events on the launch stream);
         # x goes through reps forward + reps inverse transforms and ends where it started
-        e0.record()
-        for _ in range(reps):
-            sppark_amd.NTT(0, x, Ord.NR, "gl64", stream=stream)
-        e1.record()
-        for _ in range(reps):
-            sppark_amd.iNTT(0, x, Ord.RN, "gl64", stream=stream)
-        e2.record(); torch.cuda.synchronize()
-        fwd = e0.elapsed_time(e1) / reps; inv = e1.elapsed_time(e2) / reps
+        fwd = inv = 1e30
+        for _batch in range(3):                                 # best of 3 batches: the section starts right after
+            e0.record()                                         # two seconds of MSM load, clocks settle during the first
+            for _ in range(reps):
+                sppark_amd.NTT(0, x, Ord.NR, "gl64", stream=stream)
+            e1.record()
+            for _ in range(reps):
+                sppark_amd.iNTT(0, x, Ord.RN, "gl64", stream=stream)
+            e2.record(); torch.cuda.synchronize()
+            fwd = min(fwd, e0.elapsed_time(e1) / reps); inv = min(inv, e1.elapsed_time(e2) / reps)
         e0.record()
         for _ in range(reps):
             sppark_amd.NTT(0, x, Ord.NN, "gl64", stream=stream)      # natural in, natural out (adds the bit reversal)
         e1.record(); torch.cuda.synchronize()
         fwd_nn = e0.elapsed_time(e1) / reps
         ntt = {"metric": "Goldilocks NTT 2^%d elements/s (forward NR / inverse RN, device-resident)" % lg,
+               "timing": "HIP events around 20 back-to-back transforms, best of 3 batches",
                "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
                "forward_elems_per_s": (1 << lg) / (fwd * 1e-3), "inverse_elems_per_s": (1 << lg) / (inv * 1e-3),
                "pair_elems_per_s": (1 << lg) / ((fwd + inv) * 1e-3),

@@ -159,7 +159,10 @@ public:
         : gpu(&select_gpu(device_id)), stream(s), own_stream(false)
     {
         if (stream == nullptr) {
-            HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            // a BLOCKING stream: it orders itself after work already queued on the legacy default
+            // stream (where most callers, PyTorch included, produce device-resident inputs);
+            // callers working on other streams pass theirs explicitly
+            HIP_OK(hipStreamCreate(&stream));
             own_stream = true;
         }
     }

@@ -21,10 +21,10 @@ typedef fr256_dev<alt_bn128_fr_p> ntt_fr_t;
 
 // The pass kernels are instantiated in their own translation units (ntt/k_ntt_pass.hip,
 // compiled once with -DSPPARK_NTT_DIF=1 and once with =0) so that the library builds in
-// parallel: for the 256-bit fields one unit with all of them takes minutes.
-#define SPPARK_NTT_PASS_SET(X, DIF, INV)                                                          \
-    X(DIF, INV, 1, 0) X(DIF, INV, 1, 1) X(DIF, INV, 2, 1) X(DIF, INV, 2, 2) X(DIF, INV, 3, 2) X(DIF, INV, 3, 3)
-#define SPPARK_NTT_PASS_SET_BIG(X, DIF, INV) X(DIF, INV, 4, 3) X(DIF, INV, 4, 4)
+// parallel: for the 256-bit fields one unit with all of them takes minutes.  The 256-bit fields
+// use at most 4 stages per pass (radix-4 x radix-4 in registers), the single-word fields up to 8.
+#define SPPARK_NTT_PASS_SET(X, DIF, INV) X(DIF, INV, 1, 0) X(DIF, INV, 1, 1) X(DIF, INV, 2, 1) X(DIF, INV, 2, 2)
+#define SPPARK_NTT_PASS_SET_BIG(X, DIF, INV) X(DIF, INV, 3, 2) X(DIF, INV, 3, 3) X(DIF, INV, 4, 3) X(DIF, INV, 4, 4)
 #define SPPARK_NTT_PASS_ALL(X, DIF)                                                               \
     SPPARK_NTT_PASS_SET(X, DIF, false) SPPARK_NTT_PASS_SET(X, DIF, true)
 #define SPPARK_NTT_PASS_ALL_BIG(X, DIF)                                                           \

@@ -72,13 +72,14 @@ class ntt_engine {
     std::map<std::tuple<int, unsigned, int>, table_set> cache;     // (hip device, lg, inverse)
     std::mutex mtx;
 
-    // elements per 128-byte line / per 32 KB LDS tile
-    static constexpr unsigned LG_LINE = sizeof(F) == 4 ? 5 : sizeof(F) == 8 ? 4 : 2;
+    // columns per tile row (single-word fields: one 128-byte line; 256-bit fields: 16 elements =
+    // 512 bytes, so that a 4-stage tile still has 64 register sub-transforms) / elements per LDS tile
+    static constexpr unsigned LG_LINE = sizeof(F) == 4 ? 5 : sizeof(F) == 8 ? 4 : 4;
     static constexpr unsigned LG_TILE = sizeof(F) == 4 ? 13 : sizeof(F) == 8 ? 12 : 10;
-    // stages per pass.  For 256-bit elements hipcc keeps the 16-element arrays of a radix-16
-    // round in scratch memory (528 B/lane) and the radix-16 instantiations dominate the
-    // library's compile time, so wide fields stop at radix-8 rounds (6 stages per pass).
-    static constexpr unsigned S_MAX = sizeof(F) > 8 ? 6 : 8;
+    // stages per pass.  256-bit elements: radix-4 x radix-4 (S = 4).  Larger register radices keep
+    // 8 or 16 eight-word elements per lane (152 VGPRs, scratch) and measured slower in spite of
+    // fewer passes: 2^24 in 2.8 ms with S = 4, 3.3 ms with S = 6 (tools/gpu_ntt_wide_knobs.py).
+    static constexpr unsigned S_MAX = sizeof(F) > 8 ? 4 : 8;
 
     const table_set& tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
     {
@@ -145,6 +146,10 @@ public:
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);
             size_t lds = ntt_lds_elems(P) * sizeof(F);
+            // one lane per register sub-transform: a tile has 2^(lgG + R1 + lgC) of them in its
+            // larger round (small tiles of wide elements would leave most of 256 lanes idle)
+            const unsigned groups = 1u << (P.lgG + (P.S + 1) / 2 + P.lgC);
+            const unsigned nthr = groups >= 256 ? 256 : groups <= 64 ? 64 : groups;
 #define SPPARK_NTT_LAUNCH(R1, R2)                                                                              \
             do {                                                                                               \
                 if (lds > 65536) {                                                                             \
@@ -152,13 +157,13 @@ public:
                                         : (inverse ? (const void*)k_ntt_pass<F, false, true, R1, R2> : (const void*)k_ntt_pass<F, false, false, R1, R2>); \
                     HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
                 }                                                                                              \
-                if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, true, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);   \
-                          else         hipLaunchKernelGGL((k_ntt_pass<F, true, false, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P); } \
-                else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, false, true, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P);  \
-                          else         hipLaunchKernelGGL((k_ntt_pass<F, false, false, R1, R2>), dim3(tiles), dim3(256), lds, stream, d, T, P); } \
+                if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, true, true, R1, R2>), dim3(tiles), dim3(nthr), lds, stream, d, T, P);   \
+                          else         hipLaunchKernelGGL((k_ntt_pass<F, true, false, R1, R2>), dim3(tiles), dim3(nthr), lds, stream, d, T, P); } \
+                else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass<F, false, true, R1, R2>), dim3(tiles), dim3(nthr), lds, stream, d, T, P);  \
+                          else         hipLaunchKernelGGL((k_ntt_pass<F, false, false, R1, R2>), dim3(tiles), dim3(nthr), lds, stream, d, T, P); } \
             } while (0)
             if constexpr (S_MAX >= 8) { SPPARK_NTT_DISPATCH_S(P.S, SPPARK_NTT_LAUNCH); }
-            else                      { SPPARK_NTT_DISPATCH_S6(P.S, SPPARK_NTT_LAUNCH); }
+            else                      { SPPARK_NTT_DISPATCH_S4(P.S, SPPARK_NTT_LAUNCH); }
 #undef SPPARK_NTT_LAUNCH
         }
         if (inverse && type == NTT_COSET)

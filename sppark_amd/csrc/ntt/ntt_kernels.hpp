@@ -292,12 +292,11 @@ void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
         case 7: CALL(4, 3); break; default: CALL(4, 4); break;          \
     }
 
-// the same for at most 6 stages per pass (wide fields)
-#define SPPARK_NTT_DISPATCH_S6(S, CALL)                                 \
+// the same for at most 4 stages per pass (wide fields)
+#define SPPARK_NTT_DISPATCH_S4(S, CALL)                                 \
     switch (S) {                                                        \
         case 1: CALL(1, 0); break; case 2: CALL(1, 1); break;           \
-        case 3: CALL(2, 1); break; case 4: CALL(2, 2); break;           \
-        case 5: CALL(3, 2); break; default: CALL(3, 3); break;          \
+        case 3: CALL(2, 1); break; default: CALL(2, 2); break;          \
     }
 
 // LDS elements a tile needs

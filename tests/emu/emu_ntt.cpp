@@ -28,7 +28,7 @@ typedef bls12_381_fr_p FRP;
 typedef alt_bn128_fr_p FRP;
 # endif
 typedef fr256_dev<FRP> F;
-static const unsigned LG_LINE = 2, LG_TILE = 10;
+static const unsigned LG_LINE = 4, LG_TILE = 10;
 static F pow_big(F b, const uint64_t* e, unsigned from_bit)
 {
     F r = F::one();
@@ -85,7 +85,7 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     if (!inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)bitrev, i);
 
 #ifndef EMU_SMAX
-#define EMU_SMAX (sizeof(F) > 8 ? 6 : 8)        // as ntt_engine<F>::S_MAX
+#define EMU_SMAX (sizeof(F) > 8 ? 4 : 8)        // as ntt_engine<F>::S_MAX
 #endif
     ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
     for (unsigned i = 0; i < pl.npass; i++) {

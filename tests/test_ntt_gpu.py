@@ -239,3 +239,28 @@ def test_lde_large_properties(libs):
     back = ext.clone(); sppark_amd.coset_iNTT(0, back, Ord.NN, "gl64", stream=s)
     torch.cuda.synchronize()
     assert torch.equal(back[:1 << lg], coef) and int(back[1 << lg:].abs().sum()) == 0
+
+
+def test_lde_and_msm_argument_errors(libs):
+    """Invalid arguments come back as a non-zero {code, message} (no crash, no C++ exception across the
+    boundary): domain larger than the field's two-adicity, NULL inputs, host pointers where device
+    pointers are required."""
+    import torch
+    import sppark_amd
+    from sppark_amd import ffi
+    L = ffi.load("bb31")                                        # two-adicity 27
+    d = torch.zeros(16, dtype=torch.int32, device="cuda")
+    for call in (lambda: L.sppark_lde(0, d.data_ptr(), 26, 2, None, None),
+                 lambda: L.sppark_lde_powers(0, d.data_ptr(), 28, None),
+                 lambda: L.sppark_lde_expand(0, d.data_ptr(), d.data_ptr(), 2, 1, None),          # overlapping
+                 lambda: L.sppark_lde_powers(0, np.zeros(16, dtype=np.uint32).ctypes.data, 4, None)):   # host pointer
+        err = call()
+        assert err.code != 0
+        with pytest.raises(ffi.SpparkError):
+            ffi.check(L, err)
+    M = ffi.load("bls12_381")
+    out = np.ones(144, dtype=np.uint8)
+    err = M.mult_pippenger_inf(out.ctypes.data, None, 5, np.zeros(160, dtype=np.uint8).ctypes.data, 104)
+    assert err.code != 0 and (out == 0).all()                   # out = infinity on error (pippenger.cuh:740)
+    with pytest.raises(ffi.SpparkError):
+        ffi.check(M, err)

@@ -89,9 +89,9 @@ SppError cuda_func(void *ptr);
 typedef struct sppark_msm_ctx sppark_msm_ctx;
 
 /* device_id indexes the filtered device list, -1 = current HIP device.
- * stream: a hipStream_t to launch on, or NULL for a private stream that is ordered after the
- * legacy default stream (device-resident inputs produced on any OTHER stream must be complete,
- * or that stream must be passed here). */
+ * stream: a hipStream_t to launch on, or NULL for a private stream; every call on the private
+ * stream first waits for the work already queued on the legacy default stream (device-resident
+ * inputs produced on any OTHER stream must be complete, or that stream must be passed here). */
 SppError sppark_msm_create(sppark_msm_ctx **ctx, int device_id, void *stream);
 void     sppark_msm_destroy(sppark_msm_ctx *ctx);
 SppError sppark_msm_set_stream(sppark_msm_ctx *ctx, void *stream);

@@ -97,6 +97,7 @@ private:
     const gpu_info* gpu;
     hipStream_t stream;
     bool own_stream;
+    hipEvent_t join_ev = nullptr;
     unsigned char* blob = nullptr;
     size_t blob_sz = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -159,10 +160,11 @@ public:
         : gpu(&select_gpu(device_id)), stream(s), own_stream(false)
     {
         if (stream == nullptr) {
-            // a BLOCKING stream: it orders itself after work already queued on the legacy default
-            // stream (where most callers, PyTorch included, produce device-resident inputs);
-            // callers working on other streams pass theirs explicitly
-            HIP_OK(hipStreamCreate(&stream));
+            // a non-blocking private stream (a blocking one pays an implicit legacy-stream check on
+            // every launch: +36 ms on a 2^26 MSM); join_default_stream() orders each call after the
+            // work already queued on the legacy default stream instead
+            HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            HIP_OK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
             own_stream = true;
         }
     }
@@ -173,6 +175,7 @@ public:
         if (pre_points) (void)hipFree(pre_points);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (own_stream) (void)hipStreamDestroy(stream);
+        if (join_ev) (void)hipEventDestroy(join_ev);
     }
     msm_t(const msm_t&) = delete;
     msm_t& operator=(const msm_t&) = delete;
@@ -200,6 +203,16 @@ public:
         reserve(l.total);
     }
 
+    // Private stream only: wait for everything queued so far on the legacy default stream, where
+    // most callers (PyTorch included) produce device-resident inputs.  Callers that work on other
+    // streams pass theirs to the constructor / set_stream().
+    void join_default_stream()
+    {
+        if (!own_stream) return;
+        HIP_OK(hipEventRecord(join_ev, nullptr));
+        HIP_OK(hipStreamWaitEvent(stream, join_ev, 0));
+    }
+
     // Keep a copy of |np| points in HBM for later invoke(out, nullptr, n <= np, scalars, ...)
     // calls: the reference's msm_t(points, np, ffi_affine_sz) + invoke(out, scalars)
     // (pippenger.cuh:351-385,604-605).  |points| may be a host or a device pointer; np == 0 drops the copy.
@@ -207,6 +220,7 @@ public:
     {
         HIP_OK(hipSetDevice(gpu->hip_id));
         HIP_OK(hipStreamSynchronize(stream));
+        join_default_stream();
         if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
         if (np == 0) return;
         if (points == nullptr || ffi_affine_sz < 2 * FP_BYTES || np > (1u << 31)) HIP_OK(hipErrorInvalidValue);
@@ -256,6 +270,7 @@ public:
             points = pre_points; ffi_affine_sz = pre_stride;
         }
         if (scalars == nullptr) HIP_OK(hipErrorInvalidValue);
+        join_default_stream();
 
         const bool flagged = ffi_affine_sz > 2 * FP_BYTES;
         const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);

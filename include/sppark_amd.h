@@ -100,6 +100,9 @@ SppError sppark_msm_tune(sppark_msm_ctx *ctx, unsigned wbits, unsigned L, unsign
                          unsigned K, unsigned nslabs);
 /* low_bits of the bucket index sorted by the second LDS level (0 = automatic) */
 SppError sppark_msm_tune_sort(sppark_msm_ctx *ctx, unsigned low_bits);
+/* sort partitions with more entries than this are split over several work-groups (skewed scalars;
+ * 0 = automatic, 2^18) */
+SppError sppark_msm_tune_split(sppark_msm_ctx *ctx, unsigned big_partition);
 SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affine_sz,
                             int host_points, int host_scalars);
 /* Preloaded bases (msm_t(points, np, ffi_affine_sz), msm/pippenger.cuh:351-385): copy npoints

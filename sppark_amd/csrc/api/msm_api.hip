@@ -110,6 +110,9 @@ SPPARK_FFI RustError sppark_msm_tune(sppark_msm_ctx* ctx, unsigned wbits, unsign
 // split of the bucket index between the two sort levels (0 = automatic)
 SPPARK_FFI RustError sppark_msm_tune_sort(sppark_msm_ctx* ctx, unsigned low_bits)
 {   return guarded([&] { ctx->impl.tune.LB = low_bits; });   }
+// level-A partitions with more entries than this are sorted by several work-groups (0 = 2^18)
+SPPARK_FFI RustError sppark_msm_tune_split(sppark_msm_ctx* ctx, unsigned big_partition)
+{   return guarded([&] { ctx->impl.tune.big = big_partition; });   }
 SPPARK_FFI RustError sppark_msm_reserve(sppark_msm_ctx* ctx, size_t npoints, size_t ffi_affine_sz,
                                         int host_points, int host_scalars)
 {   return guarded([&] { ctx->impl.reserve_for(npoints, ffi_affine_sz, host_points, host_scalars); });   }

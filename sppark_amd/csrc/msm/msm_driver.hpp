@@ -35,6 +35,7 @@ struct msm_plan {
 
 struct msm_tunables {                   // 0 = automatic
     unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0, LB = 0;
+    unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
 };
 
 static inline unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
@@ -108,7 +109,7 @@ private:
 
     struct layout {
         size_t points, scalars, digits, sorted, partA, H, tot, offA, off, buckets;
-        size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, conv, fin, total;
+        size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, conv, fin, curB, bigl, total;
     };
 
     static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -141,6 +142,8 @@ private:
         l.A2 = take(n2 * sizeof(bucket_t)); l.W2 = take(n2 * sizeof(bucket_t));
         l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
         l.fin  = take(INTERNAL ? (size_t)p.nwins * sizeof(std_bucket_t) : 0);
+        l.curB = take((size_t)p.nwins * (p.NB + 1) * 4);                    // cursors of the cooperative sort
+        l.bigl = take(((size_t)p.nwins * p.NA + 1) * 4);                    // [count | list of oversized partitions]
         l.total = o;
         return l;
     }
@@ -328,8 +331,19 @@ public:
             hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, p.nwins), dim3(1024), ldsA, stream,
                                partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
             HIP_OK(hipGetLastError());
+            const unsigned big = tune.big ? tune.big : (1u << 18);
+            u32* nbig = (u32*)(blob + l.bigl); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB);
+            HIP_OK(hipMemsetAsync(nbig, 0, 4, stream));
             hipLaunchKernelGGL(k_sortB, dim3(p.NA, p.nwins), dim3(1024), ldsB, stream,
-                               sorted, off, partA, offA, p.n, p.NA, p.LB);
+                               sorted, off, partA, offA, p.n, p.NA, p.LB, big);
+            HIP_OK(hipGetLastError());
+            // oversized partitions (skewed scalars); empty list and immediate return otherwise
+            hipLaunchKernelGGL(k_big_find, dim3((p.NA * p.nwins + 255) / 256), dim3(256), 0, stream,
+                               nbig, blist, off, offA, p.NA, p.LB, p.nwins, big);
+            size_t ldsBig = ((size_t)1 << p.LB) * 4;
+            hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, stream, off, partA, offA, nbig, blist, p.n, p.NA, p.LB);
+            hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, stream, off, curB, offA, nbig, blist, p.NA, p.LB);
+            hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, stream, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB);
             HIP_OK(hipGetLastError());
         }
         HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));

@@ -123,7 +123,7 @@ void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
 //   sorted[w*n + pos] = point index | sign<<31
 __global__ __launch_bounds__(1024)
 void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __restrict__ partA,
-             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LB)
+             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LB, unsigned big)
 {
     extern __shared__ u32 lds[];            // 2^LB counters, then 1024 scan words
     const unsigned NL = 1u << LB;
@@ -133,6 +133,10 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     const u32* oA = offA + (size_t)w * (NA + 1);
     const unsigned begin = oA[khi], end = oA[khi + 1];
     const uint2* src = partA + (size_t)w * n;
+    if (end - begin > big) {                // oversized partition: the cooperative kernels below sort it
+        if (khi == NA - 1 && tid == 0) off[(size_t)w * (((size_t)NA << LB) + 1) + ((size_t)NA << LB)] = end;
+        return;
+    }
 
     for (unsigned b = tid; b < NL; b += 1024) cnt[b] = 0;
     __syncthreads();
@@ -177,6 +181,120 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
                 dst[pos] = r[u].x;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Oversized level-A partitions (skewed scalars: "all equal", "all ones" put a whole window into
+// ONE partition).  k_sortB finishes a partition with one work-group, which is right for the
+// ~16 K entries of the uniform case and takes 120 ms for 2^26.  Partitions above |big| entries
+// are listed and sorted by SPLIT work-groups each, in three steps that mirror k_sortB:
+// slice histograms added into off[] (as counters), one scan per partition (off[] becomes the
+// bucket offsets, cur[] the running cursors), slice scatter with one global reservation per
+// (slice, bucket) and LDS cursors inside it.  In the uniform case the list is empty and the three
+// kernels return at once.
+// ---------------------------------------------------------------------------
+static constexpr unsigned SORTB_SPLIT = 64;
+
+__global__ __launch_bounds__(256)
+void k_big_find(u32* __restrict__ nbig, u32* __restrict__ list, u32* __restrict__ off,
+                const u32* __restrict__ offA, unsigned NA, unsigned LB, unsigned nwins, unsigned big)
+{
+    const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= NA * nwins) return;
+    const unsigned w = id / NA, khi = id % NA;
+    const u32* oA = offA + (size_t)w * (NA + 1);
+    if (oA[khi + 1] - oA[khi] <= big) return;
+    list[atomicAdd(nbig, 1u)] = id;
+    u32* o = off + (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+    for (unsigned j = 0; j < (1u << LB); j++) o[j] = 0;                 // counters of the histogram step
+}
+
+// slice s of listed partition b; returns false when the work item does not exist
+__device__ inline bool big_slice(const u32* nbig, const u32* list, const u32* offA, unsigned NA, unsigned item,
+                                 unsigned& w, unsigned& khi, unsigned& lo, unsigned& hi)
+{
+    const unsigned b = item / SORTB_SPLIT, s = item % SORTB_SPLIT;
+    if (b >= *nbig) return false;
+    w = list[b] / NA; khi = list[b] % NA;
+    const u32* oA = offA + (size_t)w * (NA + 1);
+    const unsigned begin = oA[khi], end = oA[khi + 1];
+    const unsigned per = (end - begin + SORTB_SPLIT - 1) / SORTB_SPLIT;
+    lo = min(end, begin + s * per); hi = min(end, lo + per);
+    return true;
+}
+
+__global__ __launch_bounds__(1024)
+void k_big_hist(u32* __restrict__ off, const uint2* __restrict__ partA, const u32* __restrict__ offA,
+                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned n, unsigned NA, unsigned LB)
+{
+    extern __shared__ u32 lds[];
+    const unsigned NL = 1u << LB, tid = threadIdx.x;
+    for (unsigned item = blockIdx.x; ; item += gridDim.x) {
+        unsigned w, khi, lo, hi;
+        if (!big_slice(nbig, list, offA, NA, item, w, khi, lo, hi)) return;
+        for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
+        __syncthreads();
+        const uint2* src = partA + (size_t)w * n;
+        for (unsigned i = lo + tid; i < hi; i += 1024) atomicAdd(&lds[src[i].y], 1u);
+        __syncthreads();
+        u32* o = off + (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+        for (unsigned j = tid; j < NL; j += 1024) if (lds[j]) atomicAdd(&o[j], lds[j]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void k_big_scan(u32* __restrict__ off, u32* __restrict__ cur, const u32* __restrict__ offA,
+                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned NA, unsigned LB)
+{
+    __shared__ u32 part[1024];
+    const unsigned NL = 1u << LB, tid = threadIdx.x;
+    for (unsigned b = blockIdx.x; b < *nbig; b += gridDim.x) {
+        const unsigned w = list[b] / NA, khi = list[b] % NA;
+        const u32 begin = offA[(size_t)w * (NA + 1) + khi];
+        const size_t base = (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+        const unsigned per = (NL + 1023) / 1024, lo = min(NL, tid * per), hi = min(NL, lo + per);
+        u32 sum = 0;
+        for (unsigned j = lo; j < hi; j++) sum += off[base + j];
+        part[tid] = sum;
+        __syncthreads();
+        for (unsigned d = 1; d < 1024; d <<= 1) {
+            u32 v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        u32 run = begin + part[tid] - sum;
+        for (unsigned j = lo; j < hi; j++) { u32 c = off[base + j]; off[base + j] = run; cur[base + j] = run; run += c; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2* __restrict__ partA,
+                   const u32* __restrict__ offA, const u32* __restrict__ nbig, const u32* __restrict__ list,
+                   unsigned n, unsigned NA, unsigned LB)
+{
+    extern __shared__ u32 lds[];
+    const unsigned NL = 1u << LB, tid = threadIdx.x;
+    for (unsigned item = blockIdx.x; ; item += gridDim.x) {
+        unsigned w, khi, lo, hi;
+        if (!big_slice(nbig, list, offA, NA, item, w, khi, lo, hi)) return;
+        for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
+        __syncthreads();
+        const uint2* src = partA + (size_t)w * n;
+        for (unsigned i = lo + tid; i < hi; i += 1024) atomicAdd(&lds[src[i].y], 1u);
+        __syncthreads();
+        u32* c = cur + (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+        for (unsigned j = tid; j < NL; j += 1024) if (lds[j]) lds[j] = atomicAdd(&c[j], lds[j]);   // reserve a range
+        __syncthreads();
+        u32* dst = sorted + (size_t)w * n;
+        for (unsigned i = lo + tid; i < hi; i += 1024) {
+            const uint2 r = src[i];
+            dst[atomicAdd(&lds[r.y], 1u)] = r.x;
+        }
+        __syncthreads();
     }
 }
 

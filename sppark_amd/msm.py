@@ -89,6 +89,9 @@ class MsmContext:
     def tune_sort(self, low_bits=0):
         ffi.check(self.L, self.L.sppark_msm_tune_sort(self.h, low_bits))
 
+    def tune_split(self, big_partition=0):
+        ffi.check(self.L, self.L.sppark_msm_tune_split(self.h, big_partition))
+
     def reserve(self, npoints, ffi_affine_sz, host_points=False, host_scalars=False):
         ffi.check(self.L, self.L.sppark_msm_reserve(self.h, npoints, ffi_affine_sz,
                                                     int(host_points), int(host_scalars)))

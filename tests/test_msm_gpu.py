@@ -563,6 +563,29 @@ def test_msm_randomised_plans_and_inputs(oracle, libs):
         c.close()
 
 
+def test_msm_oversized_sort_partitions(oracle, libs):
+    """Skewed scalars put a whole window into one sort partition; partitions above the split
+    threshold are sorted cooperatively by several work-groups (k_big_*).  Forced here with a tiny
+    threshold on all the skew shapes, against the oracle."""
+    import sppark_amd
+    O = oracle
+    n = 6000
+    pts, sc = recipe.msm_inputs(O.BLS12_381, n, 4040, ndistinct=300, flagged=True)
+    s_eq = sc.copy(); s_eq[:] = sc[0]
+    s_one = np.zeros_like(sc); s_one[:, 0] = 1
+    s_small = np.zeros_like(sc); s_small[:, 0] = sc[:, 0] & 7
+    s_half = sc.copy(); s_half[::2] = 0
+    ctx = sppark_amd.MsmContext("bls12_381")
+    for big in (1, 37, 500):
+        ctx.tune_split(big)
+        for wb, lb in ((0, 0), (13, 3), (9, 0), (17, 6)):
+            ctx.tune(wbits=wb); ctx.tune_sort(lb)
+            for s in (sc, s_eq, s_one, s_small, s_half):
+                out = ctx.invoke(pts, s, ffi_affine_sz=104)
+                assert (sppark_amd.to_affine(out) == O.msm_affine(O.BLS12_381, pts, s, algo=0, param=8)).all(), (big, wb, lb)
+    ctx.close()
+
+
 def test_msm_full_size_periodic(oracle, libs):
     """BASELINE size (2^26 points, BLS12-381 G1), checked through a size-independent property:
     with 2048 distinct points and scalars repeated with the same period,

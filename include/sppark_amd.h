@@ -86,6 +86,11 @@ SppError cuda_func(void *ptr);
 /*    (msm/pippenger.cuh:351-388,582-610; ntt/ntt.cuh:344-350).              */
 /* ------------------------------------------------------------------------ */
 
+/* The one-shot entry points of section 1 keep their scratch memory (one context per host thread
+ * and device) between calls instead of allocating and freeing tens of GB every time, as the
+ * reference's per-call msm_t does (msm/pippenger.cuh:730-747).  This gives it back. */
+void sppark_msm_release_cached(void);
+
 typedef struct sppark_msm_ctx sppark_msm_ctx;
 
 /* device_id indexes the filtered device list, -1 = current HIP device.

@@ -33,6 +33,8 @@ extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, c
 #include "../ff/fp2_host.hpp"
 #include "../msm/msm_driver.hpp"
 #include "common_api.hpp"
+#include <map>
+#include <memory>
 
 using namespace sppark_amd;
 
@@ -56,12 +58,34 @@ template<class Fn> static RustError guarded(Fn&& fn)
     catch (...) { return rust_err(-1, "unknown exception"); }
 }
 
+// The reference's entry points build an msm_t per call (msm/pippenger.cuh:730-747), i.e. a device
+// allocation and release of the whole scratch blob every time.  With tens of GB of scratch that
+// costs up to 100+ ms per call on a busy device, so the one-shot entry points keep ONE context per
+// (host thread, device) alive between calls; sppark_msm_release_cached() gives the memory back.
+template<class Impl> static Impl& cached_context()
+{
+    // raw pointers, never deleted: a destructor running HIP calls at thread / process exit would
+    // race the runtime's own teardown; the driver reclaims the memory with the process
+    static thread_local std::map<int, Impl*> cache;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    Impl*& slot = cache[dev];
+    if (!slot) slot = new Impl(-1);                     // select_gpu(-1): current device
+    return *slot;
+}
+template<class Impl> static void drop_cached_context()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    try { Impl& c = cached_context<Impl>(); c.release_scratch(); } catch (...) {}
+}
+
 static RustError one_shot(void* out, const void* points, size_t npoints, const void* scalars,
                           bool mont, size_t ffi_sz)
 {
     store_inf(out);
     return guarded([&] {
-        msm_impl msm(-1);                               // select_gpu(-1): current device
+        msm_impl& msm = cached_context<msm_impl>();
         point_t r;
         msm.invoke(r, points, npoints, scalars, mont, ffi_sz);
         store_point(out, r);
@@ -83,12 +107,16 @@ SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_
 {
     memset(out, 0, sizeof(point2_t));
     return guarded([&] {
-        msm2_impl msm(-1);
+        msm2_impl& msm = cached_context<msm2_impl>();
         point2_t r;
         msm.invoke(r, points, npoints, scalars, false, ffi_affine_sz);
         memcpy(out, &r, sizeof(r));
     });
 }
+
+// release the scratch memory kept by this thread's one-shot contexts on the current device
+SPPARK_FFI void sppark_msm_release_cached(void)
+{   drop_cached_context<msm_impl>(); drop_cached_context<msm2_impl>();   }
 
 SPPARK_FFI RustError sppark_msm_create(sppark_msm_ctx** ctx, int device_id, void* stream)
 {

@@ -195,6 +195,11 @@ public:
     }
     float kernel_ms(int which) const { return which >= 0 && which < 3 ? last_ms[which] : -1.f; }
     size_t scratch_bytes() const { return blob_sz; }
+    void release_scratch()
+    {
+        (void)hipStreamSynchronize(stream);
+        if (blob) { (void)hipFree(blob); blob = nullptr; blob_sz = 0; }
+    }
     msm_plan plan_for(size_t npoints) const { return make_plan(npoints, FRp::NBITS, tune); }
 
     // Size the blob for |npoints| ahead of time (so a timed invoke does not allocate).

@@ -76,6 +76,8 @@ def load(name):
         L.sppark_msm_set_stream.restype = _Error
         L.sppark_msm_tune.argtypes = [vp, cu, cu, cu, cu, cu]
         L.sppark_msm_tune.restype = _Error
+        L.sppark_msm_release_cached.argtypes = []
+        L.sppark_msm_release_cached.restype = None
         L.sppark_msm_tune_split.argtypes = [vp, cu]
         L.sppark_msm_tune_split.restype = _Error
         L.sppark_msm_tune_sort.argtypes = [vp, cu]

@@ -563,6 +563,23 @@ def test_msm_randomised_plans_and_inputs(oracle, libs):
         c.close()
 
 
+def test_one_shot_entry_points_reuse_and_release_scratch(oracle, libs):
+    """mult_pippenger_inf / mult_pippenger_fp2_inf keep one context per (thread, device) between
+    calls; results stay right across sizes, curves' groups and after sppark_msm_release_cached()."""
+    import sppark_amd
+    from sppark_amd import ffi
+    O = oracle
+    L = ffi.load("bls12_381")
+    for n in (3000, 50, 7000):
+        pts, sc = recipe.msm_inputs(O.BLS12_381, n, 77 + n, flagged=True)
+        assert (sppark_amd.to_affine(sppark_amd.multi_scalar_mult_arkworks(pts, sc)) == O.msm_affine(O.BLS12_381, pts, sc, algo=0, param=8)).all()
+        p2, s2 = recipe.msm_inputs(O.BLS12_381_G2, n // 10 + 1, 78 + n, flagged=True)
+        assert (sppark_amd.to_affine_g2(sppark_amd.multi_scalar_mult_fp2_arkworks(p2, s2)) == O.msm_affine(O.BLS12_381_G2, p2, s2, algo=0, param=8)).all()
+        if n == 50:
+            L.sppark_msm_release_cached()
+    L.sppark_msm_release_cached()
+
+
 def test_msm_oversized_sort_partitions(oracle, libs):
     """Skewed scalars put a whole window into one sort partition; partitions above the split
     threshold are sorted cooperatively by several work-groups (k_big_*).  Forced here with a tiny

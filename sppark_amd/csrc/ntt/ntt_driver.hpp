@@ -149,7 +149,7 @@ public:
             // one lane per register sub-transform: a tile has 2^(lgG + R1 + lgC) of them in its
             // larger round (small tiles of wide elements would leave most of 256 lanes idle)
             const unsigned groups = 1u << (P.lgG + (P.S + 1) / 2 + P.lgC);
-            const unsigned nthr = groups >= 256 ? 256 : groups <= 64 ? 64 : groups;
+            const unsigned nthr = groups >= 512 ? 512 : groups <= 64 ? 64 : groups;
 #define SPPARK_NTT_LAUNCH(R1, R2)                                                                              \
             do {                                                                                               \
                 if (lds > 65536) {                                                                             \

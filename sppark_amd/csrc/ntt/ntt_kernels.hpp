@@ -264,7 +264,7 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
 }
 
 template<class F, bool DIF, bool INV, unsigned R1, unsigned R2>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(512)
 void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
 {
     extern __shared__ unsigned char ntt_lds[];

@@ -264,3 +264,24 @@ def test_lde_and_msm_argument_errors(libs):
     assert err.code != 0 and (out == 0).all()                   # out = infinity on error (pippenger.cuh:740)
     with pytest.raises(ffi.SpparkError):
         ffi.check(M, err)
+
+
+@pytest.mark.parametrize("field", FIELDS + WIDE)
+def test_lde_sweep_vs_oracle(oracle, libs, field):
+    """every (domain, blow-up) up to 2^12 x 8 against the oracle's restatement of NTT::LDE_aux,
+    host buffers, with the coefficient output."""
+    import sppark_amd
+    O = oracle
+    dt, w = _field_views(field)
+    top = 12 if field in FIELDS else 9
+    for lg in range(0, top + 1):
+        for lgb in (1, 2, 3):
+            if field == "bb31" and lg + lgb > 27:
+                continue
+            x = recipe.ntt_input(field, lg, 900 + 17 * lg + lgb)
+            exp, aux_exp = O.lde(field, x, lgb, want_aux=True)
+            buf = np.zeros(((1 << (lg + lgb)), w), dtype=dt); buf[:1 << lg] = x.reshape(-1, w)
+            aux = np.zeros((1 << lg, w), dtype=dt)
+            sppark_amd.LDE(0, buf, lg, lgb, field, aux_out=aux)
+            assert (buf.reshape(exp.shape) == exp).all(), (field, lg, lgb)
+            assert (aux.reshape(aux_exp.shape) == aux_exp).all(), (field, lg, lgb)

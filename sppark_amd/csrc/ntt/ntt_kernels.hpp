@@ -312,7 +312,7 @@ template<class F>
 SPPARK_DEVFN void bitrev_item(F* data, unsigned lg_n, size_t i)
 {
     size_t r = 0;
-    for (unsigned k = 0; k < lg_n; k++) r |= ((i >> k) & 1) << (lg_n - 1 - k);
+    r = bit_rev32((unsigned)i, lg_n);                        // lg_n <= 32: the index fits 32 bits
     if (i < r) { F t = data[i]; data[i] = data[r]; data[r] = t; }
 }
 template<class F>
@@ -337,7 +337,7 @@ SPPARK_DEVFN void bitrev_tile_item(F* data, F* ldsA, F* ldsB, unsigned lg_n, siz
 {
     const unsigned lg_mid = lg_n - 2 * TB, T = 1u << TB;
     size_t rmid = 0;
-    for (unsigned k = 0; k < lg_mid; k++) rmid |= ((mid >> k) & 1) << (lg_mid - 1 - k);
+    rmid = bit_rev32((unsigned)mid, lg_mid);
     if (mid > rmid) return;
     const bool pair = mid != rmid;
     if (phase == 0) {                                   // rows of the two tiles -> LDS
@@ -373,7 +373,7 @@ template<class F>
 SPPARK_DEVFN void coset_item(F* data, const ntt_tables<F>& G, int bitrev, size_t i)
 {
     size_t e = i;
-    if (bitrev) { e = 0; for (unsigned k = 0; k < G.lg_n; k++) e |= ((i >> k) & 1) << (G.lg_n - 1 - k); }
+    if (bitrev) e = bit_rev32((unsigned)i, G.lg_n);
     data[i] = data[i] * ntt_twiddle(G, e);
 }
 template<class F>
@@ -397,7 +397,7 @@ SPPARK_DEVFN void lde_spread_item(F* out, const F* in, const ntt_tables<F>& G, u
         r = in[idx];
         if (shift) {
             size_t e = 0;
-            for (unsigned k = 0; k < lg_domain; k++) e |= ((idx >> k) & 1) << (lg_domain - 1 - k);
+            e = bit_rev32((unsigned)idx, lg_domain);
             r = r * ntt_twiddle(G, e);
         }
     }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_bitrev_copy(F* out, const F* in, unsign
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ((size_t)1 << lg_n)) return;
     size_t r = 0;
-    for (unsigned k = 0; k < lg_n; k++) r |= ((i >> k) & 1) << (lg_n - 1 - k);
+    r = bit_rev32((unsigned)i, lg_n);
     out[r] = in[i];
 }
 

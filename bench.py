@@ -232,10 +232,18 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import oracle as O                                      # cpu_baseline leg only
         cores = len(os.sched_getaffinity(0))
+        # oracle/_ref (the reference's own msm/pippenger.hpp + util/thread_pool_t.hpp, compiled in place
+        # by oracle/Makefile over the oracle's portable field; prebuilt, travels with the snapshot) when it
+        # is there, otherwise the restatement ("port")
+        use_ref = O.ref_available()
+        if use_ref:
+            cpu_msm = lambda p_, s_: O.ref_msm_affine(O.BLS12_381, p_, s_, nthreads=cores)
+        else:
+            cpu_msm = lambda p_, s_: O.msm_affine(O.BLS12_381, p_, s_, algo=0, param=cores)
         # size the sample for ~15 s of CPU work from a 2^16 probe (config 1 of BASELINE.json)
         hp = pts[:1 << 16].cpu().numpy(); hs = sc[:1 << 16].cpu().numpy()
         t1 = time.perf_counter()
-        O.msm_affine(O.BLS12_381, hp, hs, algo=0, param=cores)
+        cpu_msm(hp, hs)
         probe = time.perf_counter() - t1
         lgm = 16
         while lgm < min(args.lg, 24) and probe * (1 << (lgm + 1 - 16)) * 0.6 < 15.0:
@@ -243,12 +251,14 @@ def main():
         m = 1 << lgm
         hp = pts[:m].cpu().numpy(); hs = sc[:m].cpu().numpy()
         t1 = time.perf_counter()
-        ref = O.msm_affine(O.BLS12_381, hp, hs, algo=0, param=cores)
+        ref = cpu_msm(hp, hs)
         dt = time.perf_counter() - t1
         got = sppark_amd.to_affine(ctx.invoke(pts[:m], sc[:m]))
-        cpu = {"value": m / dt, "unit": "points/s", "cores": cores, "kind": "port",
-               "sample": "first 2^%d points of the same workload, oracle restatement of msm/pippenger.hpp "
-                         "(portable C++ field, not blst asm), %d threads, %.2f s" % (m.bit_length() - 1, cores, dt),
+        cpu = {"value": m / dt, "unit": "points/s", "cores": cores, "kind": "reference" if use_ref else "port",
+               "sample": "first 2^%d points of the same workload, %s (portable C++ field, not blst asm), %d threads, %.2f s"
+                         % (m.bit_length() - 1,
+                            "the reference's msm/pippenger.hpp + thread_pool_t compiled in place (oracle/_ref)" if use_ref
+                            else "oracle restatement of msm/pippenger.hpp", cores, dt),
                "parity_with_gpu_on_sample": bool((got == ref).all())}
 
     if rank == 0:

@@ -4,7 +4,11 @@
 
 MSM expectations come from the REFERENCE's own msm/pippenger.hpp compiled in
 place (oracle/_ref/libref_msm.so, see oracle/ref_shim.cpp), 1-thread and
-8-thread paths required to agree.  NTT expectations come from an independent
+8-thread paths required to agree -- and, for every case with n <= 1024 (G1 and
+G2, both curves, all edge cases), a second time from tests/golden/pygroup.py, a
+pure-Python big-int affine group law that shares no code with oracle/ (points are
+decoded from their wire bytes and checked against the curve equation there); the
+two must agree or generation fails.  Cases so checked carry "python_checked".  NTT expectations come from an independent
 definition-level Python big-int DFT written here (the reference has no CPU NTT),
 applied through the order/direction/coset semantics of ntt/ntt.cuh:161-213.
 """
@@ -19,12 +23,65 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle as O          # noqa: E402
 import recipe               # noqa: E402
+import pygroup              # noqa: E402  (independent pure-Python group law: the second pin)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def hexs(a):
     return np.ascontiguousarray(a).tobytes().hex()
+
+
+def python_pin(cname, g2, pts, sc, flagged):
+    return pygroup.msm_affine_bytes(cname, g2, pts.tobytes(), pts.shape[1], flagged, sc.tobytes())
+
+
+def edge_cases(curve, cname, g2):
+    """Small named cases with their bytes stored: what the reference's tests and SURVEY 8(c) list
+    (zero scalars, r-1, infinity inputs, duplicated / all-equal points, P and -P, everything
+    cancelling).  Each expectation = reference build == pure-Python law."""
+    r = O.FR_MODULUS[curve]
+    le = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)
+    out = []
+
+    def emit(name, pts, sc, flagged):
+        e = O.ref_msm_affine(curve, pts, sc, nthreads=0)
+        assert (e == O.ref_msm_affine(curve, pts, sc, nthreads=8)).all(), name
+        assert python_pin(cname, g2, pts, sc, flagged) == e.tobytes(), (cname, g2, name)
+        out.append({"curve": cname, "n": int(pts.shape[0]), "name": name, "flagged": flagged, "python_checked": True,
+                    "points": hexs(pts), "scalars": hexs(sc), "expect_affine": hexs(e)})
+    for flagged in (False, True):
+        tag = "_flagged" if flagged else ""
+        pts, sc = recipe.msm_inputs(curve, 13, 0xed6e + flagged, ndistinct=13, flagged=flagged)       # all edge rows of the recipe
+        emit("recipe_edges_13" + tag, pts, sc, flagged)
+        pts, sc = recipe.msm_inputs(curve, 24, 0xed6f, ndistinct=24, flagged=flagged, edge=False)
+        z = sc.copy(); z[:] = 0
+        emit("all_zero_scalars" + tag, pts, z, flagged)                                  # -> infinity
+        inf = pts.copy(); inf[:] = 0
+        if flagged:
+            inf[:, -8] = 1
+        emit("all_infinity_points" + tag, inf, sc, flagged)                              # -> infinity
+        same = pts.copy(); same[:] = pts[0]
+        emit("all_equal_points" + tag, same, sc, flagged)
+        eq = sc.copy(); eq[:] = sc[1]
+        emit("all_equal_scalars" + tag, pts, eq, flagged)
+        both_sc = sc.copy(); both_sc[:] = le(r - 1)
+        emit("all_equal_points_scalar_r_minus_1" + tag, same, both_sc, flagged)         # repeated doubling branch
+        # pairs (s, P), (r - s, P): the whole sum cancels
+        can = pts.copy(); can_sc = sc.copy()
+        for i in range(0, 24, 2):
+            can[i + 1] = can[i]
+            can_sc[i + 1] = le((r - int.from_bytes(can_sc[i].tobytes(), "little")) % r)
+        emit("cancelling_pairs" + tag, can, can_sc, flagged)
+        one = sc.copy(); one[:] = le(1)
+        emit("all_ones_scalars" + tag, pts, one, flagged)                                # plain sum of the points
+        top = sc.copy()
+        for i in range(24):
+            top[i] = le(r - 1 - i)
+        emit("scalars_near_r" + tag, pts, top, flagged)
+        small = sc.copy(); small[:, 1:] = 0
+        emit("8bit_scalars" + tag, pts, small, flagged)
+    return out
 
 
 def make_msm():
@@ -40,9 +97,13 @@ def make_msm():
             assert (e1 == e8).all()
             case = {"curve": cname, "n": n, "seed": seed, "flagged": flagged,
                     "ndistinct": 2048 if n > 4096 else 64, "expect_affine": hexs(e1)}
+            if n <= 1024:
+                assert python_pin(cname, False, pts, sc, flagged) == e1.tobytes(), (cname, n)
+                case["python_checked"] = True
             if n <= 33:
                 case["points"] = hexs(pts); case["scalars"] = hexs(sc)
             cases.append(case)
+        cases += edge_cases(curve, cname, False)
     # KAT of SURVEY Appendix A.4: sum_{i=1..4} i*(i*G) = 30*G
     G = O.g1_generator(O.BLS12_381)
     pts = np.stack([O.g1_mul(O.BLS12_381, G, i) for i in range(1, 5)])
@@ -116,9 +177,13 @@ def make_msm_g2():
             e8 = O.ref_msm_affine(curve, pts, sc, nthreads=8)
             assert (e1 == e8).all()
             case = {"curve": cname, "n": n, "seed": seed, "flagged": flagged, "ndistinct": 64, "expect_affine": hexs(e1)}
+            if n <= 1024:
+                assert python_pin(cname, True, pts, sc, flagged) == e1.tobytes(), (cname, n)
+                case["python_checked"] = True
             if n <= 33:
                 case["points"] = hexs(pts); case["scalars"] = hexs(sc)
             cases.append(case)
+        cases += edge_cases(curve, cname, True)
         # KAT by the independent Python group law: sum_{i=1..4} i*(i*G2) = 30*G2
         pts = np.stack([g2_wire(g2_mul(G2_GEN[cname], i, p), p, base) for i in range(1, 5)])
         sc = np.stack([np.frombuffer(int(i).to_bytes(32, "little"), dtype=np.uint8) for i in range(1, 5)])

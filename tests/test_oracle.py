@@ -89,6 +89,38 @@ def test_msm_golden(oracle):
             assert (got[:2 * fb] == exp).all(), (c["curve"], c["n"], algo)
 
 
+@pytest.mark.parametrize("fname,g2", [("msm_golden.json", False), ("msm_g2_golden.json", True)])
+def test_msm_golden_vs_independent_python_group_law(oracle, fname, g2):
+    """Second, independent pin of the MSM expectations: tests/golden/pygroup.py (pure-Python
+    big-int affine arithmetic, decodes the wire bytes itself, shares nothing with oracle/) re-derives
+    every golden case whose bytes are stored (all edge cases, both curves, G1 and G2) and one
+    n = 1000 case per file; it must equal the committed expectation (= the reference build's
+    output) AND the restatement."""
+    import pygroup
+    O = oracle
+    big_done = set()
+    for c in json.load(open(os.path.join(HERE, "golden", fname))):
+        if g2:
+            curve = O.BLS12_381_G2 if c["curve"] == "bls12_381" else O.BN254_G2
+        else:
+            curve = O.BLS12_381 if c["curve"] == "bls12_381" else O.BN254
+        fb = O.FP_BYTES[curve]
+        stride = 2 * fb + 8 if c["flagged"] else 2 * fb
+        if "points" in c:
+            praw, sraw = bytes.fromhex(c["points"]), bytes.fromhex(c["scalars"])
+        elif c["n"] == 1000 and c["curve"] not in big_done and not g2:
+            big_done.add(c["curve"])
+            pts, sc = recipe.msm_inputs(curve, c["n"], c["seed"], c["ndistinct"], c["flagged"])
+            praw, sraw = pts.tobytes(), sc.tobytes()
+        else:
+            continue
+        got = pygroup.msm_affine_bytes(c["curve"], g2, praw, stride, c["flagged"], sraw)
+        assert got.hex() == c["expect_affine"], (fname, c["curve"], c["n"], c.get("name"))
+        pts = np.frombuffer(praw, dtype=np.uint8).reshape(c["n"], stride)
+        sc = np.frombuffer(sraw, dtype=np.uint8).reshape(c["n"], 32)
+        assert O.msm_affine(curve, pts, sc, algo=0, param=0).tobytes() == got
+
+
 def test_msm_vs_reference_build(oracle):
     """Restatement == the reference's own template, on fresh random inputs."""
     O = oracle

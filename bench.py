@@ -1,16 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py --gpus N --steps K --warmup W
+"""bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--lg 26 | --total-lg 28]
 
-Headline: BLS12-381 G1 Pippenger MSM, 2^26 points per GPU, inputs resident in
-HBM (BASELINE.json metric / configs[2]; weak scaling: every rank owns 2^26 points
-of a 2^26*N-point MSM, one RCCL all-gather of the 144-byte partial results per
-step, combine on every rank).  A step = one full MSM.  Secondary (same JSON line,
-key "ntt"): Goldilocks NTT 2^24 forward NR + inverse RN (configs[1]).
+Headline (BASELINE.json metric): BLS12-381 G1 Pippenger MSM of 2^26 points, inputs resident in
+HBM, on N GPUs of one node.  A step = one full MSM.
 
-One JSON line on rank 0; "roofline" is for the dominant kernel k_accumulate
-(HIP-event timed inside the library on the launch stream), "cpu_baseline" is the
-oracle's restatement of msm/pippenger.hpp on the host cores (N=1 only)."""
+  N = 1                 2^26 points on one GPU (configs[2])
+  N > 1, default        STRONG scaling: the SAME 2^26-point MSM cut into N contiguous shards, one
+                        rank per GPU, one RCCL all-gather of the 144-byte partial sums per step,
+                        combine on every rank -- "MSM points/sec (2^26) at 1/2/4/8 GPUs"
+  --total-lg 28         strong scaling at 2^28 total (configs[3]: 2^25 per rank on 8 GPUs)
+  --scaling weak        2^lg points PER RANK (a 2^lg * N-point MSM)
+
+Inputs follow poc/msm-cuda/src/util.rs:11-38: 2^11 distinct points replicated cyclically
+(point 3 = infinity), independent uniform scalars on [0, r) (rejection sampled).
+The result of the LAST TIMED step is asserted bit-exact (affine) against the oracle: the point
+period lets the whole MSM be folded into a 2048-point one (oracle/fold.py).
+
+Secondary (same JSON line, key "ntt"): Goldilocks NTT 2^24 forward NR + inverse RN (configs[1]),
+output asserted equal to the oracle's at the timed size.
+
+One JSON line on rank 0; "roofline" is for the dominant kernel k_accumulate (HIP-event timed
+inside the library on the launch stream), "roofline_alu" prices the same kernel against the
+measured v_mad_u64_u32 issue peak, "cpu_baseline" is the reference's msm/pippenger.hpp
+(oracle/_ref) on the host cores (N = 1 only)."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,25 +37,26 @@ import numpy as np
 import torch
 
 import sppark_amd
-from sppark_amd import multi_gpu
+from sppark_amd import multi_gpu, synth
 
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MSM_BYTES_PER_POINT = 128           # 96-byte affine point + 32-byte scalar
 NTT_BYTES_PER_ELEM = 16             # read + write one u64 per transform
+PERIOD = 2048                       # distinct points (util.rs:15 uses 2^11 too)
+# measured issue peak of the one wide integer multiplier, v_mad_u64_u32: 0.181 wave-instr/clk/SIMD
+# (profiles/r01_ubench2_instruction_rates.log) x 1024 SIMDs x 64 lanes x 2.4 GHz
+MAD_PEAK_PER_S = 0.181 * 1024 * 64 * 2.4e9
+MADS_PER_MIXED_ADD = 8 * 392 + 2 * 301      # ff/montx_dev.hpp: 14x14 + 14x14 per product, 105 + 196 per square
 
 
-def make_msm_inputs(lg, seed, curve="bls12_381", fb=48):
-    """poc/msm-cuda/src/util.rs:11-38 shape: 2^11 distinct points replicated,
-    index 3 = infinity, independent uniform scalars (254-bit, all < r)."""
-    n = 1 << lg
-    base = torch.zeros((2048, 2 * fb), dtype=torch.uint8, device="cuda")
-    sppark_amd.generate_points(base, 2048, 0x5eed5eed0001, 2 * fb, curve)
-    pts = base[torch.arange(n, device="cuda") % 2048].contiguous()
-    pts[3] = 0
-    g = torch.Generator(device="cuda"); g.manual_seed(seed)
-    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
-    sc[:, 31] &= 0x3f
-    return pts, sc
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -49,11 +64,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lg", type=int, default=26, help="log2 points per GPU (default: the BASELINE size)")
+    ap.add_argument("--lg", type=int, default=26, help="log2 points: of the whole MSM (strong) / per GPU (weak)")
+    ap.add_argument("--total-lg", type=int, default=None, help="strong scaling with 2^TOTAL_LG points in total (configs[3]: 28)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--ntt-lg", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--groups", type=int, default=0, help="window groups of the MSM pipeline (0 = automatic)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,9 +88,22 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, "--gpus must equal WORLD_SIZE"
 
-    n = 1 << args.lg
-    pts, sc = make_msm_inputs(args.lg, 0x5eed5eed0001 + rank)
+    scaling = args.scaling
+    if args.total_lg is not None:
+        scaling, total = "strong", 1 << args.total_lg
+    elif scaling == "strong":
+        total = 1 << args.lg
+    else:
+        total = world << args.lg
+    lo, hi = multi_gpu.shard_bounds(total, world, rank)
+    assert lo % PERIOD == 0 and (hi - lo) % PERIOD == 0, "shards must be multiples of the point period"
+    n = hi - lo                                                  # this rank's points
+
+    pts, base = synth.replicated_points(n, "bls12_381", PERIOD, 0x5eed5eed0001)
+    sc = synth.uniform_scalars(n, "bls12_381", 0x5eed5eed0001 + rank)
     ctx = sppark_amd.MsmContext("bls12_381", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
+    if args.groups:
+        ctx.tune_pipeline(groups=args.groups)
     ctx.enable_timing(True)
     ctx.reserve(n, 96)
 
@@ -97,10 +128,36 @@ def main():
         accum_ms.append(ctx.kernel_ms(1)); sort_ms.append(ctx.kernel_ms(0)); dev_ms.append(ctx.kernel_ms(2))
     fence()
     elapsed = time.perf_counter() - t0
+    acc_launches = int(ctx.kernel_ms(3))
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- CHECKER (outside the timed region): the last timed result against the oracle ------------
+    # class sums of this rank's scalars (exact integer arithmetic), gathered over the ranks; rank 0
+    # evaluates the folded 2048-point MSM with the oracle and compares affine coordinates bit for bit
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import oracle as O                                          # checker / cpu_baseline legs only
+    from oracle import fold
+    r_mod = O.FR_MODULUS[O.BLS12_381]
+    folded = fold.fold_scalars(sc, PERIOD, r_mod)
+    if use_dist:
+        allf = multi_gpu.all_gather_bytes(folded.reshape(-1)).reshape(-1, PERIOD, 32)
+    else:
+        allf = folded.reshape(1, PERIOD, 32)
+    parity = None
+    if rank == 0:
+        tot = np.zeros((PERIOD, 32), dtype=np.uint8)
+        for j in range(PERIOD):
+            v = sum(int.from_bytes(allf[k, j].tobytes(), "little") for k in range(allf.shape[0])) % r_mod
+            tot[j] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+        expect = O.msm_affine(O.BLS12_381, base.cpu().numpy(), tot, algo=0, param=8)
+        got = sppark_amd.to_affine(result)
+        parity = {"timed_msm_equals_oracle": bool((got == expect).all()),
+                  "how": "last timed result, affine, vs oracle MSM of the 2048 distinct points with the exactly folded scalars (oracle/fold.py)",
+                  "result_affine_sha256": hashlib.sha256(got.tobytes()).hexdigest()}
+        assert parity["timed_msm_equals_oracle"], "timed MSM result differs from the oracle"
 
     ntt = None
     if rank == 0 and not args.no_ntt:
@@ -128,26 +185,38 @@ def main():
                 sppark_amd.iNTT(0, x, Ord.RN, "gl64", stream=stream)
             e2.record(); torch.cuda.synchronize()
             fwd = min(fwd, e0.elapsed_time(e1) / reps); inv = min(inv, e1.elapsed_time(e2) / reps)
+        assert torch.equal(x, ref), "timed NTT sequence did not return to its input"
         e0.record()
         for _ in range(reps):
             sppark_amd.NTT(0, x, Ord.NN, "gl64", stream=stream)      # natural in, natural out (adds the bit reversal)
         e1.record(); torch.cuda.synchronize()
         fwd_nn = e0.elapsed_time(e1) / reps
+        # CHECKER: the timed transform at the timed size against the oracle, whole array
+        y = ref.clone()
+        sppark_amd.NTT(0, y, Ord.NR, "gl64", stream=stream); torch.cuda.synchronize()
+        y_host = y.cpu().numpy().view(np.uint64)
+        y_ref = O.ntt_gl64(ref.cpu().numpy().view(np.uint64), O.NR)
+        ntt_ok = bool((y_host == y_ref).all())
+        sppark_amd.iNTT(0, y, Ord.RN, "gl64", stream=stream); torch.cuda.synchronize()
+        ntt_ok = ntt_ok and bool(torch.equal(y, ref))
+        assert ntt_ok, "timed NTT differs from the oracle"
         ntt = {"metric": "Goldilocks NTT 2^%d elements/s (forward NR / inverse RN, device-resident)" % lg,
                "timing": "HIP events around 20 back-to-back transforms, best of 3 batches",
                "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
                "forward_elems_per_s": (1 << lg) / (fwd * 1e-3), "inverse_elems_per_s": (1 << lg) / (inv * 1e-3),
                "pair_elems_per_s": (1 << lg) / ((fwd + inv) * 1e-3),
+               "equals_oracle": ntt_ok, "output_sha256": hashlib.sha256(y_host.tobytes()).hexdigest(),
                "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "whole forward transform (3 register-radix passes, 0.8 GB of traffic) vs 16 B/element algorithmic"}}
+                            "note": "whole forward transform vs 16 B/element algorithmic (one read + one write of the array)"}}
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
         # BASELINE configs[4]: alt_bn128 G1 MSM + BabyBear NTT (multi-field instantiation)
-        bpts, bsc = make_msm_inputs(args.lg, 7, "bn254", 32)
+        bpts, bbase = synth.replicated_points(n, "bn254", PERIOD, 7)
+        bsc = synth.uniform_scalars(n, "bn254", 7)
         # bases kept in the context (the reference's msm_t(points) + invoke(out, scalars),
         # msm/pippenger.cuh:351-385,604-605): the one-time conversion of the points into the
         # kernels' own records is then outside the call; NOT the headline value, which pays it
@@ -160,15 +229,22 @@ def main():
         extras["bls12_381_g1_msm_preloaded_bases_points_per_s"] = 3 * n / (time.perf_counter() - t1)
         ctx.set_points(None)
         bctx = sppark_amd.MsmContext("bn254", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
-        bctx.invoke(bpts, bsc)
+        bout = bctx.invoke(bpts, bsc)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         for _ in range(3):
-            bctx.invoke(bpts, bsc)
+            bout = bctx.invoke(bpts, bsc)
         torch.cuda.synchronize()
         extras["alt_bn128_g1_msm_points_per_s"] = 3 * n / (time.perf_counter() - t1)
+        bexp = O.msm_affine(O.BN254, bbase.cpu().numpy(), fold.fold_scalars(bsc, PERIOD, O.FR_MODULUS[O.BN254]), algo=0, param=8)
+        extras["alt_bn128_g1_msm_equals_oracle"] = bool((sppark_amd.to_affine(bout, "bn254") == bexp).all())
+        assert extras["alt_bn128_g1_msm_equals_oracle"]
         bctx.close(); del bpts, bsc
         y = torch.randint(0, 0x78000000, (1 << args.ntt_lg,), dtype=torch.int32, device="cuda")
+        y0 = y.clone()
         stream = torch.cuda.current_stream().cuda_stream
+        sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream); torch.cuda.synchronize()
+        extras["babybear_ntt_equals_oracle"] = bool((y.cpu().numpy().view(np.uint32) == O.ntt_bb31(y0.cpu().numpy().view(np.uint32), O.NR)).all())
+        assert extras["babybear_ntt_equals_oracle"]
         for _ in range(3):
             sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -217,20 +293,28 @@ def main():
         e1.record(); torch.cuda.synchronize()
         extras["goldilocks_lde_2^%d_to_2^%d_ms" % (llg, llg + 2)] = e0.elapsed_time(e1) / 5
         del ext
-        # through-the-FFI path with HOST buffers (PCIe inclusive; never the headline value)
-        lgh = min(args.lg, 24)
-        hp = np.zeros(((1 << lgh), 104), dtype=np.uint8); hp[:, :96] = pts[:1 << lgh].cpu().numpy()
-        hs = sc[:1 << lgh].cpu().numpy()
-        sppark_amd.multi_scalar_mult_arkworks(hp[:4096], hs[:4096])
-        t1 = time.perf_counter()
-        sppark_amd.multi_scalar_mult_arkworks(hp, hs)
-        extras["mult_pippenger_inf_host_buffers"] = {"points": 1 << lgh, "seconds": time.perf_counter() - t1,
-                                                     "points_per_s": (1 << lgh) / (time.perf_counter() - t1)}
+        # through-the-FFI path with HOST buffers (PCIe inclusive; never the headline value): what the
+        # reference's Rust / Go callers use.  2^24 and the full 2^26, chunked copy under the arithmetic.
+        host = {}
+        for lgh in sorted({min(args.lg, 24), args.lg}):
+            m = 1 << lgh
+            hp = np.zeros((m, 104), dtype=np.uint8); hp[:, :96] = pts[:m].cpu().numpy()
+            hp[3::PERIOD, 96] = 1                                # Affine_inf_t: the flag byte marks infinity
+            hs = sc[:m].cpu().numpy()
+            sppark_amd.multi_scalar_mult_arkworks(hp[:1 << 21], hs[:1 << 21])
+            t1 = time.perf_counter()
+            hout = sppark_amd.multi_scalar_mult_arkworks(hp, hs)
+            dt = time.perf_counter() - t1
+            hexp = O.msm_affine(O.BLS12_381, base.cpu().numpy(), fold.fold_scalars(sc[:m], PERIOD, r_mod), algo=0, param=8)
+            ok = bool((sppark_amd.to_affine(hout) == hexp).all())
+            assert ok, "host-buffer MSM differs from the oracle"
+            host["2^%d" % lgh] = {"points": m, "seconds": dt, "points_per_s": m / dt, "equals_oracle": ok}
+            del hp, hs
+        extras["mult_pippenger_inf_host_buffers"] = host
+        sppark_amd.ffi.load("bls12_381").sppark_msm_release_cached()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        import oracle as O                                      # cpu_baseline leg only
         cores = len(os.sched_getaffinity(0))
         # oracle/_ref (the reference's own msm/pippenger.hpp + util/thread_pool_t.hpp, compiled in place
         # by oracle/Makefile over the oracle's portable field; prebuilt, travels with the snapshot) when it
@@ -254,53 +338,66 @@ def main():
         ref = cpu_msm(hp, hs)
         dt = time.perf_counter() - t1
         got = sppark_amd.to_affine(ctx.invoke(pts[:m], sc[:m]))
-        cpu = {"value": m / dt, "unit": "points/s", "cores": cores, "kind": "reference" if use_ref else "port",
+        cpu = {"value": m / dt, "unit": "points/s", "cores": cores, "cpu_model": cpu_model(),
+               "kind": "reference" if use_ref else "port",
                "sample": "first 2^%d points of the same workload, %s (portable C++ field, not blst asm), %d threads, %.2f s"
                          % (m.bit_length() - 1,
                             "the reference's msm/pippenger.hpp + thread_pool_t compiled in place (oracle/_ref)" if use_ref
                             else "oracle restatement of msm/pippenger.hpp", cores, dt),
                "parity_with_gpu_on_sample": bool((got == ref).all())}
+        assert cpu["parity_with_gpu_on_sample"], "GPU result differs from the CPU baseline on the sample"
 
     if rank == 0:
         a_ms = float(np.mean(accum_ms))
         achieved = MSM_BYTES_PER_POINT * n / (a_ms * 1e-3) / 1e9
         plan = ctx.plan(n)
         nwins = plan["windows"]
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the
-        # timed run, so the value comes from the committed rocprofv3 --pmc passes of this
-        # same workload (profiles/r01_pmc_traffic.json); null for any other workload.
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the timed run, so the
+        # value is a CONSTANT read from the committed rocprofv3 --pmc passes of this same workload
+        # (profiles/r02_pmc_traffic.json, else r01), not an in-run measurement; null for any other workload.
         traffic, traffic_note = None, ""
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("lg") == args.lg and pmc.get("curve") == "bls12_381":
-                traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) / 1e9
-                traffic_note = ("; traffic = GB per launch from rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes, "
-                                "profiles/r01_pmc_traffic.json): the 112-byte point-record gathers pull whole 128-byte lines, "
-                                "hidden behind the multiplier-bound arithmetic")
-        except (OSError, ValueError, KeyError):
-            pass
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    pmc = json.load(f)
+                if pmc.get("lg") == n.bit_length() - 1 and pmc.get("curve") == "bls12_381" and n & (n - 1) == 0:
+                    traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) / 1e9
+                    traffic_note = ("; traffic = GB per MSM (all k_accumulate launches of one step) from the committed rocprofv3 "
+                                    "--pmc FETCH_SIZE + WRITE_SIZE passes (profiles/%s; a recorded constant, not measured in this run)" % fn)
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
+        mads = float(nwins) * n * MADS_PER_MIXED_ADD
         line = {
-            "metric": "MSM points/sec (BLS12-381 G1, 2^%d points per GPU)" % args.lg,
-            "value": world * n * args.steps / elapsed, "unit": "points/s",
+            "metric": "MSM points/sec (BLS12-381 G1, 2^%d points%s)" % (total.bit_length() - 1, " in total over %d GPUs" % world if world > 1 else ""),
+            "value": total * args.steps / elapsed, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "BLS12-381 G1 Pippenger MSM, 2^%d points per GPU, device-resident inputs "
-                                   "(BASELINE configs[2]%s)" % (args.lg, "; sharded x%d with RCCL all-gather of partial sums" % world if world > 1 else ""),
-                       "curve": "bls12_381", "points_per_gpu": n, "window_bits": plan["window_bits"], "windows": nwins,
-                       "distinct_points": 2048, "scalars": "uniform 254-bit"},
+            "config": {"workload": "BLS12-381 G1 Pippenger MSM, 2^%d points in total, %d per GPU, device-resident inputs (%s)"
+                                   % (total.bit_length() - 1, n,
+                                      "BASELINE configs[2]" if world == 1 and total == 1 << 26 else
+                                      "BASELINE configs[3]" if total == 1 << 28 else
+                                      "BASELINE metric: the 2^26 MSM sharded x%d, RCCL all-gather of partial sums" % world if total == 1 << 26 else
+                                      "sharded x%d, RCCL all-gather of partial sums" % world),
+                       "curve": "bls12_381", "points_total": total, "points_per_gpu": n,
+                       "window_bits": plan["window_bits"], "windows": nwins, "window_groups": acc_launches,
+                       "distinct_points": PERIOD, "scalars": "uniform on [0, r), rejection sampled"},
+            "parity": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
-                         "algorithmic_gb_per_launch": achieved * a_ms * 1e-3, "kernel": "k_accumulate",
-                         "kernel_ms": a_ms,
-                         "note": "MSM is integer-multiplier bound, not HBM bound (SURVEY F11): the kernel does "
-                                 "%d mixed additions per launch = %.3e additions/s against 7.29e9/s for the same "
-                                 "addition chain on registers (profiles/r01_montx_vs_mont32.log); rocprofv3 PMC: the vector ALU "
-                                 "issues 83 %% of the kernel's cycles, instruction-cache hit rate > 99.999 %% "
-                                 "(profiles/r01_accumulate_pmc.txt)"
-                                 % (nwins * n, nwins * n / (a_ms * 1e-3)) + traffic_note},
-            "phases_ms": {"digits_sort": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per step (all launches)",
+                         "algorithmic_gb_per_step": MSM_BYTES_PER_POINT * n / 1e9, "kernel": "k_accumulate",
+                         "kernel_ms": a_ms, "launches_per_step": acc_launches, "kernel_ms_per_launch": a_ms / max(1, acc_launches),
+                         "note": "one step runs k_accumulate once per window group (%d launches, each all points x 1/%d of the "
+                                 "windows = 1/%d of the 128 B/point); achieved = 128 B x points / summed launch time. MSM is "
+                                 "integer-multiplier bound, not HBM bound (SURVEY F11): see roofline_alu" % (acc_launches, acc_launches, acc_launches) + traffic_note},
+            "roofline_alu": {"bound": "v_mad_u64_u32 issue", "achieved": mads / (a_ms * 1e-3) / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
+                             "unit": "T mad/s (32x32+64 multiply-adds, lane level)", "frac": mads / (a_ms * 1e-3) / MAD_PEAK_PER_S,
+                             "note": "%d windows x points mixed additions x %d multiply-adds each (8 products + 2 squares on 14 limbs "
+                                     "of 28 bits) against the measured issue peak 0.181 wave-instr/clk/SIMD "
+                                     "(profiles/r01_ubench2_instruction_rates.log) x 1024 SIMDs x 64 lanes x 2.4 GHz"
+                                     % (nwins, MADS_PER_MIXED_ADD)},
+            "phases_ms": {"before_first_accumulate": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
             "cpu_baseline": cpu, "ntt": ntt, "extras": extras,
         }
         print(json.dumps(line))

@@ -86,10 +86,41 @@ SppError cuda_func(void *ptr);
 /*    (msm/pippenger.cuh:351-388,582-610; ntt/ntt.cuh:344-350).              */
 /* ------------------------------------------------------------------------ */
 
-/* The one-shot entry points of section 1 keep their scratch memory (one context per host thread
- * and device) between calls instead of allocating and freeing tens of GB every time, as the
- * reference's per-call msm_t does (msm/pippenger.cuh:730-747).  This gives it back. */
+/* The one-shot entry points of section 1 borrow a context (streams + scratch memory) from a
+ * process-wide pool keyed by device instead of allocating and freeing GBs on every call as the
+ * reference's per-call msm_t does (msm/pippenger.cuh:730-747).  A context goes back to the pool
+ * after the call and keeps its scratch only while that is below SPPARK_MSM_CACHE_BYTES
+ * (environment, default 32 GiB); nothing is tied to the calling thread.  This call frees the
+ * scratch of every idle pooled context (all devices).
+ *
+ * Stream contract of the one-shot entry points: they are synchronous.  Host inputs are copied in
+ * chunks that overlap the arithmetic.  When an input is a DEVICE pointer the call first waits for
+ * the whole device (hipDeviceSynchronize), so data produced on any stream is complete; results
+ * are equal as group elements from run to run, but the Jacobian bytes may differ (the order of
+ * additions inside a bucket depends on LDS-atomic cursors): compare after normalisation, as the
+ * reference's tests do (poc/msm-cuda/tests/msm.rs:26-38). */
 void sppark_msm_release_cached(void);
+
+/* number of usable devices = ngpus() of util/all_gpus.cpp:62-63 (the filtered list) */
+size_t sppark_ngpus(void);
+
+/* Multi-GPU G1 MSM inside one process (north star: "MSM shards the point/scalar vector across
+ * the 8 GPUs of one node").  The reference models one gpu_t per device in a process
+ * (util/all_gpus.cpp:39-63, util/gpu_t.cuh:173-267) but its msm_t drives one of them; here the
+ * vector is cut into ndev contiguous shards, shard i runs on device i on its own host thread
+ * (own context, own streams), and the ndev Jacobian partial sums are added on the host -- one
+ * exchange step of 144 bytes per device.  points / scalars: HOST pointers, same formats as
+ * mult_pippenger_inf (mont != 0: scalars in Montgomery form); ndev == 0: all devices.
+ * The multi-PROCESS variant (one rank per GPU, RCCL all-gather of the partial sums) is
+ * sppark_amd/multi_gpu.py. */
+SppError sppark_msm_multi(void *out, const void *points, size_t npoints, const void *scalars,
+                          int mont, size_t ffi_affine_sz, unsigned ndev);
+/* General form: nshards independent (points[i], npoints[i], scalars[i]) triples; shard i runs on
+ * device device_ids[i] (index in the filtered list; NULL: device i).  Each pointer is a host
+ * pointer or a pointer into the memory of the shard's own device; a device may be named twice. */
+SppError sppark_msm_multi_shards(void *out, const void *const *points, const size_t *npoints,
+                                 const void *const *scalars, int mont, size_t ffi_affine_sz,
+                                 unsigned nshards, const int *device_ids);
 
 typedef struct sppark_msm_ctx sppark_msm_ctx;
 
@@ -108,6 +139,17 @@ SppError sppark_msm_tune_sort(sppark_msm_ctx *ctx, unsigned low_bits);
 /* sort partitions with more entries than this are split over several work-groups (skewed scalars;
  * 0 = automatic, 2^18) */
 SppError sppark_msm_tune_split(sppark_msm_ctx *ctx, unsigned big_partition);
+/* Pipeline shape.  groups: the windows are processed in this many groups, the digits + sort of
+ * group g+1 on a second stream under the bucket accumulation of group g (0 = automatic: 4 from
+ * 2^21 points, else 1; 1 = single stream).  chunk_points: host-resident inputs, and inputs whose
+ * scratch would not fit the device, are processed in chunks of this many points, the copy of
+ * chunk c+1 under the arithmetic of chunk c (0 = automatic).  max_scratch_bytes: upper bound of the
+ * scratch memory the context may allocate; the chunk is halved until it fits (0 = what is free). */
+SppError sppark_msm_tune_pipeline(sppark_msm_ctx *ctx, unsigned groups, size_t chunk_points,
+                                  size_t max_scratch_bytes);
+/* chunks the last invoke was cut into / window groups the context would use for npoints */
+unsigned sppark_msm_last_chunks(const sppark_msm_ctx *ctx);
+unsigned sppark_msm_plan_groups(const sppark_msm_ctx *ctx, size_t npoints);
 SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affine_sz,
                             int host_points, int host_scalars);
 /* Preloaded bases (msm_t(points, np, ffi_affine_sz), msm/pippenger.cuh:351-385): copy npoints
@@ -122,7 +164,9 @@ size_t   sppark_msm_preloaded(const sppark_msm_ctx *ctx);
 SppError sppark_msm_invoke(sppark_msm_ctx *ctx, void *out, const void *points, size_t npoints,
                            const void *scalars, int mont, size_t ffi_affine_sz);
 SppError sppark_msm_enable_timing(sppark_msm_ctx *ctx, int on);
-/* which: 0 digits+sort, 1 bucket accumulation kernel, 2 all device work (ms of the last invoke) */
+/* which: 0 = before the first accumulation launch (exposed sort + point conversion), 1 = the
+ * k_accumulate launches (sum over the window groups), 2 = all device work, 3 = number of
+ * k_accumulate launches; ms of the last invoke (of its first chunk when it was chunked) */
 float    sppark_msm_kernel_ms(const sppark_msm_ctx *ctx, int which);
 size_t   sppark_msm_scratch_bytes(const sppark_msm_ctx *ctx);
 /* plan for npoints: {window bits, windows, buckets/window, run length, partitions, low bits, fan-in, chunk} */

@@ -1,7 +1,8 @@
 """Build the sppark_amd C-ABI libraries for gfx950 with hipcc (cross-compiles
 without a GPU).  One shared object per FEATURE, as the reference builds one per
 -DFEATURE_* (rust/src/build.rs ccmd(); poc/*/build.rs).  Translation units are
-compiled in parallel; libraries are rebuilt only when the contents of csrc/ change.
+compiled in parallel; a library is re-linked when the contents of csrc/ change, a translation
+unit is recompiled only when one of the files it includes (hipcc -MD) or its flags changed.
 
     python -m sppark_amd.build [--force] [--only bls12_381,gl64]
 """
@@ -21,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          "-Wno-duplicate-decl-specifier"]
 
 MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
-           "msm/k_bucket1.hip", "msm/k_bucketN.hip", "api/devtest_api.hip",
+           "msm/k_bucket1.hip", "msm/k_bucketN.hip",
            "msm/k_accumulate.hip:SPPARK_G2", "msm/k_reduce.hip:SPPARK_G2",       # the same kernels over Fp2 (G2)
            "msm/k_bucket1.hip:SPPARK_G2", "msm/k_bucketN.hip:SPPARK_G2",
            "api/ntt_api.hip:SPPARK_NTT_WITH_MSM",          # compute_ntt over the curve's scalar field
@@ -33,7 +34,13 @@ TARGETS = {
     "bn254":     ("FEATURE_BN254", MSM_TUS),
     "gl64":      ("FEATURE_GOLDILOCKS", NTT_TUS),
     "bb31":      ("FEATURE_BABY_BEAR", NTT_TUS),
+    # test-only libraries (device test hooks + micro-benchmarks): never linked into the product ones
+    "bls12_381_devtest": ("FEATURE_BLS12_381", ["api/devtest_api.hip"]),
+    "bn254_devtest":     ("FEATURE_BN254", ["api/devtest_api.hip"]),
+    "gl64_devtest":      ("FEATURE_GOLDILOCKS", ["api/devtest_small_api.hip"]),
+    "bb31_devtest":      ("FEATURE_BABY_BEAR", ["api/devtest_small_api.hip"]),
 }
+PRODUCT = ("bls12_381", "bn254", "gl64", "bb31")
 
 
 def lib_path(name):
@@ -50,13 +57,39 @@ def _sources_stamp():
     return h.hexdigest()[:16]
 
 
+def _deps_changed(obj, cmdline):
+    """True when |obj| must be recompiled: missing, compiled with other flags, or older than one of
+    the files its depfile (-MD) lists.  Keeps an edit of one kernel header from rebuilding the lot."""
+    dep, flg = obj + ".d", obj + ".cmd"
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(flg)):
+        return True
+    if open(flg).read() != cmdline:
+        return True
+    t = os.path.getmtime(obj)
+    txt = open(dep).read().replace("\\\n", " ")
+    for tok in txt.split()[1:]:
+        if tok.endswith(":"):
+            continue
+        try:
+            if os.path.getmtime(tok) > t:
+                return True
+        except OSError:
+            return True
+    return False
+
+
 def _compile(job):
     src, obj, feature = job
     t0 = time.time()
     src, _, extra = src.partition(":")
     cmd = [HIPCC] + FLAGS + ["-D" + feature] + (["-D" + extra] if extra else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    return src, feature, time.time() - t0, r.returncode, r.stderr
+    cmdline = " ".join(cmd)
+    if not _deps_changed(obj, cmdline):
+        return src, feature, 0.0, 0, "", False
+    r = subprocess.run(cmd + ["-MD", "-MF", obj + ".d"], capture_output=True, text=True)
+    if r.returncode == 0:
+        open(obj + ".cmd", "w").write(cmdline)
+    return src, feature, time.time() - t0, r.returncode, r.stderr, True
 
 
 def build(only=None, force=False, verbose=True, jobs=None):
@@ -74,8 +107,10 @@ def build(only=None, force=False, verbose=True, jobs=None):
             continue
         objs = []
         for s in tus:
-            obj = os.path.join(OBJDIR, "%s__%s.o" % (n, s.replace(":", "__").replace("/", "_")))
+            obj = os.path.join(OBJDIR, "%s__%s.o" % (n.replace("_devtest", ""), s.replace(":", "__").replace("/", "_")))
             objs.append(obj)
+            if force and os.path.exists(obj + ".cmd"):
+                os.remove(obj + ".cmd")
             todo.append((s, obj, feature))
         links[n] = objs
     # longest translation units first (measured seconds, BLS12-381 / alt_bn128 roughly 2:1):
@@ -87,8 +122,8 @@ def build(only=None, force=False, verbose=True, jobs=None):
     todo.sort(key=lambda job: -cost.get(job[0], 5) * (2 if "BLS12" in job[2] else 1))
     if todo:
         with cf.ThreadPoolExecutor(max_workers=jobs or os.cpu_count() or 4) as ex:
-            for src, feature, dt, rc, err in ex.map(_compile, todo):
-                if verbose:
+            for src, feature, dt, rc, err, ran in ex.map(_compile, todo):
+                if verbose and ran:
                     print("[sppark_amd.build] %-24s %-20s %6.1fs" % (src, feature, dt), flush=True)
                 if rc != 0:
                     raise RuntimeError("hipcc failed for %s (%s):\n%s" % (src, feature, err))

@@ -1,4 +1,5 @@
-// Device test hooks and micro-benchmarks (exported as sppark_devtest_*).
+// Device test hooks and micro-benchmarks (exported as sppark_devtest_* from
+// libsppark_<curve>_devtest.so -- a TEST library, not part of the product libraries).
 // They exist so that tests/ can check the DEVICE field / point arithmetic
 // element-by-element against the oracle, and so that DESIGN.md's instruction
 // costs are measured on the box rather than assumed.  Not part of the
@@ -10,6 +11,7 @@
 using namespace sppark_amd;
 
 #define SPPARK_FFI extern "C" __attribute__((visibility("default")))
+SPPARK_FFI void drop_error_message(char* ptr) { free(ptr); }
 
 template<class F>
 __global__ void k_field_op(u32* out, const u32* a, const u32* b, unsigned n, int op)

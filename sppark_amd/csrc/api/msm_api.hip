@@ -59,37 +59,111 @@ template<class Fn> static RustError guarded(Fn&& fn)
 }
 
 // The reference's entry points build an msm_t per call (msm/pippenger.cuh:730-747), i.e. a device
-// allocation and release of the whole scratch blob every time.  With tens of GB of scratch that
-// costs up to 100+ ms per call on a busy device, so the one-shot entry points keep ONE context per
-// (host thread, device) alive between calls; sppark_msm_release_cached() gives the memory back.
-template<class Impl> static Impl& cached_context()
-{
-    // raw pointers, never deleted: a destructor running HIP calls at thread / process exit would
-    // race the runtime's own teardown; the driver reclaims the memory with the process
-    static thread_local std::map<int, Impl*> cache;
-    int dev = 0;
-    HIP_OK(hipGetDevice(&dev));
-    Impl*& slot = cache[dev];
-    if (!slot) slot = new Impl(-1);                     // select_gpu(-1): current device
-    return *slot;
-}
-template<class Impl> static void drop_cached_context()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    try { Impl& c = cached_context<Impl>(); c.release_scratch(); } catch (...) {}
-}
+// allocation and release of the whole scratch every time.  With GBs of scratch that costs up to
+// 100+ ms per call on a busy device, so the one-shot entry points borrow a context from a
+// PROCESS-WIDE pool keyed by device (not thread-local: a caller that runs every proof on a fresh
+// thread must not strand one scratch blob per dead thread) and give it back after the call.  A
+// returned context keeps its scratch only while it is below the cache limit
+// (SPPARK_MSM_CACHE_BYTES, default 32 GiB); sppark_msm_release_cached() frees the scratch of
+// every idle context.  The pool itself is never destroyed: destructors running HIP calls at
+// process exit would race the runtime's own teardown.
+#include <mutex>
+#include <thread>
+template<class Impl> class ctx_pool {
+    std::mutex mtx;
+    std::multimap<int, Impl*> idle;         // HIP device ordinal -> idle contexts
+    static size_t cache_limit()
+    {
+        static const size_t lim = [] {
+            const char* e = getenv("SPPARK_MSM_CACHE_BYTES");
+            return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)32 << 30;
+        }();
+        return lim;
+    }
+public:
+    static ctx_pool& get() { static ctx_pool* p = new ctx_pool; return *p; }
+    // |gid|: index in the filtered device list, -1 = the calling thread's current device
+    Impl* take(int gid)
+    {
+        const gpu_info& g = select_gpu(gid);
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            auto it = idle.find(g.hip_id);
+            if (it != idle.end()) { Impl* c = it->second; idle.erase(it); return c; }
+        }
+        return new Impl(g.gid);
+    }
+    void give(Impl* c)
+    {
+        if (c->scratch_bytes() > cache_limit()) c->release_scratch();
+        std::lock_guard<std::mutex> lk(mtx);
+        idle.emplace(c->device(), c);
+    }
+    void release_idle()
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        for (auto& kv : idle) kv.second->release_scratch();
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
+};
+template<class Impl> struct borrowed {      // RAII: back to the pool on every exit path
+    Impl* c;
+    explicit borrowed(int gid) : c(ctx_pool<Impl>::get().take(gid)) {}
+    ~borrowed() { ctx_pool<Impl>::get().give(c); }
+    Impl* operator->() { return c; }
+};
 
 static RustError one_shot(void* out, const void* points, size_t npoints, const void* scalars,
                           bool mont, size_t ffi_sz)
 {
     store_inf(out);
     return guarded([&] {
-        msm_impl& msm = cached_context<msm_impl>();
+        borrowed<msm_impl> msm(-1);
+        // device-resident inputs may have been produced on ANY stream of the caller: the pooled
+        // context's private stream only orders itself after the legacy default stream
+        if (is_device_pointer(points) || is_device_pointer(scalars)) HIP_OK(hipDeviceSynchronize());
         point_t r;
-        msm.invoke(r, points, npoints, scalars, mont, ffi_sz);
+        msm->invoke(r, points, npoints, scalars, mont, ffi_sz);
         store_point(out, r);
     });
+}
+
+// Multi-GPU MSM inside ONE process (the reference keeps one gpu_t per device in a process,
+// util/all_gpus.cpp:39-63, but its msm_t drives a single one): shard i runs on device
+// device_ids[i] on its own host thread with a context of its own; the partial results are added
+// on the host.  Sum_i s_i*P_i splits over any partition of the index set, so there is exactly
+// one exchange step, of 144-byte points.
+static void msm_shards(point_t& out, const void* const* points, const size_t* npoints, const void* const* scalars,
+                       bool mont, size_t ffi_sz, unsigned nshards, const int* device_ids)
+{
+    out.set_inf();
+    if (nshards == 0) return;
+    std::vector<point_t> part(nshards);
+    std::vector<RustError> err(nshards, rust_ok());
+    auto work = [&](unsigned i) {
+        err[i] = guarded([&] {
+            part[i].set_inf();
+            if (npoints[i] == 0) return;
+            borrowed<msm_impl> msm(device_ids ? device_ids[i] : (int)i);
+            msm->invoke(part[i], points[i], npoints[i], scalars[i], mont, ffi_sz);
+        });
+    };
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    std::vector<std::thread> threads;
+    for (unsigned i = 1; i < nshards; i++) threads.emplace_back(work, i);
+    work(0);
+    for (auto& t : threads) t.join();
+    if (cur >= 0) (void)hipSetDevice(cur);      // shard 0 ran on this thread and selected its device
+    for (unsigned i = 0; i < nshards; i++)
+        if (err[i].code) {
+            std::string msg = err[i].message ? err[i].message : "";
+            for (auto& e : err) free(e.message);
+            throw hip_error(err[i].code, "shard " + std::to_string(i) + ": " + msg);
+        }
+    for (unsigned i = 0; i < nshards; i++) out.add(part[i]);
 }
 
 extern "C" {
@@ -107,16 +181,70 @@ SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_
 {
     memset(out, 0, sizeof(point2_t));
     return guarded([&] {
-        msm2_impl& msm = cached_context<msm2_impl>();
+        borrowed<msm2_impl> msm(-1);
+        if (is_device_pointer(points) || is_device_pointer(scalars)) HIP_OK(hipDeviceSynchronize());
         point2_t r;
-        msm.invoke(r, points, npoints, scalars, false, ffi_affine_sz);
+        msm->invoke(r, points, npoints, scalars, false, ffi_affine_sz);
         memcpy(out, &r, sizeof(r));
     });
 }
 
-// release the scratch memory kept by this thread's one-shot contexts on the current device
+// free the scratch memory kept by the idle one-shot contexts (all devices)
 SPPARK_FFI void sppark_msm_release_cached(void)
-{   drop_cached_context<msm_impl>(); drop_cached_context<msm2_impl>();   }
+{   ctx_pool<msm_impl>::get().release_idle(); ctx_pool<msm2_impl>::get().release_idle();   }
+
+// number of usable devices (the filtered list of util/all_gpus.cpp:39-54; ngpus(), :62-63)
+SPPARK_FFI size_t sppark_ngpus(void) { return gpus_t::all().size(); }
+
+// Multi-GPU G1 MSM in one process: the vector is cut into ndev contiguous shards (shard i =
+// [i*n/ndev, (i+1)*n/ndev)) that run concurrently on devices 0..ndev-1; ndev == 0 = all devices.
+// points / scalars: HOST pointers (each device copies its own shard, chunk by chunk).
+SPPARK_FFI RustError sppark_msm_multi(void* out, const void* points, size_t npoints, const void* scalars,
+                                      int mont, size_t ffi_affine_sz, unsigned ndev)
+{
+    store_inf(out);
+    return guarded([&] {
+        const size_t avail = gpus_t::all().size();
+        if (avail == 0) HIP_OK(hipErrorNoDevice);
+        if (ndev == 0) ndev = (unsigned)avail;
+        if (ndev > avail || ffi_affine_sz < 2 * sizeof(fp_h) || (npoints && (!points || !scalars))) HIP_OK(hipErrorInvalidValue);
+        std::vector<const void*> p(ndev), s(ndev);
+        std::vector<size_t> n(ndev);
+        std::vector<int> ids(ndev);
+        const size_t base = npoints / ndev, rem = npoints % ndev;
+        for (unsigned i = 0; i < ndev; i++) {
+            size_t lo = i * base + std::min<size_t>(i, rem);
+            n[i] = base + (i < rem ? 1 : 0);
+            p[i] = (const char*)points + lo * ffi_affine_sz;
+            s[i] = (const char*)scalars + lo * sizeof(fr_d);
+            ids[i] = (int)i;
+        }
+        point_t r;
+        msm_shards(r, p.data(), n.data(), s.data(), mont != 0, ffi_affine_sz, ndev, ids.data());
+        store_point(out, r);
+    });
+}
+// The general form: nshards independent (points, npoints, scalars) triples, shard i on device
+// device_ids[i] (index in the filtered list; NULL = device i).  Pointers may be host pointers or
+// pointers into the memory of the shard's own device.  A device may appear more than once.
+SPPARK_FFI RustError sppark_msm_multi_shards(void* out, const void* const* points, const size_t* npoints,
+                                             const void* const* scalars, int mont, size_t ffi_affine_sz,
+                                             unsigned nshards, const int* device_ids)
+{
+    store_inf(out);
+    return guarded([&] {
+        if (nshards && (!points || !npoints || !scalars)) HIP_OK(hipErrorInvalidValue);
+        if (ffi_affine_sz < 2 * sizeof(fp_h)) HIP_OK(hipErrorInvalidValue);
+        const size_t avail = gpus_t::all().size();
+        for (unsigned i = 0; i < nshards; i++) {
+            int id = device_ids ? device_ids[i] : (int)i;
+            if (id < 0 || (size_t)id >= avail) HIP_OK(hipErrorInvalidDevice);
+        }
+        point_t r;
+        msm_shards(r, points, npoints, scalars, mont != 0, ffi_affine_sz, nshards, device_ids);
+        store_point(out, r);
+    });
+}
 
 SPPARK_FFI RustError sppark_msm_create(sppark_msm_ctx** ctx, int device_id, void* stream)
 {
@@ -141,6 +269,11 @@ SPPARK_FFI RustError sppark_msm_tune_sort(sppark_msm_ctx* ctx, unsigned low_bits
 // level-A partitions with more entries than this are sorted by several work-groups (0 = 2^18)
 SPPARK_FFI RustError sppark_msm_tune_split(sppark_msm_ctx* ctx, unsigned big_partition)
 {   return guarded([&] { ctx->impl.tune.big = big_partition; });   }
+// pipeline shape: window groups (0 = automatic, 1 = single stream), points per chunk of the
+// chunked path (0 = automatic), upper bound of the scratch memory in bytes (0 = what the device has)
+SPPARK_FFI RustError sppark_msm_tune_pipeline(sppark_msm_ctx* ctx, unsigned groups, size_t chunk_points, size_t max_scratch_bytes)
+{   return guarded([&] { ctx->impl.tune.groups = groups; ctx->impl.tune.chunk = chunk_points; ctx->impl.tune.max_scratch = max_scratch_bytes; });   }
+SPPARK_FFI unsigned sppark_msm_last_chunks(const sppark_msm_ctx* ctx) { return ctx->impl.chunks_of_last_invoke(); }
 SPPARK_FFI RustError sppark_msm_reserve(sppark_msm_ctx* ctx, size_t npoints, size_t ffi_affine_sz,
                                         int host_points, int host_scalars)
 {   return guarded([&] { ctx->impl.reserve_for(npoints, ffi_affine_sz, host_points, host_scalars); });   }
@@ -168,6 +301,8 @@ SPPARK_FFI void sppark_msm_plan(const sppark_msm_ctx* ctx, size_t npoints, unsig
     msm_plan p = ctx->impl.plan_for(npoints);
     out[0] = p.wbits; out[1] = p.nwins; out[2] = p.NB; out[3] = p.L; out[4] = p.NA; out[5] = p.LB; out[6] = p.F; out[7] = p.K;
 }
+// window groups the context would use for |npoints|
+SPPARK_FFI unsigned sppark_msm_plan_groups(const sppark_msm_ctx* ctx, size_t npoints) { return ctx->impl.plan_for(npoints).G; }
 
 // ---- host-side point helpers (no GPU work) --------------------------------
 SPPARK_FFI void sppark_g1_jacobian_sum(void* out, const void* points, size_t n)

@@ -1,10 +1,23 @@
 // Host driver of the MI355X MSM pipeline: plays the role of the reference's
-// msm_t (msm/pippenger.cuh:325-728) -- window choice, one device blob, kernel
+// msm_t (msm/pippenger.cuh:325-728) -- window choice, device scratch, kernel
 // sequence, error mapping -- re-planned for a 288 GB / 256-CU part:
 //
-//  * no batching: the whole point/scalar vector is resident (the reference
-//    streams 2^24-point strides through a 3-stream pipeline, :454-557, to stay
-//    inside a few GB);
+//  * WINDOW GROUPS on two streams.  The W windows are cut into G groups; the digits + counting
+//    sort of group g+1 run on an auxiliary stream while the bucket accumulation of group g runs
+//    on the main one.  The sort kernels are bound by scattered memory transactions and are
+//    built to fit beside k_accumulate on the same CU (512-lane work-groups, <= 24 VGPRs, see
+//    msm_sort_kernels.hpp), the accumulation is bound by the integer multiplier and uses no
+//    LDS: apart from the first group's sort the whole sort disappears behind the arithmetic.
+//    Scratch for digits / partitions / sorted lists is two group-sized sets instead of W.
+//    (The reference overlaps its sort with the previous batch's accumulation through a
+//    3-stream flip-flop over POINT batches, pippenger.cuh:494-557.)
+//  * CHUNKS.  Host-resident inputs (what mult_pippenger_inf's callers pass) are cut into
+//    point chunks: chunk c+1 is copied to the device (scalars first) while chunk c is being
+//    computed; every chunk is a complete MSM and the partial results are added on the host.
+//    The same loop bounds the scratch memory: when the device cannot hold the scratch of the
+//    whole MSM (or tune.max_scratch says so) the chunk is halved until it does, for host AND
+//    device-resident inputs.  The reference streams 2^24-point strides for the same two
+//    reasons (pippenger.cuh:454-459,494-557).
 //  * no cooperative launches or device-global work counters (:157-223): kernel
 //    boundaries are the only grid-wide synchronisation;
 //  * the host part is O(windows): it receives one XYZZ sum per window and runs
@@ -12,8 +25,7 @@
 //    window on a host thread pool, :627-727).
 //
 // Inputs may be host or device pointers (cf. is_device_ptr, util/gpu_t.cuh:385-395,
-// and the preloaded-points constructor :351-388): device pointers are used in
-// place, host pointers are staged with one H2D copy each.
+// and the preloaded-points constructor :351-388).
 #pragma once
 #include "msm_kernels.hpp"
 #include "../ec/jacobian_host.hpp"
@@ -31,11 +43,15 @@ struct msm_plan {
     unsigned nslabs, slab_sz;           // hist/scatter point slabs
     unsigned F;                         // reduce_runs fan-in
     unsigned K;                         // bucket-reduction chunk
+    unsigned G, wpg;                    // window groups, windows per group (the last group may be shorter)
 };
 
 struct msm_tunables {                   // 0 = automatic
     unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0, LB = 0;
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
+    unsigned groups = 0;                // window groups (1 = everything on one stream)
+    size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
+    size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
 };
 
 static inline unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
@@ -74,6 +90,12 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.F = std::max(4u, t.F ? t.F : 8u);        // fan-in < 3 would never shrink the record list
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
+    // window groups: below ~2^21 points an MSM is a chain of latency-bound launches and a second
+    // stream only adds events; above, four groups leave 1/4 of the sort exposed
+    unsigned G = t.groups ? t.groups : (lg >= 21 ? 4u : 1u);
+    G = std::max(1u, std::min(G, p.nwins));
+    p.wpg = (p.nwins + G - 1) / G;
+    p.G = (p.nwins + p.wpg - 1) / p.wpg;
     return p;
 }
 
@@ -93,23 +115,33 @@ public:
     typedef xyzz_mem<STD_WORDS> std_bucket_t;
     static_assert(INTERNAL || sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
+    static constexpr unsigned MAX_WINS = 128;
 
 private:
     const gpu_info* gpu;
-    hipStream_t stream;
+    hipStream_t stream;                 // main stream: the caller's, or a private one
     bool own_stream;
+    hipStream_t aux = nullptr;          // sort of the next window group
+    hipStream_t cpy = nullptr;          // host -> device copies of the next chunk
     hipEvent_t join_ev = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_accdone[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_chunkdone[2] = {nullptr, nullptr};
     unsigned char* blob = nullptr;
     size_t blob_sz = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned char* stage = nullptr;     // two staging sets for host-resident chunks
+    size_t stage_sz = 0;
+    std_bucket_t* h_sums = nullptr;     // pinned: window sums of every chunk in flight
+    size_t h_sums_cap = 0;
+    std::vector<hipEvent_t> tev;        // timing events: [0] start, [1] end, [2+2g], [3+2g] around k_accumulate of group g
     unsigned char* pre_points = nullptr;    // points kept on the device by preload() (msm_t ctor with points, pippenger.cuh:351-385)
     size_t pre_n = 0, pre_stride = 0;
-    float last_ms[3] = {0, 0, 0};       // [0] digits+sort, [1] accumulate, [2] whole device part
+    float last_ms[4] = {0, 0, 0, 0};    // [0] before the first accumulation, [1] accumulation kernels, [2] whole device part, [3] accumulate launches
+    unsigned last_chunks = 0;
     bool timing = false;
 
     struct layout {
-        size_t points, scalars, digits, sorted, partA, H, tot, offA, off, buckets;
-        size_t keyA, ptA, keyB, ptB, A1, W1, A2, W2, conv, fin, curB, bigl, total;
+        size_t digits[2], sorted[2], partA[2], H[2], tot[2], offA[2], off[2], curB[2], bigl[2];
+        size_t buckets, keyA, ptA, keyB, ptB, A1, W1, A2, W2, conv, sums, total;
     };
 
     static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -118,32 +150,37 @@ private:
         if constexpr (INTERNAL) return affine_loader<FD>::STRIDE; else return 0;
     }
 
-    layout make_layout(const msm_plan& p, size_t pts_bytes, size_t sc_bytes, bool convert = true) const
+    layout make_layout(const msm_plan& p, bool convert) const
     {
         layout l; size_t o = 0;
         auto take = [&](size_t sz) { size_t r = o; o += align_up(sz); return r; };
-        l.points  = take(pts_bytes);
-        l.scalars = take(sc_bytes);
-        l.digits  = take((size_t)p.nwins * p.n * 4);
-        l.sorted  = take((size_t)p.nwins * p.n * 4);
-        l.partA   = take((size_t)p.nwins * p.n * 8);
-        l.H       = take((size_t)p.nwins * p.nslabs * p.NA * 4);
-        l.tot     = take((size_t)p.nwins * p.NA * 4);
-        l.offA    = take((size_t)p.nwins * (p.NA + 1) * 4);
-        l.off     = take((size_t)p.nwins * (p.NB + 1) * 4);
-        l.buckets = take((size_t)p.nwins * p.NB * sizeof(bucket_t));
-        size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win;
+        const size_t wg = p.wpg;
+        for (unsigned b = 0; b < 2; b++) {
+            if (b == 1 && p.G == 1) {               // a single group needs one set
+                l.digits[1] = l.digits[0]; l.sorted[1] = l.sorted[0]; l.partA[1] = l.partA[0]; l.H[1] = l.H[0]; l.tot[1] = l.tot[0];
+                l.offA[1] = l.offA[0]; l.off[1] = l.off[0]; l.curB[1] = l.curB[0]; l.bigl[1] = l.bigl[0];
+                break;
+            }
+            l.digits[b] = take(wg * p.n * 4);
+            l.sorted[b] = take(wg * p.n * 4);
+            l.partA[b]  = take(wg * p.n * 8);
+            l.H[b]      = take(wg * p.nslabs * p.NA * 4);
+            l.tot[b]    = take(wg * p.NA * 4);
+            l.offA[b]   = take(wg * (p.NA + 1) * 4);
+            l.off[b]    = take(wg * ((size_t)p.NB + 1) * 4);
+            l.curB[b]   = take(wg * ((size_t)p.NB + 1) * 4);                    // cursors of the cooperative sort
+            l.bigl[b]   = take((wg * p.NA + 1) * 4);                            // [count | list of oversized partitions]
+        }
+        l.buckets = take(wg * p.NB * sizeof(bucket_t));
+        size_t nrecA = (size_t)2 * wg * p.chunks_per_win;
         size_t nrecB = 2 * ((nrecA + p.F - 1) / p.F);
         l.keyA = take(nrecA * 4); l.ptA = take(nrecA * sizeof(bucket_t));
         l.keyB = take(nrecB * 4); l.ptB = take(nrecB * sizeof(bucket_t));
-        size_t n1 = (size_t)p.nwins * (p.NB / p.K);
-        size_t n2 = n1;
+        size_t n1 = wg * (p.NB / p.K);
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
-        l.A2 = take(n2 * sizeof(bucket_t)); l.W2 = take(n2 * sizeof(bucket_t));
+        l.A2 = take(n1 * sizeof(bucket_t)); l.W2 = take(n1 * sizeof(bucket_t));
         l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
-        l.fin  = take(INTERNAL ? (size_t)p.nwins * sizeof(std_bucket_t) : 0);
-        l.curB = take((size_t)p.nwins * (p.NB + 1) * 4);                    // cursors of the cooperative sort
-        l.bigl = take(((size_t)p.nwins * p.NA + 1) * 4);                    // [count | list of oversized partitions]
+        l.sums = take((size_t)p.nwins * std::max(sizeof(std_bucket_t), sizeof(bucket_t)));
         l.total = o;
         return l;
     }
@@ -151,9 +188,44 @@ private:
     void reserve(size_t sz)
     {
         if (sz <= blob_sz) return;
-        if (blob) { HIP_OK(hipFree(blob)); blob = nullptr; blob_sz = 0; }
+        if (blob) { HIP_OK(hipStreamSynchronize(stream)); HIP_OK(hipFree(blob)); blob = nullptr; blob_sz = 0; }
         HIP_OK(hipMalloc((void**)&blob, sz));
         blob_sz = sz;
+    }
+    void reserve_stage(size_t sz)
+    {
+        if (sz <= stage_sz) return;
+        if (stage) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(stage)); stage = nullptr; stage_sz = 0; }
+        HIP_OK(hipMalloc((void**)&stage, sz));
+        stage_sz = sz;
+    }
+    void reserve_sums(size_t count)
+    {
+        if (count <= h_sums_cap) return;
+        if (h_sums) { HIP_OK(hipStreamSynchronize(stream)); HIP_OK(hipHostFree(h_sums)); h_sums = nullptr; h_sums_cap = 0; }
+        HIP_OK(hipHostMalloc((void**)&h_sums, count * sizeof(std_bucket_t), hipHostMallocDefault));
+        h_sums_cap = count;
+    }
+    void need_event(hipEvent_t& e) { if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    void need_aux()
+    {
+        if (aux) return;
+        int lo = 0, hi = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
+        // the sort of the next group is short and on the critical path of the next accumulation
+        HIP_OK(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi));
+        need_event(ev_fork);
+        for (int b = 0; b < 2; b++) { need_event(ev_sorted[b]); need_event(ev_accdone[b]); }
+    }
+    void need_cpy()
+    {
+        if (cpy) return;
+        HIP_OK(hipStreamCreateWithFlags(&cpy, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) { need_event(ev_copied[b]); need_event(ev_chunkdone[b]); }
+    }
+    void need_tev(size_t count)
+    {
+        while (tev.size() < count) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); tev.push_back(e); }
     }
 
 public:
@@ -173,42 +245,64 @@ public:
     }
     ~msm_t()
     {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != gpu->hip_id) (void)hipSetDevice(gpu->hip_id);
         (void)hipStreamSynchronize(stream);
+        if (aux) (void)hipStreamSynchronize(aux);
+        if (cpy) (void)hipStreamSynchronize(cpy);
         if (blob) (void)hipFree(blob);
+        if (stage) (void)hipFree(stage);
+        if (h_sums) (void)hipHostFree(h_sums);
         if (pre_points) (void)hipFree(pre_points);
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : tev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_fork, ev_sorted[0], ev_sorted[1], ev_accdone[0], ev_accdone[1],
+                             ev_copied[0], ev_copied[1], ev_chunkdone[0], ev_chunkdone[1], join_ev})
+            if (e) (void)hipEventDestroy(e);
+        if (aux) (void)hipStreamDestroy(aux);
+        if (cpy) (void)hipStreamDestroy(cpy);
         if (own_stream) (void)hipStreamDestroy(stream);
-        if (join_ev) (void)hipEventDestroy(join_ev);
+        if (cur >= 0 && cur != gpu->hip_id) (void)hipSetDevice(cur);
     }
     msm_t(const msm_t&) = delete;
     msm_t& operator=(const msm_t&) = delete;
 
+    int device() const { return gpu->hip_id; }
     void set_stream(hipStream_t s)
     {
+        (void)hipStreamSynchronize(stream);
         if (own_stream) { (void)hipStreamDestroy(stream); own_stream = false; }
         stream = s;
+        if (stream == nullptr) {
+            HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            if (!join_ev) HIP_OK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+            own_stream = true;
+        }
     }
-    void enable_timing(bool on)
-    {
-        timing = on;
-        if (on) for (auto& e : ev) if (!e) HIP_OK(hipEventCreate(&e));
-    }
-    float kernel_ms(int which) const { return which >= 0 && which < 3 ? last_ms[which] : -1.f; }
-    size_t scratch_bytes() const { return blob_sz; }
+    void enable_timing(bool on) { timing = on; }
+    float kernel_ms(int which) const { return which >= 0 && which < 4 ? last_ms[which] : -1.f; }
+    unsigned chunks_of_last_invoke() const { return last_chunks; }
+    size_t scratch_bytes() const { return blob_sz + stage_sz; }
     void release_scratch()
     {
+        (void)hipSetDevice(gpu->hip_id);
         (void)hipStreamSynchronize(stream);
+        if (aux) (void)hipStreamSynchronize(aux);
+        if (cpy) (void)hipStreamSynchronize(cpy);
         if (blob) { (void)hipFree(blob); blob = nullptr; blob_sz = 0; }
+        if (stage) { (void)hipFree(stage); stage = nullptr; stage_sz = 0; }
     }
     msm_plan plan_for(size_t npoints) const { return make_plan(npoints, FRp::NBITS, tune); }
 
-    // Size the blob for |npoints| ahead of time (so a timed invoke does not allocate).
+    // Size the scratch for |npoints| ahead of time (so a timed invoke does not allocate).
     void reserve_for(size_t npoints, size_t ffi_affine_sz, bool host_points, bool host_scalars)
     {
-        msm_plan p = make_plan(npoints, FRp::NBITS, tune);
-        layout l = make_layout(p, host_points ? npoints * ffi_affine_sz : 0,
-                                  host_scalars ? npoints * SCALAR_BYTES : 0);
-        reserve(l.total);
+        HIP_OK(hipSetDevice(gpu->hip_id));
+        size_t chunk = choose_chunk(npoints, (host_points ? ffi_affine_sz : 0) + (host_scalars ? SCALAR_BYTES : 0));
+        msm_plan p = make_plan(chunk, FRp::NBITS, tune);
+        reserve(make_layout(p, true).total);
+        if (host_points || host_scalars)
+            reserve_stage(2 * (align_up(host_points ? chunk * ffi_affine_sz : 0) + align_up(host_scalars ? chunk * SCALAR_BYTES : 0)));
     }
 
     // Private stream only: wait for everything queued so far on the legacy default stream, where
@@ -232,37 +326,236 @@ public:
         if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
         if (np == 0) return;
         if (points == nullptr || ffi_affine_sz < 2 * FP_BYTES || np > (1u << 31)) HIP_OK(hipErrorInvalidValue);
-        if constexpr (INTERNAL) {
-            // bases are constant across invocations: convert them into the field's own records once
-            const unsigned char* src = (const unsigned char*)points;
-            unsigned char* staging = nullptr;
-            if (!is_device_pointer(points)) {
-                HIP_OK(hipMalloc((void**)&staging, np * ffi_affine_sz));
-                HIP_OK(hipMemcpyAsync(staging, points, np * ffi_affine_sz, hipMemcpyHostToDevice, stream));
-                src = staging;
+        struct dev_buf {                // staging copy of host-resident points: freed on every exit path
+            unsigned char* p = nullptr;
+            ~dev_buf() { if (p) (void)hipFree(p); }
+        } staging;
+        try {
+            if constexpr (INTERNAL) {
+                // bases are constant across invocations: convert them into the field's own records once
+                const unsigned char* src = (const unsigned char*)points;
+                if (!is_device_pointer(points)) {
+                    HIP_OK(hipMalloc((void**)&staging.p, np * ffi_affine_sz));
+                    HIP_OK(hipMemcpyAsync(staging.p, points, np * ffi_affine_sz, hipMemcpyHostToDevice, stream));
+                    src = staging.p;
+                }
+                HIP_OK(hipMalloc((void**)&pre_points, np * conv_stride()));
+                launch_convert(pre_points, src, (unsigned)np, ffi_affine_sz);
+            } else {
+                HIP_OK(hipMalloc((void**)&pre_points, np * ffi_affine_sz));
+                HIP_OK(hipMemcpyAsync(pre_points, points, np * ffi_affine_sz,
+                                      is_device_pointer(points) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
             }
-            hipError_t e = hipMalloc((void**)&pre_points, np * conv_stride());
-            if (e == hipSuccess) {
-                unsigned grid = (unsigned)((np + 255) / 256);
-                if (ffi_affine_sz > 2 * FP_BYTES)
-                    hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream, pre_points, src, (unsigned)np, (unsigned)ffi_affine_sz);
-                else
-                    hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, stream, pre_points, src, (unsigned)np, (unsigned)ffi_affine_sz);
-                e = hipGetLastError();
-                if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            }
-            if (staging) (void)hipFree(staging);
-            if (e != hipSuccess) { if (pre_points) { (void)hipFree(pre_points); pre_points = nullptr; } HIP_OK(e); }
-        } else {
-            HIP_OK(hipMalloc((void**)&pre_points, np * ffi_affine_sz));
-            HIP_OK(hipMemcpyAsync(pre_points, points, np * ffi_affine_sz,
-                                  is_device_pointer(points) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
             HIP_OK(hipStreamSynchronize(stream));
+        } catch (...) {
+            if (pre_points) { (void)hipFree(pre_points); pre_points = nullptr; }
+            throw;
         }
         pre_n = np; pre_stride = ffi_affine_sz;
     }
     size_t preloaded() const { return pre_n; }
 
+private:
+    void launch_convert(unsigned char* dst, const unsigned char* src, unsigned n, size_t stride)
+    {
+        if constexpr (INTERNAL) {
+            unsigned grid = (n + 255) / 256;
+            if (stride > 2 * FP_BYTES) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream, dst, src, n, (unsigned)stride);
+            else                       hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, stream, dst, src, n, (unsigned)stride);
+            HIP_OK(hipGetLastError());
+        }
+    }
+
+    // points per chunk.  |stage_per_point|: bytes of host-resident input per point that have to be
+    // copied (0: everything is on the device); chunking then overlaps the copies with the
+    // arithmetic.  Device-resident inputs are chunked only when the scratch would not fit.
+    size_t choose_chunk(size_t n, size_t stage_per_point) const
+    {
+        size_t chunk = n;
+        if (tune.chunk) chunk = std::min(n, std::max<size_t>(tune.chunk, 1));
+        else if (stage_per_point && n > ((size_t)1 << 21)) {
+            // ~8 chunks: the exposed first copy and last computation are 1/8 of the total each;
+            // 2^20..2^24 points per chunk keep every chunk an efficient MSM
+            chunk = std::min<size_t>(std::max<size_t>(n / 8, (size_t)1 << 20), (size_t)1 << 24);
+        }
+        auto need = [&](size_t c) {
+            return make_layout(make_plan(c, FRp::NBITS, tune), true).total + 2 * c * stage_per_point + 1024;
+        };
+        size_t limit = tune.max_scratch;
+        if (!limit) {
+            if (need(chunk) <= blob_sz + stage_sz) return chunk;        // already reserved: no driver query
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return chunk; }
+            limit = free_b - (free_b >> 5) + blob_sz + stage_sz;        // what this context may hold in total
+        }
+        while (need(chunk) > limit && chunk > 4096) chunk = (chunk + 1) / 2;
+        return chunk;
+    }
+
+    // ---- one complete MSM over device-resident data, asynchronously on stream (+ aux) --------
+    // d_points: wire points (stride, flagged) or, when preconverted, the field's own records.
+    // h_out: nwins window sums in pinned host memory (valid after the stream has been synchronised).
+    void enqueue(const msm_plan& p, const layout& l, const unsigned char* d_points, size_t stride, bool preconverted,
+                 const u32* d_scalars, bool mont, std_bucket_t* h_out, bool first_timed)
+    {
+        const bool flagged = !preconverted && stride > 2 * FP_BYTES;
+        const bool two = p.G > 1;
+        if (two) need_aux();
+        if (timing && first_timed) { need_tev(2 + 2 * p.G); HIP_OK(hipEventRecord(tev[0], stream)); }
+        if (two) {                                  // everything queued on the main stream so far (inputs, the
+            HIP_OK(hipEventRecord(ev_fork, stream));        // previous MSM on this scratch) precedes the first sort
+            HIP_OK(hipStreamWaitEvent(aux, ev_fork, 0));
+        }
+        bucket_t* buckets = (bucket_t*)(blob + l.buckets);
+        std_bucket_t* d_sums_std = (std_bucket_t*)(blob + l.sums);
+        bucket_t* d_sums_raw = (bucket_t*)(blob + l.sums);
+
+        for (unsigned g = 0; g < p.G; g++) {
+            const unsigned b = g & 1, w0 = g * p.wpg, wn = std::min(p.wpg, p.nwins - w0);
+            hipStream_t ss = two ? aux : stream;
+            u32* digits = (u32*)(blob + l.digits[b]);
+            u32* sorted = (u32*)(blob + l.sorted[b]);
+            u32* H = (u32*)(blob + l.H[b]);
+            u32* tot = (u32*)(blob + l.tot[b]);
+            u32* off = (u32*)(blob + l.off[b]);
+            uint2* partA = (uint2*)(blob + l.partA[b]);
+            u32* offA = (u32*)(blob + l.offA[b]);
+
+            // ---- digits + counting sort of the group (aux stream) ------------------------
+            if (two && g >= 2) HIP_OK(hipStreamWaitEvent(aux, ev_accdone[b], 0));    // accumulate(g-2) has read this set
+            {
+                unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
+                hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
+                                   digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
+                HIP_OK(hipGetLastError());
+                size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + 4096;
+                if (ldsA > 65536) {
+                    HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+                    HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+                }
+                if (ldsB > 65536)
+                    HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+                hipLaunchKernelGGL(k_histA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                                   H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+                HIP_OK(hipGetLastError());
+                size_t na_total = (size_t)wn * p.NA;
+                hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((na_total + 255) / 256)), dim3(256), 0, ss,
+                                   H, tot, p.nslabs, p.NA, wn);
+                HIP_OK(hipGetLastError());
+                hipLaunchKernelGGL(k_scan_parts, dim3(wn), dim3(1024), 0, ss, offA, tot, p.NA);
+                HIP_OK(hipGetLastError());
+                hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                                   partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+                HIP_OK(hipGetLastError());
+                const unsigned big = tune.big ? tune.big : (1u << 18);
+                u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
+                HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
+                hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
+                                   sorted, off, partA, offA, p.n, p.NA, p.LB, big);
+                HIP_OK(hipGetLastError());
+                // oversized partitions (skewed scalars); empty list and immediate return otherwise
+                hipLaunchKernelGGL(k_big_find, dim3((p.NA * wn + 255) / 256), dim3(256), 0, ss,
+                                   nbig, blist, off, offA, p.NA, p.LB, wn, big);
+                size_t ldsBig = ((size_t)1 << p.LB) * 4;
+                hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB);
+                hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB);
+                hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB);
+                HIP_OK(hipGetLastError());
+            }
+            if (two) HIP_OK(hipEventRecord(ev_sorted[b], aux));
+
+            // ---- main stream -------------------------------------------------------------
+            if (g == 0 && INTERNAL && !preconverted) {  // wire points -> the field's own records (2 products per
+                launch_convert(blob + l.conv, d_points, p.n, stride);   // point), beside the first group's sort
+                d_points = blob + l.conv;
+            }
+            HIP_OK(hipMemsetAsync(buckets, 0, (size_t)wn * p.NB * sizeof(bucket_t), stream));
+            if (two) HIP_OK(hipStreamWaitEvent(stream, ev_sorted[b], 0));
+
+            // bucket accumulation: level 0 + segmented tree
+            u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
+            u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
+            if (timing && first_timed) HIP_OK(hipEventRecord(tev[2 + 2 * g], stream));
+            {
+                dim3 grid((p.chunks_per_win + 255) / 256, wn);
+                // (fields with their own records read them at their own stride and ignore this one)
+                if (flagged)
+                    hipLaunchKernelGGL((k_accumulate<fp_d, true>), grid, dim3(256), 0, stream,
+                                       buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
+                                       p.n, p.NB, p.L, p.chunks_per_win);
+                else
+                    hipLaunchKernelGGL((k_accumulate<fp_d, false>), grid, dim3(256), 0, stream,
+                                       buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
+                                       p.n, p.NB, p.L, p.chunks_per_win);
+                HIP_OK(hipGetLastError());
+            }
+            if (timing && first_timed) HIP_OK(hipEventRecord(tev[3 + 2 * g], stream));
+            if (two && g + 2 < p.G) HIP_OK(hipEventRecord(ev_accdone[b], stream));
+            {
+                size_t nrec = (size_t)2 * wn * p.chunks_per_win;
+                u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
+                for (;;) {
+                    unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
+                    int last = nthreads == 1;
+                    hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
+                                       buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last);
+                    HIP_OK(hipGetLastError());
+                    if (last) break;
+                    nrec = (size_t)2 * nthreads;
+                    std::swap(ik, ok); std::swap(ip, op);
+                }
+            }
+
+            // per-window weighted bucket sums
+            bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
+            bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
+            bucket_t* result;
+            {
+                unsigned nitems = p.NB / p.K;
+                size_t nthr = (size_t)wn * nitems;
+                hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                   A1, W1, buckets, p.NB, p.K, wn);
+                HIP_OK(hipGetLastError());
+                unsigned lgG = lg2_floor(p.K);
+                bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
+                while (nitems > 1) {
+                    unsigned K = std::min(p.K, nitems);
+                    nthr = (size_t)wn * (nitems / K);
+                    hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                       oa, ow, ia, iw, nitems, K, lgG, wn);
+                    HIP_OK(hipGetLastError());
+                    nitems /= K; lgG += lg2_floor(K);
+                    std::swap(ia, oa); std::swap(iw, ow);
+                }
+                result = iw;
+            }
+            // the group's window sums -> their slots of the sums area (wire image for internal fields)
+            if constexpr (INTERNAL) {
+                hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((wn + 63) / 64), dim3(64), 0, stream, d_sums_std + w0, result, wn);
+                HIP_OK(hipGetLastError());
+            } else {
+                HIP_OK(hipMemcpyAsync(d_sums_raw + w0, result, wn * sizeof(bucket_t), hipMemcpyDeviceToDevice, stream));
+            }
+        }
+        if (timing && first_timed) HIP_OK(hipEventRecord(tev[1], stream));
+        HIP_OK(hipMemcpyAsync(h_out, blob + l.sums, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+    }
+
+    // Horner over the window sums (the reference's host-side collect, pippenger.cuh:627-727, is O(256 * windows))
+    static point_t horner(const std_bucket_t* sums, const msm_plan& p)
+    {
+        point_t out; out.set_inf();
+        for (unsigned w = p.nwins; w--;) {
+            fp_h c[4];
+            memcpy(c, &sums[w], sizeof(c));
+            point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
+            out.add(s);
+            if (w) for (unsigned k = 0; k < window_len(w - 1, p.nwins, p.nbits); k++) out.dbl();
+        }
+        return out;
+    }
+
+public:
     // out: Jacobian X|Y|Z (Montgomery).  points: stride ffi_affine_sz, flagged
     // format iff ffi_affine_sz > 2*FP_BYTES.  scalars: SCALAR_BYTES each.
     void invoke(point_t& out, const void* points, size_t npoints, const void* scalars,
@@ -277,175 +570,73 @@ public:
             if (npoints > pre_n) HIP_OK(hipErrorInvalidValue);
             points = pre_points; ffi_affine_sz = pre_stride;
         }
-        if (scalars == nullptr) HIP_OK(hipErrorInvalidValue);
+        if (scalars == nullptr || ffi_affine_sz < 2 * FP_BYTES) HIP_OK(hipErrorInvalidValue);
         join_default_stream();
 
-        const bool flagged = ffi_affine_sz > 2 * FP_BYTES;
         const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);
-        const msm_plan p = make_plan(npoints, FRp::NBITS, tune);
-        const layout l = make_layout(p, pts_dev ? 0 : npoints * ffi_affine_sz,
-                                        sc_dev ? 0 : npoints * SCALAR_BYTES, !preconverted);
-        reserve(l.total);
+        const bool host = !pts_dev || !sc_dev;
+        const size_t chunk = choose_chunk(npoints, (pts_dev ? 0 : ffi_affine_sz) + (sc_dev ? 0 : SCALAR_BYTES));
+        const size_t nchunks = (npoints + chunk - 1) / chunk;
+        const size_t in_stride = preconverted ? conv_stride() : ffi_affine_sz;     // bytes between input records
+        if (nchunks > 4096) HIP_OK(hipErrorOutOfMemory);
 
-        const unsigned char* d_points = (const unsigned char*)points;
-        const u32* d_scalars = (const u32*)scalars;
-        if (!pts_dev) {
-            HIP_OK(hipMemcpyAsync(blob + l.points, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, stream));
-            d_points = blob + l.points;
-        }
-        if (!sc_dev) {
-            HIP_OK(hipMemcpyAsync(blob + l.scalars, scalars, npoints * SCALAR_BYTES, hipMemcpyHostToDevice, stream));
-            d_scalars = (const u32*)(blob + l.scalars);
-        }
+        // one plan for the full chunks and one for the (shorter) last chunk; scratch for the larger
+        const msm_plan p_full = make_plan(chunk, FRp::NBITS, tune);
+        const msm_plan p_last = make_plan(npoints - (nchunks - 1) * chunk, FRp::NBITS, tune);
+        if (p_full.nwins > MAX_WINS || p_last.nwins > MAX_WINS) HIP_OK(hipErrorInvalidValue);
+        const layout l_full = make_layout(p_full, !preconverted), l_last = make_layout(p_last, !preconverted);
+        reserve(std::max(l_full.total, l_last.total));
+        reserve_sums(nchunks * MAX_WINS);
+        const size_t st_pts = align_up(pts_dev ? 0 : chunk * ffi_affine_sz), st_sc = align_up(sc_dev ? 0 : chunk * SCALAR_BYTES);
+        if (host) { reserve_stage(2 * (st_pts + st_sc)); if (nchunks > 1) need_cpy(); }
 
-        u32* digits = (u32*)(blob + l.digits);
-        u32* sorted = (u32*)(blob + l.sorted);
-        u32* H = (u32*)(blob + l.H);
-        u32* tot = (u32*)(blob + l.tot);
-        u32* off = (u32*)(blob + l.off);
-        bucket_t* buckets = (bucket_t*)(blob + l.buckets);
-
-        if (timing) HIP_OK(hipEventRecord(ev[0], stream));
-
-        // ---- digits + counting sort -------------------------------------
-        {
-            unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
-            hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, stream,
-                               digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont);
-            HIP_OK(hipGetLastError());
-        }
-        {
-            uint2* partA = (uint2*)(blob + l.partA);
-            u32* offA = (u32*)(blob + l.offA);
-            size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + 4096;
-            if (ldsA > 65536) {
-                HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
-                HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+        for (size_t c = 0; c < nchunks; c++) {
+            const size_t lo = c * chunk, cn = std::min(chunk, npoints - lo);
+            const msm_plan& p = c + 1 == nchunks ? p_last : p_full;
+            const layout& l = c + 1 == nchunks ? l_last : l_full;
+            const unsigned sb = c & 1;
+            const unsigned char* d_points = (const unsigned char*)points + lo * in_stride;
+            const u32* d_scalars = (const u32*)((const unsigned char*)scalars + lo * SCALAR_BYTES);
+            if (host) {
+                // copies of chunk c: scalars first (the sort only needs them).  With more than one chunk they run
+                // on the copy stream, under the arithmetic of chunk c-1; pageable source memory makes the call
+                // itself block until the data has left the host buffer, which is fine: chunk c-1's kernels are
+                // already queued.
+                hipStream_t cs = nchunks > 1 ? cpy : stream;
+                unsigned char* sp = stage + sb * (st_pts + st_sc);
+                if (nchunks > 1 && c >= 2) HIP_OK(hipStreamWaitEvent(cpy, ev_chunkdone[sb], 0));    // chunk c-2 is done with this set
+                if (!sc_dev) {
+                    HIP_OK(hipMemcpyAsync(sp + st_pts, d_scalars, cn * SCALAR_BYTES, hipMemcpyHostToDevice, cs));
+                    d_scalars = (const u32*)(sp + st_pts);
+                }
+                if (!pts_dev) {
+                    HIP_OK(hipMemcpyAsync(sp, d_points, cn * ffi_affine_sz, hipMemcpyHostToDevice, cs));
+                    d_points = sp;
+                }
+                if (nchunks > 1) {
+                    HIP_OK(hipEventRecord(ev_copied[sb], cpy));
+                    HIP_OK(hipStreamWaitEvent(stream, ev_copied[sb], 0));
+                }
             }
-            if (ldsB > 65536)
-                HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
-            hipLaunchKernelGGL(k_histA, dim3(p.nslabs, p.nwins), dim3(1024), ldsA, stream,
-                               H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
-            HIP_OK(hipGetLastError());
-            size_t na_total = (size_t)p.nwins * p.NA;
-            hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((na_total + 255) / 256)), dim3(256), 0, stream,
-                               H, tot, p.nslabs, p.NA, p.nwins);
-            HIP_OK(hipGetLastError());
-            hipLaunchKernelGGL(k_scan_parts, dim3(p.nwins), dim3(1024), 0, stream, offA, tot, p.NA);
-            HIP_OK(hipGetLastError());
-            hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, p.nwins), dim3(1024), ldsA, stream,
-                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
-            HIP_OK(hipGetLastError());
-            const unsigned big = tune.big ? tune.big : (1u << 18);
-            u32* nbig = (u32*)(blob + l.bigl); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB);
-            HIP_OK(hipMemsetAsync(nbig, 0, 4, stream));
-            hipLaunchKernelGGL(k_sortB, dim3(p.NA, p.nwins), dim3(1024), ldsB, stream,
-                               sorted, off, partA, offA, p.n, p.NA, p.LB, big);
-            HIP_OK(hipGetLastError());
-            // oversized partitions (skewed scalars); empty list and immediate return otherwise
-            hipLaunchKernelGGL(k_big_find, dim3((p.NA * p.nwins + 255) / 256), dim3(256), 0, stream,
-                               nbig, blist, off, offA, p.NA, p.LB, p.nwins, big);
-            size_t ldsBig = ((size_t)1 << p.LB) * 4;
-            hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, stream, off, partA, offA, nbig, blist, p.n, p.NA, p.LB);
-            hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, stream, off, curB, offA, nbig, blist, p.NA, p.LB);
-            hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, stream, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB);
-            HIP_OK(hipGetLastError());
-        }
-        HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
-
-        if constexpr (INTERNAL) if (!preconverted) {   // wire points -> the field's own records (2 products per point)
-            unsigned char* conv = blob + l.conv;
-            unsigned grid = (unsigned)((p.n + 255) / 256);
-            if (flagged) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream,
-                                            conv, d_points, p.n, (unsigned)ffi_affine_sz);
-            else         hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, stream,
-                                            conv, d_points, p.n, (unsigned)ffi_affine_sz);
-            HIP_OK(hipGetLastError());
-            d_points = conv;
-        }
-
-        if (timing) HIP_OK(hipEventRecord(ev[1], stream));
-
-        // ---- bucket accumulation: level 0 + segmented tree ------------------
-        u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
-        u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
-        {
-            dim3 grid((p.chunks_per_win + 255) / 256, p.nwins);
-            if (flagged)
-                hipLaunchKernelGGL((k_accumulate<fp_d, true>), grid, dim3(256), 0, stream,
-                                   buckets, keyA, ptA, d_points, (unsigned)ffi_affine_sz, sorted, off,
-                                   p.n, p.NB, p.L, p.chunks_per_win);
-            else
-                hipLaunchKernelGGL((k_accumulate<fp_d, false>), grid, dim3(256), 0, stream,
-                                   buckets, keyA, ptA, d_points, (unsigned)ffi_affine_sz, sorted, off,
-                                   p.n, p.NB, p.L, p.chunks_per_win);
-            HIP_OK(hipGetLastError());
-        }
-        if (timing) HIP_OK(hipEventRecord(ev[2], stream));
-        {
-            size_t nrec = (size_t)2 * p.nwins * p.chunks_per_win;
-            u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
-            for (;;) {
-                unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
-                int last = nthreads == 1;
-                hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
-                                   buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last);
-                HIP_OK(hipGetLastError());
-                if (last) break;
-                nrec = (size_t)2 * nthreads;
-                std::swap(ik, ok); std::swap(ip, op);
-            }
-        }
-
-        // ---- per-window weighted bucket sums --------------------------------
-        bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
-        bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
-        bucket_t* result;
-        {
-            unsigned nitems = p.NB / p.K;
-            size_t nthr = (size_t)p.nwins * nitems;
-            hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                               A1, W1, buckets, p.NB, p.K, p.nwins);
-            HIP_OK(hipGetLastError());
-            unsigned lgG = lg2_floor(p.K);
-            bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
-            while (nitems > 1) {
-                unsigned K = std::min(p.K, nitems);
-                nthr = (size_t)p.nwins * (nitems / K);
-                hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                                   oa, ow, ia, iw, nitems, K, lgG, p.nwins);
-                HIP_OK(hipGetLastError());
-                nitems /= K; lgG += lg2_floor(K);
-                std::swap(ia, oa); std::swap(iw, ow);
-            }
-            result = iw;
-        }
-        if (timing) HIP_OK(hipEventRecord(ev[3], stream));
-
-        // ---- device -> host: one XYZZ per window; Horner on the host --------
-        std::vector<std_bucket_t> sums(p.nwins);
-        if constexpr (INTERNAL) {           // window sums back to the reference's wire image
-            std_bucket_t* fin = (std_bucket_t*)(blob + l.fin);
-            hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((p.nwins + 63) / 64), dim3(64), 0, stream, fin, result, p.nwins);
-            HIP_OK(hipGetLastError());
-            HIP_OK(hipMemcpyAsync(sums.data(), fin, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
-        } else {
-            HIP_OK(hipMemcpyAsync(sums.data(), result, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+            enqueue(p, l, d_points, in_stride, preconverted, d_scalars, mont, h_sums + c * MAX_WINS, c == 0);
+            if (host && nchunks > 1) HIP_OK(hipEventRecord(ev_chunkdone[sb], stream));
         }
         HIP_OK(hipStreamSynchronize(stream));
+        last_chunks = (unsigned)nchunks;
 
         if (timing) {
-            HIP_OK(hipEventElapsedTime(&last_ms[0], ev[0], ev[1]));
-            HIP_OK(hipEventElapsedTime(&last_ms[1], ev[1], ev[2]));
-            HIP_OK(hipEventElapsedTime(&last_ms[2], ev[0], ev[3]));
+            const msm_plan& p = nchunks == 1 ? p_last : p_full;
+            float acc = 0, t;
+            for (unsigned g = 0; g < p.G; g++) { HIP_OK(hipEventElapsedTime(&t, tev[2 + 2 * g], tev[3 + 2 * g])); acc += t; }
+            HIP_OK(hipEventElapsedTime(&last_ms[0], tev[0], tev[2]));
+            last_ms[1] = acc;
+            HIP_OK(hipEventElapsedTime(&last_ms[2], tev[0], tev[1]));
+            last_ms[3] = (float)p.G;
         }
 
-        for (unsigned w = p.nwins; w--;) {
-            fp_h c[4];
-            memcpy(c, &sums[w], sizeof(c));
-            point_t s = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
-            out.add(s);
-            if (w) for (unsigned k = 0; k < window_len(w - 1, p.nwins, p.nbits); k++) out.dbl();
+        for (size_t c = 0; c < nchunks; c++) {
+            point_t part = horner(h_sums + c * MAX_WINS, c + 1 == nchunks ? p_last : p_full);
+            out.add(part);
         }
     }
 };

@@ -54,12 +54,16 @@ static constexpr u32 KEY_NONE = 0xffffffffu;
 __host__ __device__ inline unsigned window_len(unsigned w, unsigned nwins, unsigned nbits)   // also used by the host Horner
 {   return nbits / nwins + (w < nbits % nwins ? 1u : 0u);   }
 
+// Only the digits of windows [w_begin, w_begin + w_count) are stored (a window group of the
+// pipelined driver), at digits[(w - w_begin) * n + i]; the carry still runs through all
+// lower windows.
 template<class LimbFn>
 SPPARK_DEVFN void recode_digits(u32* digits, size_t n, size_t i, LimbFn limb, bool flip,
-                                unsigned nwins, unsigned nbits)
+                                unsigned nwins, unsigned nbits, unsigned w_begin = 0, unsigned w_count = ~0u)
 {
     u32 carry = 0;
-    for (unsigned w = 0, bit = 0; w < nwins; w++) {
+    const unsigned w_end = w_count > nwins - w_begin ? nwins : w_begin + w_count;
+    for (unsigned w = 0, bit = 0; w < w_end; w++) {
         const unsigned len = window_len(w, nwins, nbits);
         const u32 half = 1u << (len - 1), full = 1u << len, mask = full - 1;
         const unsigned li = bit >> 5, sh = bit & 31;
@@ -69,7 +73,7 @@ SPPARK_DEVFN void recode_digits(u32* digits, size_t n, size_t i, LimbFn limb, bo
         bool minus = d > half;
         carry = minus;
         d = minus ? full - d : d;
-        digits[(size_t)w * n + i] = d ? (d | ((u32)(minus != flip) << 31)) : 0;
+        if (w >= w_begin) digits[(size_t)(w - w_begin) * n + i] = d ? (d | ((u32)(minus != flip) << 31)) : 0;
     }
 }
 
@@ -97,7 +101,7 @@ SPPARK_DEVFN FR load_scalar_abs(const u32* scalars, size_t i, int mont, bool& fl
 template<class FR>
 __global__ __launch_bounds__(256)
 void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
-                 unsigned n, unsigned nwins, unsigned nbits, int mont)
+                 unsigned n, unsigned nwins, unsigned nbits, int mont, unsigned w_begin, unsigned w_count)
 {
     constexpr int N = FR::N;
     __shared__ u32 limbs[N + 2][256];                   // transposed: dynamic limb index without scratch
@@ -108,7 +112,7 @@ void k_breakdown(u32* __restrict__ digits, const u32* __restrict__ scalars,
         #pragma unroll
         for (int k = 0; k < N; k++) limbs[k][tid] = s.v[k];
         limbs[N][tid] = 0; limbs[N + 1][tid] = 0;
-        recode_digits(digits, n, i, [&](unsigned k) { return limbs[k][tid]; }, flip, nwins, nbits);
+        recode_digits(digits, n, i, [&](unsigned k) { return limbs[k][tid]; }, flip, nwins, nbits, w_begin, w_count);
     }
 }
 

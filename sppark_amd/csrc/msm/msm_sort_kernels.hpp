@@ -20,8 +20,17 @@
 
 namespace sppark_amd {
 
+// Work-group size of the three bulk kernels (k_histA, k_scatterA, k_sortB).  512 lanes = 2 waves
+// per SIMD at <= 24 VGPRs each: such a work-group fits NEXT TO the two 232-VGPR waves per SIMD
+// of k_accumulate (2*232 + 2*24 = 512 registers per lane), so the sort of window group g+1
+// runs on the same CUs, at the same time, as the accumulation of group g (msm_driver.hpp): the
+// one is bound by scattered memory transactions, the other by the integer multiplier.
+static constexpr unsigned SORT_NT = 512;
+#define SORT_VGPRS 24
+static constexpr int SORTB_UNROLL = 4;       // loads in flight per lane in k_sortB
+
 // H[(w*nslabs + slab)*NA + k_hi] = count of the slab's window-w digits in partition k_hi
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
 void k_histA(u32* __restrict__ H, const u32* __restrict__ digits, unsigned n,
              unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
 {
@@ -87,7 +96,7 @@ void k_scan_parts(u32* __restrict__ offA, const u32* __restrict__ tot, unsigned 
 }
 
 // level-A scatter: partA[w*n + pos] = { point index | sign<<31, k_lo }
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
 void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
                 const u32* __restrict__ H, const u32* __restrict__ offA,
                 unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
@@ -121,11 +130,12 @@ void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
 // level B: block (k_hi, w) groups its partition by k_lo.
 //   off[w*(NB+1) + k_hi*2^LB + j] = first position of bucket (k_hi, j) in window w's list
 //   sorted[w*n + pos] = point index | sign<<31
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
 void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __restrict__ partA,
              const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LB, unsigned big)
 {
-    extern __shared__ u32 lds[];            // 2^LB counters, then 1024 scan words
+    extern __shared__ u32 lds[];            // 2^LB counters, then SORT_NT scan words
+    constexpr unsigned NT = SORT_NT;
     const unsigned NL = 1u << LB;
     u32* cnt = lds;
     u32* part = lds + NL;
@@ -138,25 +148,26 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
         return;
     }
 
-    for (unsigned b = tid; b < NL; b += 1024) cnt[b] = 0;
+    for (unsigned b = tid; b < NL; b += NT) cnt[b] = 0;
     __syncthreads();
-    for (unsigned i = begin + tid; i < end; i += 4096) {
-        u32 k[4];
+    for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
+        u32 k[SORTB_UNROLL];
         #pragma unroll
-        for (int u = 0; u < 4; u++) { unsigned j = i + u * 1024; k[u] = j < end ? src[j].y : 0xffffffffu; }
+        for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; k[u] = j < end ? src[j].y : 0xffffffffu; }
         #pragma unroll
-        for (int u = 0; u < 4; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
+        for (int u = 0; u < SORTB_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
     }
     __syncthreads();
 
     // exclusive scan of cnt[0..NL) in place, offsets relative to |begin|
-    const unsigned per = (NL + 1023) / 1024;
+    const unsigned per = (NL + NT - 1) / NT;
     const unsigned lo = min(NL, tid * per), hi = min(NL, lo + per);
     u32 sum = 0;
+    #pragma unroll 1                        // (a handful of counters per lane: unrolling only costs registers)
     for (unsigned b = lo; b < hi; b++) sum += cnt[b];
     part[tid] = sum;
     __syncthreads();
-    for (unsigned d = 1; d < 1024; d <<= 1) {
+    for (unsigned d = 1; d < NT; d <<= 1) {
         u32 v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
         part[tid] += v;
@@ -165,17 +176,18 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     u32 run = begin + part[tid] - sum;
     const size_t NB = (size_t)NA << LB;
     u32* o = off + (size_t)w * (NB + 1) + ((size_t)khi << LB);
+    #pragma unroll 1
     for (unsigned b = lo; b < hi; b++) { u32 c = cnt[b]; cnt[b] = run; o[b] = run; run += c; }
     if (khi == NA - 1 && tid == 0) off[(size_t)w * (NB + 1) + NB] = end;
     __syncthreads();
 
     u32* dst = sorted + (size_t)w * n;
-    for (unsigned i = begin + tid; i < end; i += 4096) {
-        uint2 r[4];
+    for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
+        uint2 r[SORTB_UNROLL];
         #pragma unroll
-        for (int u = 0; u < 4; u++) { unsigned j = i + u * 1024; r[u] = j < end ? src[j] : make_uint2(0, 0xffffffffu); }
+        for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; r[u] = j < end ? src[j] : make_uint2(0, 0xffffffffu); }
         #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SORTB_UNROLL; u++) {
             if (r[u].y != 0xffffffffu) {
                 u32 pos = atomicAdd(&cnt[r[u].y], 1u);
                 dst[pos] = r[u].x;

@@ -78,11 +78,11 @@ static inline const gpu_info& select_gpu(int id)
 {
     auto& gpus = gpus_t::all();
     if (gpus.empty()) HIP_OK(hipErrorNoDevice);
-    if (id == -1) {
-        int cur;
+    if (id == -1) {                     // the calling thread's current device; never switched silently:
+        int cur;                        // the caller's device pointers live there
         HIP_OK(hipGetDevice(&cur));
         for (auto& g : gpus) if (g.hip_id == cur) return g;
-        id = 0;
+        HIP_OK(hipErrorInvalidDevice);  // current device is not in the filtered list
     }
     if (id < 0 || (size_t)id >= gpus.size()) HIP_OK(hipErrorInvalidDevice);
     HIP_OK(hipSetDevice(gpus[id].hip_id));

@@ -82,6 +82,19 @@ def load(name):
         L.sppark_msm_tune_split.restype = _Error
         L.sppark_msm_tune_sort.argtypes = [vp, cu]
         L.sppark_msm_tune_sort.restype = _Error
+        L.sppark_msm_tune_pipeline.argtypes = [vp, cu, sz, sz]
+        L.sppark_msm_tune_pipeline.restype = _Error
+        L.sppark_msm_last_chunks.argtypes = [vp]
+        L.sppark_msm_last_chunks.restype = cu
+        L.sppark_msm_plan_groups.argtypes = [vp, sz]
+        L.sppark_msm_plan_groups.restype = cu
+        L.sppark_ngpus.argtypes = []
+        L.sppark_ngpus.restype = sz
+        L.sppark_msm_multi.argtypes = [vp, vp, sz, vp, ci, sz, cu]
+        L.sppark_msm_multi.restype = _Error
+        L.sppark_msm_multi_shards.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ci, sz, cu,
+                                              ctypes.POINTER(ci)]
+        L.sppark_msm_multi_shards.restype = _Error
         L.sppark_msm_reserve.argtypes = [vp, sz, sz, ci, ci]
         L.sppark_msm_reserve.restype = _Error
         L.sppark_msm_invoke.argtypes = [vp, vp, vp, sz, vp, ci, sz]
@@ -101,16 +114,6 @@ def load(name):
         L.sppark_g1_to_affine.argtypes = [vp, vp]
         L.sppark_g1_generate.argtypes = [vp, sz, sz, ctypes.c_uint64]
         L.sppark_g1_generate.restype = _Error
-        L.sppark_devtest_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
-        L.sppark_devtest_field_op.restype = _Error
-        L.sppark_devtest_bucket_field_op.argtypes = [ci, vp, vp, vp, sz]
-        L.sppark_devtest_bucket_field_op.restype = _Error
-        L.sppark_devtest_bucket_field_limbs.argtypes = []
-        L.sppark_devtest_bucket_field_limbs.restype = ci
-        L.sppark_devtest_bucket_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
-        L.sppark_devtest_bucket_xyzz_op.restype = _Error
-        L.sppark_devtest_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
-        L.sppark_devtest_xyzz_op.restype = _Error
     if name in NTT_FIELDS or name in CURVES:
         L.compute_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci]
         L.compute_ntt.restype = _Error
@@ -123,9 +126,41 @@ def load(name):
         L.sppark_lde_powers.restype = _Error
         L.sppark_lde_expand.argtypes = [sz, vp, vp, u32, u32, vp]
         L.sppark_lde_expand.restype = _Error
+    _LIBS[name] = L
+    return L
+
+
+def load_devtest(name):
+    """dlopen libsppark_<name>_devtest.so: the device test hooks (sppark_devtest_*), a TEST-only
+    library built next to the product ones by sppark_amd.build."""
+    key = name + "_devtest"
+    if key in _LIBS:
+        return _LIBS[key]
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = lib_path(key)
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s is missing: python -m sppark_amd.build" % path)
+    L = ctypes.CDLL(path)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.drop_error_message.argtypes = [vp]
+    if name in CURVES:
+        L.sppark_devtest_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
+        L.sppark_devtest_field_op.restype = _Error
+        L.sppark_devtest_bucket_field_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_bucket_field_op.restype = _Error
+        L.sppark_devtest_bucket_field_limbs.argtypes = []
+        L.sppark_devtest_bucket_field_limbs.restype = ci
+        L.sppark_devtest_bucket_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_bucket_xyzz_op.restype = _Error
+        L.sppark_devtest_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
+        L.sppark_devtest_xyzz_op.restype = _Error
+    else:
         L.sppark_devtest_small_field_op.argtypes = [ci, vp, vp, vp, sz]
         L.sppark_devtest_small_field_op.restype = _Error
-    _LIBS[name] = L
+    _LIBS[key] = L
     return L
 
 

@@ -92,6 +92,17 @@ class MsmContext:
     def tune_split(self, big_partition=0):
         ffi.check(self.L, self.L.sppark_msm_tune_split(self.h, big_partition))
 
+    def tune_pipeline(self, groups=0, chunk_points=0, max_scratch_bytes=0):
+        """window groups (sort of group g+1 under the accumulation of group g), points per chunk
+        of the chunked path, upper bound of the scratch memory; 0 = automatic"""
+        ffi.check(self.L, self.L.sppark_msm_tune_pipeline(self.h, groups, chunk_points, max_scratch_bytes))
+
+    def last_chunks(self):
+        return int(self.L.sppark_msm_last_chunks(self.h))
+
+    def plan_groups(self, npoints):
+        return int(self.L.sppark_msm_plan_groups(self.h, npoints))
+
     def reserve(self, npoints, ffi_affine_sz, host_points=False, host_scalars=False):
         ffi.check(self.L, self.L.sppark_msm_reserve(self.h, npoints, ffi_affine_sz,
                                                     int(host_points), int(host_scalars)))
@@ -138,6 +149,49 @@ class MsmContext:
         out = np.zeros(3 * self.fb, dtype=np.uint8)
         ffi.check(self.L, self.L.sppark_msm_invoke(self.h, out.ctypes.data, pp, n, sp, int(mont), stride))
         return out
+
+
+def ngpus(curve="bls12_381"):
+    """usable devices (ngpus(), util/all_gpus.cpp:62-63)"""
+    return int(ffi.load(curve).sppark_ngpus())
+
+
+def msm_multi(points, scalars, curve="bls12_381", ndev=0, mont=False, ffi_affine_sz=None):
+    """sppark_msm_multi: one process, one host thread + context per device, contiguous shards of
+    HOST-resident inputs, partial sums added on the host.  Returns the Jacobian result."""
+    L = ffi.load(curve)
+    fb = FP_BYTES[curve]
+    stride = ffi_affine_sz or 2 * fb
+    n = _npoints(points, stride)
+    if _nbytes(scalars) != 32 * n:
+        raise ValueError("length mismatch")
+    pp, _k1 = ffi.as_pointer(points)
+    sp, _k2 = ffi.as_pointer(scalars)
+    out = np.zeros(3 * fb, dtype=np.uint8)
+    ffi.check(L, L.sppark_msm_multi(out.ctypes.data, pp, n, sp, int(mont), stride, ndev))
+    return out
+
+
+def msm_multi_shards(shards, curve="bls12_381", device_ids=None, mont=False, ffi_affine_sz=None):
+    """sppark_msm_multi_shards: |shards| = [(points, scalars), ...], shard i on device
+    device_ids[i] (default: device i); buffers may be host arrays or tensors on that device."""
+    L = ffi.load(curve)
+    fb = FP_BYTES[curve]
+    stride = ffi_affine_sz or 2 * fb
+    k = len(shards)
+    P = (ctypes.c_void_p * k)(); S = (ctypes.c_void_p * k)(); N = (ctypes.c_size_t * k)()
+    keep = []
+    for i, (pts, sc) in enumerate(shards):
+        n = _npoints(pts, stride) if _nbytes(pts) else 0
+        if _nbytes(sc) != 32 * n:
+            raise ValueError("length mismatch in shard %d" % i)
+        pp, k1 = ffi.as_pointer(pts); sp, k2 = ffi.as_pointer(sc)
+        keep += [k1, k2]
+        P[i] = pp; S[i] = sp; N[i] = n
+    ids = (ctypes.c_int * k)(*device_ids) if device_ids is not None else None
+    out = np.zeros(3 * fb, dtype=np.uint8)
+    ffi.check(L, L.sppark_msm_multi_shards(out.ctypes.data, P, N, S, int(mont), stride, k, ids))
+    return out
 
 
 def multi_scalar_mult_fp2_arkworks(points, scalars, curve="bls12_381", ffi_affine_sz=None):

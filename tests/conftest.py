@@ -21,13 +21,14 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def libs():
-    """Paths of the HIP C-ABI libraries; built here when missing (hipcc cross-compiles)."""
+    """Paths of the HIP C-ABI libraries.  Always goes through sppark_amd.build: a no-op when the
+    source-hash stamp of every library matches csrc/, a rebuild otherwise (hipcc cross-compiles
+    here; on the GPU box the libraries arrive prebuilt with matching stamps), so the tests never
+    run against binaries that were not built from the tree they sit in."""
     from sppark_amd import build as B
     from sppark_amd import ffi
-    missing = [n for n in ("bls12_381", "bn254", "gl64", "bb31") if not os.path.exists(ffi.lib_path(n))]
-    if missing:
-        B.build(only=missing, verbose=False)
-    return {n: ffi.lib_path(n) for n in ("bls12_381", "bn254", "gl64", "bb31")}
+    B.build(verbose=False)
+    return {n: ffi.lib_path(n) for n in B.PRODUCT}
 
 
 def have_gpu():

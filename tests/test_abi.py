@@ -24,7 +24,7 @@ def test_header_symbols_exported(libs):
     assert "mult_pippenger_inf" in syms and "compute_ntt" in syms and "cuda_available" in syms
     common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message", "cuda_func",
               "sppark_gpu_ptr_alloc", "sppark_gpu_ptr_get"}
-    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1") or s.startswith("sppark_g2")}
+    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1") or s.startswith("sppark_g2")} | {"sppark_ngpus"}
     ntt_only = {"compute_ntt", "sppark_ntt", "sppark_lde", "sppark_lde_powers", "sppark_lde_expand"}
     assert set(syms) == common | msm_only | ntt_only
     for name, path in libs.items():
@@ -32,6 +32,9 @@ def test_header_symbols_exported(libs):
         want = common | ntt_only | (msm_only if name in ("bls12_381", "bn254") else set())   # curve libs: NTT over Fr too
         for s in want:
             assert hasattr(L, s), (name, s)
+        # the device test hooks live in separate test libraries (libsppark_*_devtest.so)
+        for s in ("sppark_devtest_field_op", "sppark_devtest_small_field_op", "sppark_devtest_xyzz_op"):
+            assert not hasattr(L, s), (name, s)
 
 
 def test_symbols_resolve_like_go_dlsym(libs):

@@ -24,7 +24,7 @@ def test_device_field_ops(oracle, libs, curve, name):
     """k_field_op on the GPU vs the oracle, element by element."""
     from sppark_amd import ffi
     O = oracle
-    L = ffi.load(name)
+    L = ffi.load_devtest(name)
     rng = np.random.default_rng(curve + 10)
     for which, p, nb, ofield in ((0, O.FP_MODULUS[curve], O.FP_BYTES[curve], O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP),
                                  (1, O.FR_MODULUS[curve], 32, O.FIELD_BLS_FR if curve == 0 else O.FIELD_BN_FR)):
@@ -48,7 +48,7 @@ def test_device_point_ops(oracle, libs, curve, name):
     including equal, opposite and infinite operands."""
     from sppark_amd import ffi
     O = oracle
-    L = ffi.load(name)
+    L = ffi.load_devtest(name)
     fb = O.FP_BYTES[curve]
     n = 64
     A = O.g1_gen_points(curve, n, 1); B = O.g1_gen_points(curve, n, 2)
@@ -102,7 +102,7 @@ def test_bucket_field_ops(libs):
     zero test on loosely reduced values, and both conversions from/to the wire form."""
     import random
     from sppark_amd import ffi
-    L = ffi.load("bls12_381")
+    L = ffi.load_devtest("bls12_381")
     NL = L.sppark_devtest_bucket_field_limbs()
     assert NL == 14
     Pm = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
@@ -166,7 +166,7 @@ def test_bucket_point_ops_bit_exact_with_wire_class(oracle, libs):
     same field elements), including equal, opposite and infinite operands."""
     from sppark_amd import ffi
     O = oracle
-    L = ffi.load("bls12_381")
+    L = ffi.load_devtest("bls12_381")
     curve, fb, n = 0, 48, 96
     A = O.g1_gen_points(curve, n, 11); B = O.g1_gen_points(curve, n, 12)
     B[0] = A[0]
@@ -603,34 +603,162 @@ def test_msm_oversized_sort_partitions(oracle, libs):
     ctx.close()
 
 
-def test_msm_full_size_periodic(oracle, libs):
-    """BASELINE size (2^26 points, BLS12-381 G1), checked through a size-independent property:
-    with 2048 distinct points and scalars repeated with the same period,
-    MSM_n(P, s) = MSM_2048(P, (n/2048) * s mod r), and the small one is checked against the oracle.
-    Also one run with uniformly random scalars split in two halves: whole == half + half."""
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
+    """BASELINE size (2^26 points; configs[2] BLS12-381 G1 and configs[4] alt_bn128 G1) against the
+    ORACLE through the period of the inputs: with 2048 distinct points replicated cyclically (the
+    shape of poc/msm-cuda/src/util.rs:11-38) MSM_n(P, s) = MSM_2048(B, fold(s)) where fold(s)_j is
+    the sum of the scalars of class j mod r (oracle/fold.py).  Checked for
+      (i)  periodic scalars with the recipe's edge rows (0, r-1, (r+-1)/2, duplicates, P and -P),
+      (ii) INDEPENDENT UNIFORM scalars on [0, r) -- the bench's headline workload --
+    and (iii) whole == half + half on the uniform run."""
     import torch
     import sppark_amd
+    from sppark_amd import synth
+    from oracle import fold
     O = oracle
     lg, per = 26, 2048
     n = 1 << lg
-    base, sc = recipe.msm_inputs(O.BLS12_381, per, 2626, ndistinct=per, edge=True)
+    r = O.FR_MODULUS[curve]
+    base, sc = recipe.msm_inputs(curve, per, 2626, ndistinct=per, edge=True)
     d_base = torch.from_numpy(base).cuda(); d_sc = torch.from_numpy(sc).cuda()
     idx = torch.arange(n, device="cuda") % per
     pts = d_base[idx].contiguous(); scal = d_sc[idx].contiguous()
     # device-resident inputs produced by torch kernels: run on torch's stream so that the MSM is
     # ordered after them
-    ctx = sppark_amd.MsmContext("bls12_381", stream=torch.cuda.current_stream().cuda_stream)
-    got = sppark_amd.to_affine(ctx.invoke(pts, scal))
-    r = O.FR_MODULUS[O.BLS12_381]
-    mult = np.zeros_like(sc)
-    for i in range(per):
-        v = int.from_bytes(sc[i].tobytes(), "little") * (n // per) % r
-        mult[i] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
-    assert (got == O.msm_affine(O.BLS12_381, base, mult, algo=0, param=8)).all()
-    g = torch.Generator(device="cuda"); g.manual_seed(3)
-    rnd = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g); rnd[:, 31] &= 0x3f
+    ctx = sppark_amd.MsmContext(name, stream=torch.cuda.current_stream().cuda_stream)
+    got = sppark_amd.to_affine(ctx.invoke(pts, scal), name)
+    assert (got == O.msm_affine(curve, base, fold.fold_scalars(scal, per, r), algo=0, param=8)).all()
+    del scal
+    rnd = synth.uniform_scalars(n, name, seed=3)
     whole = ctx.invoke(pts, rnd)
+    assert (sppark_amd.to_affine(whole, name) == O.msm_affine(curve, base, fold.fold_scalars(rnd, per, r), algo=0, param=8)).all()
     h = n // 2
     parts = np.stack([ctx.invoke(pts[:h], rnd[:h]), ctx.invoke(pts[h:], rnd[h:])])
-    assert (sppark_amd.to_affine(sppark_amd.jacobian_sum(parts)) == sppark_amd.to_affine(whole)).all()
+    assert (sppark_amd.to_affine(sppark_amd.jacobian_sum(parts, name), name) == sppark_amd.to_affine(whole, name)).all()
     ctx.close()
+
+
+# ------------------------------------------------- pipeline shape: window groups, chunks, devices
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_msm_window_groups_and_chunks(oracle, libs, curve, name):
+    """The two-stream window-group pipeline and the chunked path, forced through every shape on
+    sizes the oracle finishes quickly: groups 1..all windows (uneven last group included), chunks
+    that do not divide n, host and device inputs, flagged and plain points, preloaded bases, and a
+    scratch bound that forces the bounded-memory path."""
+    import torch
+    import sppark_amd
+    O = oracle
+    n = 20000
+    pts, sc = recipe.msm_inputs(curve, n, 777, ndistinct=500, flagged=True)
+    exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
+    plain = np.ascontiguousarray(pts[:, :-8])                   # Affine_t: infinity = all-zero coordinates
+    plain[(pts[:, -8] != 0)] = 0
+    d_pts = torch.from_numpy(pts).cuda(); d_sc = torch.from_numpy(sc).cuda(); d_plain = torch.from_numpy(plain).cuda()
+    ctx = sppark_amd.MsmContext(name)
+    for wb in (0, 9, 13):
+        ctx.tune(wbits=wb)
+        nw = ctx.plan(n)["windows"]
+        for groups in sorted({1, 2, 3, 5, nw}):
+            for chunk in (0, 7001, 4096):
+                ctx.tune_pipeline(groups=groups, chunk_points=chunk)
+                for p_, s_, st in ((pts, sc, pts.shape[1]), (d_pts, d_sc, pts.shape[1]), (d_plain, sc, plain.shape[1]), (plain, d_sc, plain.shape[1])):
+                    out = ctx.invoke(p_, s_, ffi_affine_sz=st)
+                    assert (sppark_amd.to_affine(out, name) == exp).all(), (name, wb, groups, chunk, st)
+                    assert ctx.last_chunks() == (1 if chunk == 0 else -(-n // chunk))
+    # preloaded bases through the chunked path
+    ctx.tune(wbits=0); ctx.tune_pipeline(groups=3, chunk_points=6000)
+    ctx.set_points(plain, ffi_affine_sz=plain.shape[1])
+    assert (sppark_amd.to_affine(ctx.invoke(None, sc), name) == exp).all()
+    assert (sppark_amd.to_affine(ctx.invoke(None, d_sc[:5000], npoints=5000), name) == O.msm_affine(curve, pts[:5000], sc[:5000], algo=0, param=8)).all()
+    ctx.set_points(None)
+    # bounded scratch: the chunk is halved until the scratch fits
+    ctx.tune_pipeline(groups=0, chunk_points=0, max_scratch_bytes=0)
+    ctx.invoke(d_pts, d_sc, ffi_affine_sz=pts.shape[1])
+    full = ctx.scratch_bytes()
+    ctx2 = sppark_amd.MsmContext(name)
+    ctx2.tune_pipeline(max_scratch_bytes=full // 3)
+    out = ctx2.invoke(d_pts, d_sc, ffi_affine_sz=pts.shape[1])
+    assert (sppark_amd.to_affine(out, name) == exp).all()
+    assert ctx2.last_chunks() > 1 and ctx2.scratch_bytes() <= full // 3
+    ctx.close(); ctx2.close()
+
+
+def test_msm_pipeline_medium_size(oracle, libs):
+    """2^22 points (automatic plan: 4 window groups on two streams; host inputs: 8 chunks) against
+    the oracle through the period fold, device- and host-resident, repeated back to back so that a
+    missing event between the streams would show."""
+    import torch
+    import sppark_amd
+    from sppark_amd import synth
+    from oracle import fold
+    O = oracle
+    n, per = 1 << 22, 512
+    base, _ = recipe.msm_inputs(O.BLS12_381, per, 99, ndistinct=per, edge=True)
+    d_base = torch.from_numpy(base).cuda()
+    pts = d_base[torch.arange(n, device="cuda") % per].contiguous()
+    ctx = sppark_amd.MsmContext("bls12_381", stream=torch.cuda.current_stream().cuda_stream)
+    assert ctx.plan_groups(n) == 4
+    for it in range(3):
+        sc = synth.uniform_scalars(n, "bls12_381", seed=10 + it)
+        exp = O.msm_affine(O.BLS12_381, base, fold.fold_scalars(sc, per, O.FR_MODULUS[O.BLS12_381]), algo=0, param=8)
+        assert (sppark_amd.to_affine(ctx.invoke(pts, sc)) == exp).all(), it
+        if it == 0:
+            h_pts, h_sc = pts.cpu().numpy(), sc.cpu().numpy()
+            assert (sppark_amd.to_affine(ctx.invoke(h_pts, h_sc)) == exp).all()
+            assert ctx.last_chunks() == 4                        # 2^22 host points: 2^20 per chunk
+            assert (sppark_amd.to_affine(sppark_amd.multi_scalar_mult(h_pts, h_sc)) == exp).all()
+    ctx.close()
+
+
+def test_msm_multi_device_entry_points(oracle, libs):
+    """sppark_msm_multi / sppark_msm_multi_shards: one host thread and one pooled context per shard.
+    On a single-GPU box the shards share device 0 (a device may be named more than once), which
+    still exercises the threads, the context pool and the host combine; uneven and empty shards and
+    a shard whose partial sum is infinity included."""
+    import torch
+    import sppark_amd
+    O = oracle
+    nd = sppark_amd.ngpus()
+    assert nd >= 1
+    n = 9001
+    pts, sc = recipe.msm_inputs(O.BLS12_381, n, 31337, ndistinct=200)
+    exp = O.msm_affine(O.BLS12_381, pts, sc, algo=0, param=8)
+    for ndev in sorted({0, 1, nd}):
+        assert (sppark_amd.to_affine(sppark_amd.msm_multi(pts, sc, ndev=ndev)) == exp).all()
+    with pytest.raises(sppark_amd.SpparkError):
+        sppark_amd.msm_multi(pts, sc, ndev=nd + 1)
+    cuts = [0, 1000, 1000, 4567, n]                              # an empty shard in the middle
+    zsc = sc.copy(); zsc[1000:4567] = 0                          # ... and one that sums to infinity
+    for s_, e_ in ((sc, exp), (zsc, O.msm_affine(O.BLS12_381, pts, zsc, algo=0, param=8))):
+        shards = [(pts[a:b], s_[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        ids = [i % nd for i in range(len(shards))]
+        assert (sppark_amd.to_affine(sppark_amd.msm_multi_shards(shards, device_ids=ids)) == e_).all()
+        dev = [(torch.from_numpy(p).to("cuda:%d" % i), torch.from_numpy(s).to("cuda:%d" % i)) for (p, s), i in zip(shards, ids)]
+        torch.cuda.synchronize()
+        assert (sppark_amd.to_affine(sppark_amd.msm_multi_shards(dev, device_ids=ids)) == e_).all()
+
+
+def test_one_shot_pool_is_not_tied_to_threads(oracle, libs):
+    """The one-shot entry points borrow contexts from a process-wide pool: calls from short-lived
+    threads reuse them (no scratch stranded per dead thread), concurrent calls get distinct ones."""
+    import threading
+    import sppark_amd
+    from sppark_amd import ffi
+    O = oracle
+    L = ffi.load("bls12_381")
+    pts, sc = recipe.msm_inputs(O.BLS12_381, 5000, 4711, flagged=True)
+    exp = O.msm_affine(O.BLS12_381, pts, sc, algo=0, param=8)
+    bad = []
+
+    def work():
+        for _ in range(3):
+            if not (sppark_amd.to_affine(sppark_amd.multi_scalar_mult_arkworks(pts, sc)) == exp).all():
+                bad.append(1)
+    for rounds in range(3):                                     # generations of threads that exit
+        ts = [threading.Thread(target=work) for _ in range(4)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+    assert not bad
+    L.sppark_msm_release_cached()
+    assert (sppark_amd.to_affine(sppark_amd.multi_scalar_mult_arkworks(pts, sc)) == exp).all()

@@ -28,7 +28,7 @@ def test_device_small_field_ops(libs):
     from sppark_amd import ffi
     random.seed(3)
     for field, P, dt in (("gl64", 0xffffffff00000001, np.uint64), ("bb31", 0x78000001, np.uint32)):
-        L = ffi.load(field)
+        L = ffi.load_devtest(field)
         M32 = 0xffffffff
         R = 1 if field == "gl64" else pow(1 << 32, P - 2, P)         # bb31 values are Montgomery residues
 
@@ -149,6 +149,57 @@ def test_ntt_linearity_full_size(libs, field):
     else:
         t = ((A.astype(np.uint64) + B) % p).astype(np.uint32)
     assert (t == S).all()
+
+
+def _big_input(field, lg, seed):
+    """vectorised inputs for sizes where recipe.ntt_input's Python loop (256-bit fields) is too slow:
+    four random u64 limbs with the top limb < 2^60, i.e. values < 2^252 < r for both curves"""
+    if field in FIELDS:
+        return recipe.ntt_input(field, lg, seed)
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 1 << 63, size=(1 << lg, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(1 << lg, 4), dtype=np.uint64)
+    x[:, 3] &= np.uint64(0x0fffffffffffffff)
+    return x
+
+
+@pytest.mark.parametrize("field", FIELDS + WIDE)
+def test_ntt_full_size_vs_oracle(oracle, libs, field):
+    """BASELINE configs[1] / [4] at their own size (2^24 Goldilocks / BabyBear), the WHOLE output
+    array against the oracle: forward NR and inverse RN (the timed pair of bench.py), forward NN
+    and the coset forward NN.  256-bit fields: 2^22 forward NR + inverse RN, 2^20 NN."""
+    import sppark_amd
+    O = oracle
+    f = _oracle_fn(O, field)
+    cases = [(24, O.NR, 0, 0), (24, O.RN, 1, 0), (24, O.NN, 0, 0), (24, O.NN, 0, 1)] if field in FIELDS else \
+            [(22, O.NR, 0, 0), (22, O.RN, 1, 0), (20, O.NN, 0, 0)]
+    xs = {}
+    for lg, order, direction, typ in cases:
+        if lg not in xs:
+            xs[lg] = _big_input(field, lg, 240 + lg)
+        y = xs[lg].copy()
+        sppark_amd.compute_ntt(0, y, order, direction, typ, field)
+        e = f(xs[lg], order, direction, typ)
+        assert y.shape == e.shape and (y == e).all(), (field, lg, order, direction, typ)
+
+
+@pytest.mark.parametrize("field", FIELDS + WIDE)
+def test_ntt_reference_test_range_top(oracle, libs, field):
+    """The top of the reference's own test ranges (poc/ntt-cuda/tests/ntt.rs:19,55: lg 1..27 for
+    Goldilocks / BabyBear; :114: lg 1..23 for the 256-bit fields), same assertions as the
+    reference: NN == RR, iNTT(NTT(v)) == v in NN, RR and NR->RN."""
+    import sppark_amd
+    from sppark_amd import NTTInputOutputOrder as Ord
+    for lg in ((25, 26, 27) if field in FIELDS else (21, 22, 23)):
+        v = _big_input(field, lg, 300 + lg)
+        nn = sppark_amd.NTT(0, v.copy(), Ord.NN, field)
+        rr = sppark_amd.NTT(0, v.copy(), Ord.RR, field)
+        assert (nn == rr).all(), lg
+        del rr
+        assert (sppark_amd.iNTT(0, nn, Ord.NN, field) == v).all(), lg
+        nr = sppark_amd.NTT(0, v.copy(), Ord.NR, field)
+        assert (sppark_amd.iNTT(0, nr, Ord.RN, field) == v).all(), lg
+        rr = sppark_amd.NTT(0, v.copy(), Ord.RR, field)
+        assert (sppark_amd.iNTT(0, rr, Ord.RR, field) == v).all(), lg
 
 
 def test_ntt_lg0_noop_and_errors(libs):

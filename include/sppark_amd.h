@@ -139,12 +139,13 @@ SppError sppark_msm_tune_sort(sppark_msm_ctx *ctx, unsigned low_bits);
 /* sort partitions with more entries than this are split over several work-groups (skewed scalars;
  * 0 = automatic, 2^18) */
 SppError sppark_msm_tune_split(sppark_msm_ctx *ctx, unsigned big_partition);
-/* Pipeline shape.  groups: the windows are processed in this many groups, the digits + sort of
- * group g+1 on a second stream under the bucket accumulation of group g (0 = automatic: 4 from
- * 2^21 points, else 1; 1 = single stream).  chunk_points: host-resident inputs, and inputs whose
- * scratch would not fit the device, are processed in chunks of this many points, the copy of
- * chunk c+1 under the arithmetic of chunk c (0 = automatic).  max_scratch_bytes: upper bound of the
- * scratch memory the context may allocate; the chunk is halved until it fits (0 = what is free). */
+/* Pipeline shape.  groups: the windows are sorted and accumulated in this many groups, the digits +
+ * sort of group g+1 on a second stream beside the bucket accumulation of group g (0 / 1 = one group,
+ * the default: on MI355X the overlap gains nothing; more groups shrink the sort
+ * scratch).  chunk_points: host-resident inputs, and inputs whose scratch would not fit the device,
+ * are processed in chunks of this many points, the copy of chunk c+1 under the arithmetic of chunk c
+ * (0 = automatic).  max_scratch_bytes: upper bound of the scratch memory the context may allocate;
+ * the chunk is halved until it fits (0 = what is free). */
 SppError sppark_msm_tune_pipeline(sppark_msm_ctx *ctx, unsigned groups, size_t chunk_points,
                                   size_t max_scratch_bytes);
 /* chunks the last invoke was cut into / window groups the context would use for npoints */

@@ -10,9 +10,9 @@
 // (msm/k_accumulate.hip, k_reduce.hip, k_bucket1.hip, k_bucketN.hip)
 namespace sppark_amd {
 extern template __global__ void k_accumulate<msm_fp_d, false>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
-                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_accumulate<msm_fp_d, true>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
-                                                         const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+                                                         const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                     unsigned, unsigned, unsigned, int);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
@@ -20,9 +20,9 @@ extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, 
                                                       unsigned, unsigned, unsigned, unsigned);
 // ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)
 extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
-                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
-                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
                                                      unsigned, unsigned, unsigned, int);
 extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);

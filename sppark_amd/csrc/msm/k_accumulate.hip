@@ -4,7 +4,7 @@
 #include "msm_kernels.hpp"
 namespace sppark_amd {
 template __global__ void k_accumulate<inst_fp, false>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
-                                                   const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+                                                   const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 template __global__ void k_accumulate<inst_fp, true>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
-                                                  const u32*, const u32*, unsigned, unsigned, unsigned, unsigned);
+                                                  const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 }

@@ -2,15 +2,17 @@
 // msm_t (msm/pippenger.cuh:325-728) -- window choice, device scratch, kernel
 // sequence, error mapping -- re-planned for a 288 GB / 256-CU part:
 //
-//  * WINDOW GROUPS on two streams.  The W windows are cut into G groups; the digits + counting
-//    sort of group g+1 run on an auxiliary stream while the bucket accumulation of group g runs
-//    on the main one.  The sort kernels are bound by scattered memory transactions and are
-//    built to fit beside k_accumulate on the same CU (512-lane work-groups, <= 24 VGPRs, see
-//    msm_sort_kernels.hpp), the accumulation is bound by the integer multiplier and uses no
-//    LDS: apart from the first group's sort the whole sort disappears behind the arithmetic.
-//    Scratch for digits / partitions / sorted lists is two group-sized sets instead of W.
-//    (The reference overlaps its sort with the previous batch's accumulation through a
-//    3-stream flip-flop over POINT batches, pippenger.cuh:494-557.)
+//  * WINDOW GROUPS (a tunable, off by default).  The W windows can be cut into G groups that are
+//    sorted and accumulated one after the other, the digits + counting sort of group g+1 on an
+//    auxiliary stream (optionally confined to a few CUs, hipExtStreamCreateWithCUMask) beside the
+//    bucket accumulation of group g on the main one; the record tree and the bucket sums still run
+//    once, for all windows (their ~15 dependent launches are latency-bound).  Scratch for digits /
+//    partitions / sorted lists is then two group-sized sets instead of W.  It does NOT make an MSM
+//    faster on MI355X: the sort kernels were shrunk to fit beside k_accumulate on a CU (512 lanes,
+//    16 VGPRs) and they do run concurrently, but the accumulation slows down by what the sort
+//    gains -- measured for 1..12 groups, 4..256 CUs for the sort stream and three stream
+//    priorities (profiles/r02_msm_groups.log).  (The reference overlaps its sort with the previous
+//    batch's accumulation through a 3-stream flip-flop over POINT batches, pippenger.cuh:494-557.)
 //  * CHUNKS.  Host-resident inputs (what mult_pippenger_inf's callers pass) are cut into
 //    point chunks: chunk c+1 is copied to the device (scalars first) while chunk c is being
 //    computed; every chunk is a complete MSM and the partial results are added on the host.
@@ -90,9 +92,12 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.F = std::max(4u, t.F ? t.F : 8u);        // fan-in < 3 would never shrink the record list
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
-    // window groups: below ~2^21 points an MSM is a chain of latency-bound launches and a second
-    // stream only adds events; above, four groups leave 1/4 of the sort exposed
-    unsigned G = t.groups ? t.groups : (lg >= 21 ? 4u : 1u);
+    // window groups: ONE by default.  Measured on MI355X (profiles/r02_msm_groups.log): whatever
+    // the sort of the next group gains by running beside k_accumulate, the accumulation loses --
+    // 2^26 points: 168.5 ms with one group, 169-190 ms with 2..12 groups, with the sort stream on
+    // all CUs or confined to 4..64 of them, at any stream priority.  Groups remain useful to bound
+    // the sort scratch (two group-sized sets instead of W) and are a tunable.
+    unsigned G = t.groups ? t.groups : 1u;
     G = std::max(1u, std::min(G, p.nwins));
     p.wpg = (p.nwins + G - 1) / G;
     p.G = (p.nwins + p.wpg - 1) / p.wpg;
@@ -122,6 +127,7 @@ private:
     hipStream_t stream;                 // main stream: the caller's, or a private one
     bool own_stream;
     hipStream_t aux = nullptr;          // sort of the next window group
+    unsigned gseq = 0;                  // running window-group counter: parity selects the buffer set
     hipStream_t cpy = nullptr;          // host -> device copies of the next chunk
     hipEvent_t join_ev = nullptr;
     hipEvent_t ev_fork = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_accdone[2] = {nullptr, nullptr};
@@ -171,12 +177,13 @@ private:
             l.curB[b]   = take(wg * ((size_t)p.NB + 1) * 4);                    // cursors of the cooperative sort
             l.bigl[b]   = take((wg * p.NA + 1) * 4);                            // [count | list of oversized partitions]
         }
-        l.buckets = take(wg * p.NB * sizeof(bucket_t));
-        size_t nrecA = (size_t)2 * wg * p.chunks_per_win;
+        // buckets, records and bucket-sum levels: all windows (one record tree / bucket-sum chain per MSM)
+        l.buckets = take((size_t)p.nwins * p.NB * sizeof(bucket_t));
+        size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win;
         size_t nrecB = 2 * ((nrecA + p.F - 1) / p.F);
         l.keyA = take(nrecA * 4); l.ptA = take(nrecA * sizeof(bucket_t));
         l.keyB = take(nrecB * 4); l.ptB = take(nrecB * sizeof(bucket_t));
-        size_t n1 = wg * (p.NB / p.K);
+        size_t n1 = (size_t)p.nwins * (p.NB / p.K);
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n1 * sizeof(bucket_t)); l.W2 = take(n1 * sizeof(bucket_t));
         l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
@@ -188,7 +195,11 @@ private:
     void reserve(size_t sz)
     {
         if (sz <= blob_sz) return;
-        if (blob) { HIP_OK(hipStreamSynchronize(stream)); HIP_OK(hipFree(blob)); blob = nullptr; blob_sz = 0; }
+        if (blob) {
+            HIP_OK(hipStreamSynchronize(stream));
+            if (aux) HIP_OK(hipStreamSynchronize(aux));
+            HIP_OK(hipFree(blob)); blob = nullptr; blob_sz = 0;
+        }
         HIP_OK(hipMalloc((void**)&blob, sz));
         blob_sz = sz;
     }
@@ -210,10 +221,22 @@ private:
     void need_aux()
     {
         if (aux) return;
-        int lo = 0, hi = 0;
-        HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = highest priority
-        // the sort of the next group is short and on the critical path of the next accumulation
-        HIP_OK(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, hi));
+        // The sort of the following window groups.  SPPARK_MSM_AUX_CUS=N confines it to N compute
+        // units (experiment knob; default: an ordinary stream on all CUs).
+        unsigned ncu = 0;
+        if (const char* e = getenv("SPPARK_MSM_AUX_CUS")) ncu = (unsigned)atoi(e);
+        const unsigned total = (unsigned)gpu->prop.multiProcessorCount;
+        hipError_t err = hipErrorNotSupported;
+        if (ncu && ncu < total) {
+            std::vector<uint32_t> mask((total + 31) / 32, 0);
+            for (unsigned k = 0; k < ncu; k++) {        // spread over the whole CU index range (all XCDs / shader engines)
+                unsigned cu = (unsigned)(((uint64_t)k * total) / ncu);
+                mask[cu / 32] |= 1u << (cu % 32);
+            }
+            err = hipExtStreamCreateWithCUMask(&aux, (uint32_t)mask.size(), mask.data());
+            if (err != hipSuccess) { (void)hipGetLastError(); aux = nullptr; }
+        }
+        if (!aux) HIP_OK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
         need_event(ev_fork);
         for (int b = 0; b < 2; b++) { need_event(ev_sorted[b]); need_event(ev_accdone[b]); }
     }
@@ -374,9 +397,11 @@ private:
         size_t chunk = n;
         if (tune.chunk) chunk = std::min(n, std::max<size_t>(tune.chunk, 1));
         else if (stage_per_point && n > ((size_t)1 << 21)) {
-            // ~8 chunks: the exposed first copy and last computation are 1/8 of the total each;
-            // 2^20..2^24 points per chunk keep every chunk an efficient MSM
-            chunk = std::min<size_t>(std::max<size_t>(n / 8, (size_t)1 << 20), (size_t)1 << 24);
+            // 4 chunks of 2^20..2^24 points: the exposed first copy and last computation are 1/4 of
+            // the total each, and every chunk is still an efficient MSM (a chunk pays its own bucket
+            // sums: 2^21-point chunks cost 2^24 points 87 ms, 2^22-point chunks 75 ms;
+            // profiles/r02_msm_host_path.log)
+            chunk = std::min<size_t>(std::max<size_t>(n / 4, (size_t)1 << 20), (size_t)1 << 24);
         }
         auto need = [&](size_t c) {
             return make_layout(make_plan(c, FRp::NBITS, tune), true).total + 2 * c * stage_per_point + 1024;
@@ -392,153 +417,159 @@ private:
         return chunk;
     }
 
-    // ---- one complete MSM over device-resident data, asynchronously on stream (+ aux) --------
+    // ---- one complete MSM over device-resident data, asynchronously on stream (+ aux) ----------
     // d_points: wire points (stride, flagged) or, when preconverted, the field's own records.
-    // h_out: nwins window sums in pinned host memory (valid after the stream has been synchronised).
+    // h_out: nwins window sums in pinned host memory, valid once |stream| has been synchronised.
+    void sort_group(hipStream_t ss, const msm_plan& p, const layout& l, unsigned b, unsigned w0, unsigned wn,
+                    const u32* d_scalars, bool mont)
+    {
+        u32* digits = (u32*)(blob + l.digits[b]);
+        u32* sorted = (u32*)(blob + l.sorted[b]);
+        u32* H = (u32*)(blob + l.H[b]);
+        u32* tot = (u32*)(blob + l.tot[b]);
+        u32* off = (u32*)(blob + l.off[b]);
+        uint2* partA = (uint2*)(blob + l.partA[b]);
+        u32* offA = (u32*)(blob + l.offA[b]);
+        unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
+                           digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
+        HIP_OK(hipGetLastError());
+        size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + 4096;
+        if (ldsA > 65536) {
+            HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+            HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+        }
+        if (ldsB > 65536)
+            HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+        hipLaunchKernelGGL(k_histA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                           H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+        HIP_OK(hipGetLastError());
+        size_t na_total = (size_t)wn * p.NA;
+        hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((na_total + 255) / 256)), dim3(256), 0, ss,
+                           H, tot, p.nslabs, p.NA, wn);
+        HIP_OK(hipGetLastError());
+        hipLaunchKernelGGL(k_scan_parts, dim3(wn), dim3(1024), 0, ss, offA, tot, p.NA);
+        HIP_OK(hipGetLastError());
+        hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                           partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+        HIP_OK(hipGetLastError());
+        const unsigned big = tune.big ? tune.big : (1u << 18);
+        u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
+        HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
+        hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
+                           sorted, off, partA, offA, p.n, p.NA, p.LB, big);
+        HIP_OK(hipGetLastError());
+        // oversized partitions (skewed scalars); empty list and immediate return otherwise
+        hipLaunchKernelGGL(k_big_find, dim3((p.NA * wn + 255) / 256), dim3(256), 0, ss,
+                           nbig, blist, off, offA, p.NA, p.LB, wn, big);
+        size_t ldsBig = ((size_t)1 << p.LB) * 4;
+        hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB);
+        hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB);
+        hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB);
+        HIP_OK(hipGetLastError());
+    }
+
     void enqueue(const msm_plan& p, const layout& l, const unsigned char* d_points, size_t stride, bool preconverted,
                  const u32* d_scalars, bool mont, std_bucket_t* h_out, bool first_timed)
     {
         const bool flagged = !preconverted && stride > 2 * FP_BYTES;
-        const bool two = p.G > 1;
-        if (two) need_aux();
+        const bool multi = p.G > 1;
+        if (multi) need_aux();
         if (timing && first_timed) { need_tev(2 + 2 * p.G); HIP_OK(hipEventRecord(tev[0], stream)); }
-        if (two) {                                  // everything queued on the main stream so far (inputs, the
-            HIP_OK(hipEventRecord(ev_fork, stream));        // previous MSM on this scratch) precedes the first sort
+        if (multi) {                                // the inputs are ready at this point of the main stream
+            HIP_OK(hipEventRecord(ev_fork, stream));
             HIP_OK(hipStreamWaitEvent(aux, ev_fork, 0));
         }
         bucket_t* buckets = (bucket_t*)(blob + l.buckets);
-        std_bucket_t* d_sums_std = (std_bucket_t*)(blob + l.sums);
-        bucket_t* d_sums_raw = (bucket_t*)(blob + l.sums);
+        u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
+        u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
+        HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
 
-        for (unsigned g = 0; g < p.G; g++) {
-            const unsigned b = g & 1, w0 = g * p.wpg, wn = std::min(p.wpg, p.nwins - w0);
-            hipStream_t ss = two ? aux : stream;
-            u32* digits = (u32*)(blob + l.digits[b]);
-            u32* sorted = (u32*)(blob + l.sorted[b]);
-            u32* H = (u32*)(blob + l.H[b]);
-            u32* tot = (u32*)(blob + l.tot[b]);
-            u32* off = (u32*)(blob + l.off[b]);
-            uint2* partA = (uint2*)(blob + l.partA[b]);
-            u32* offA = (u32*)(blob + l.offA[b]);
-
-            // ---- digits + counting sort of the group (aux stream) ------------------------
-            if (two && g >= 2) HIP_OK(hipStreamWaitEvent(aux, ev_accdone[b], 0));    // accumulate(g-2) has read this set
-            {
-                unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
-                hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
-                                   digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
-                HIP_OK(hipGetLastError());
-                size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + 4096;
-                if (ldsA > 65536) {
-                    HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
-                    HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
+        for (unsigned g = 0; g < p.G; g++, gseq++) {
+            // sort sets by the parity of a counter that keeps running across MSMs (chunks): the
+            // events of set b then always refer to the previous user of set b
+            const unsigned b = multi ? (gseq & 1) : 0, w0 = g * p.wpg, wn = std::min(p.wpg, p.nwins - w0);
+            if (g == 0) {
+                // first group: on the main stream, at full width (stream order protects the set)
+                sort_group(stream, p, l, b, w0, wn, d_scalars, mont);
+                if (INTERNAL && !preconverted) {    // wire points -> the field's own records (2 products per point)
+                    launch_convert(blob + l.conv, d_points, p.n, stride);
+                    d_points = blob + l.conv;
                 }
-                if (ldsB > 65536)
-                    HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
-                hipLaunchKernelGGL(k_histA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
-                                   H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
-                HIP_OK(hipGetLastError());
-                size_t na_total = (size_t)wn * p.NA;
-                hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((na_total + 255) / 256)), dim3(256), 0, ss,
-                                   H, tot, p.nslabs, p.NA, wn);
-                HIP_OK(hipGetLastError());
-                hipLaunchKernelGGL(k_scan_parts, dim3(wn), dim3(1024), 0, ss, offA, tot, p.NA);
-                HIP_OK(hipGetLastError());
-                hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
-                                   partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
-                HIP_OK(hipGetLastError());
-                const unsigned big = tune.big ? tune.big : (1u << 18);
-                u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
-                HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
-                hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
-                                   sorted, off, partA, offA, p.n, p.NA, p.LB, big);
-                HIP_OK(hipGetLastError());
-                // oversized partitions (skewed scalars); empty list and immediate return otherwise
-                hipLaunchKernelGGL(k_big_find, dim3((p.NA * wn + 255) / 256), dim3(256), 0, ss,
-                                   nbig, blist, off, offA, p.NA, p.LB, wn, big);
-                size_t ldsBig = ((size_t)1 << p.LB) * 4;
-                hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB);
-                hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB);
-                hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB);
-                HIP_OK(hipGetLastError());
+            } else {
+                if (gseq >= 2) HIP_OK(hipStreamWaitEvent(aux, ev_accdone[b], 0));    // the accumulation two groups back has read this set
+                sort_group(aux, p, l, b, w0, wn, d_scalars, mont);
+                HIP_OK(hipEventRecord(ev_sorted[b], aux));
+                HIP_OK(hipStreamWaitEvent(stream, ev_sorted[b], 0));
             }
-            if (two) HIP_OK(hipEventRecord(ev_sorted[b], aux));
-
-            // ---- main stream -------------------------------------------------------------
-            if (g == 0 && INTERNAL && !preconverted) {  // wire points -> the field's own records (2 products per
-                launch_convert(blob + l.conv, d_points, p.n, stride);   // point), beside the first group's sort
-                d_points = blob + l.conv;
-            }
-            HIP_OK(hipMemsetAsync(buckets, 0, (size_t)wn * p.NB * sizeof(bucket_t), stream));
-            if (two) HIP_OK(hipStreamWaitEvent(stream, ev_sorted[b], 0));
-
-            // bucket accumulation: level 0 + segmented tree
-            u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
-            u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
             if (timing && first_timed) HIP_OK(hipEventRecord(tev[2 + 2 * g], stream));
             {
+                const u32* sorted = (const u32*)(blob + l.sorted[b]);
+                const u32* off = (const u32*)(blob + l.off[b]);
                 dim3 grid((p.chunks_per_win + 255) / 256, wn);
                 // (fields with their own records read them at their own stride and ignore this one)
                 if (flagged)
                     hipLaunchKernelGGL((k_accumulate<fp_d, true>), grid, dim3(256), 0, stream,
                                        buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
-                                       p.n, p.NB, p.L, p.chunks_per_win);
+                                       p.n, p.NB, p.L, p.chunks_per_win, w0);
                 else
                     hipLaunchKernelGGL((k_accumulate<fp_d, false>), grid, dim3(256), 0, stream,
                                        buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
-                                       p.n, p.NB, p.L, p.chunks_per_win);
+                                       p.n, p.NB, p.L, p.chunks_per_win, w0);
                 HIP_OK(hipGetLastError());
             }
             if (timing && first_timed) HIP_OK(hipEventRecord(tev[3 + 2 * g], stream));
-            if (two && g + 2 < p.G) HIP_OK(hipEventRecord(ev_accdone[b], stream));
-            {
-                size_t nrec = (size_t)2 * wn * p.chunks_per_win;
-                u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
-                for (;;) {
-                    unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
-                    int last = nthreads == 1;
-                    hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
-                                       buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last);
-                    HIP_OK(hipGetLastError());
-                    if (last) break;
-                    nrec = (size_t)2 * nthreads;
-                    std::swap(ik, ok); std::swap(ip, op);
-                }
-            }
+            if (multi) HIP_OK(hipEventRecord(ev_accdone[b], stream));
+        }
 
-            // per-window weighted bucket sums
-            bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
-            bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
-            bucket_t* result;
-            {
-                unsigned nitems = p.NB / p.K;
-                size_t nthr = (size_t)wn * nitems;
-                hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                                   A1, W1, buckets, p.NB, p.K, wn);
+        // ---- segmented record tree over the records of all windows -----------------------------
+        {
+            size_t nrec = (size_t)2 * p.nwins * p.chunks_per_win;
+            u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
+            for (;;) {
+                unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
+                int last = nthreads == 1;
+                hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
+                                   buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last);
                 HIP_OK(hipGetLastError());
-                unsigned lgG = lg2_floor(p.K);
-                bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
-                while (nitems > 1) {
-                    unsigned K = std::min(p.K, nitems);
-                    nthr = (size_t)wn * (nitems / K);
-                    hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                                       oa, ow, ia, iw, nitems, K, lgG, wn);
-                    HIP_OK(hipGetLastError());
-                    nitems /= K; lgG += lg2_floor(K);
-                    std::swap(ia, oa); std::swap(iw, ow);
-                }
-                result = iw;
-            }
-            // the group's window sums -> their slots of the sums area (wire image for internal fields)
-            if constexpr (INTERNAL) {
-                hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((wn + 63) / 64), dim3(64), 0, stream, d_sums_std + w0, result, wn);
-                HIP_OK(hipGetLastError());
-            } else {
-                HIP_OK(hipMemcpyAsync(d_sums_raw + w0, result, wn * sizeof(bucket_t), hipMemcpyDeviceToDevice, stream));
+                if (last) break;
+                nrec = (size_t)2 * nthreads;
+                std::swap(ik, ok); std::swap(ip, op);
             }
         }
+        // ---- per-window weighted bucket sums ----------------------------------------------------
+        bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
+        bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
+        bucket_t* result;
+        {
+            unsigned nitems = p.NB / p.K;
+            size_t nthr = (size_t)p.nwins * nitems;
+            hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                               A1, W1, buckets, p.NB, p.K, p.nwins);
+            HIP_OK(hipGetLastError());
+            unsigned lgG = lg2_floor(p.K);
+            bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
+            while (nitems > 1) {
+                unsigned K = std::min(p.K, nitems);
+                nthr = (size_t)p.nwins * (nitems / K);
+                hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                   oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                HIP_OK(hipGetLastError());
+                nitems /= K; lgG += lg2_floor(K);
+                std::swap(ia, oa); std::swap(iw, ow);
+            }
+            result = iw;
+        }
         if (timing && first_timed) HIP_OK(hipEventRecord(tev[1], stream));
-        HIP_OK(hipMemcpyAsync(h_out, blob + l.sums, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        // ---- device -> host: one XYZZ per window (wire image); Horner on the host ------------------
+        if constexpr (INTERNAL) {
+            std_bucket_t* fin = (std_bucket_t*)(blob + l.sums);
+            hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((p.nwins + 63) / 64), dim3(64), 0, stream, fin, result, p.nwins);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipMemcpyAsync(h_out, fin, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        } else {
+            HIP_OK(hipMemcpyAsync(h_out, result, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        }
     }
 
     // Horner over the window sums (the reference's host-side collect, pippenger.cuh:627-727, is O(256 * windows))
@@ -618,6 +649,8 @@ public:
                     HIP_OK(hipStreamWaitEvent(stream, ev_copied[sb], 0));
                 }
             }
+            // (a shorter last chunk has a layout of its own: harmless, every sort set of an MSM is
+            // either written on the main stream or behind an event recorded on it after the previous MSM)
             enqueue(p, l, d_points, in_stride, preconverted, d_scalars, mont, h_sums + c * MAX_WINS, c == 0);
             if (host && nchunks > 1) HIP_OK(hipEventRecord(ev_chunkdone[sb], stream));
         }

@@ -128,11 +128,14 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
                                    const unsigned char* points, unsigned stride,
                                    const u32* sorted, const u32* off,
                                    unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win,
-                                   unsigned chunk, unsigned w)
+                                   unsigned chunk, unsigned w_local, unsigned w_base = 0)
 {
+    // |sorted| / |off| hold the windows of one window group (index w_local); buckets, records and
+    // keys are indexed by the window's number in the whole MSM (w)
     if (chunk >= chunks_per_win) return;
+    const unsigned w = w_base + w_local;
     const size_t rec0 = ((size_t)w * chunks_per_win + chunk) * 2;
-    const u32* o = off + (size_t)w * (NB + 1);
+    const u32* o = off + (size_t)w_local * (NB + 1);
     const unsigned total = o[NB];
     unsigned p = chunk * L;
     if (p >= total) { rec_key[rec0] = KEY_NONE; rec_key[rec0 + 1] = KEY_NONE; return; }
@@ -146,7 +149,7 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     }
     unsigned b = lo, next = o[b + 1];
 
-    const u32* src = sorted + (size_t)w * n;
+    const u32* src = sorted + (size_t)w_local * n;
     xyzz_dev<FP> acc;
     bool first_run = true;
     u32 slot0_key = KEY_NONE;
@@ -193,10 +196,10 @@ void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
                   u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict__ rec_pt,
                   const unsigned char* __restrict__ points, unsigned stride,
                   const u32* __restrict__ sorted, const u32* __restrict__ off,
-                  unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win)
+                  unsigned n, unsigned NB, unsigned L, unsigned chunks_per_win, unsigned w_base)
 {
     accumulate_chunk<FP, FLAGGED>(buckets, rec_key, rec_pt, points, stride, sorted, off, n, NB, L,
-                                  chunks_per_win, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
+                                  chunks_per_win, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, w_base);
 }
 
 // ---------------------------------------------------------------------------

@@ -685,7 +685,7 @@ def test_msm_window_groups_and_chunks(oracle, libs, curve, name):
 
 
 def test_msm_pipeline_medium_size(oracle, libs):
-    """2^22 points (automatic plan: 4 window groups on two streams; host inputs: 8 chunks) against
+    """2^22 points (4 window groups on two streams forced; host inputs: 4 chunks) against
     the oracle through the period fold, device- and host-resident, repeated back to back so that a
     missing event between the streams would show."""
     import torch
@@ -698,6 +698,8 @@ def test_msm_pipeline_medium_size(oracle, libs):
     d_base = torch.from_numpy(base).cuda()
     pts = d_base[torch.arange(n, device="cuda") % per].contiguous()
     ctx = sppark_amd.MsmContext("bls12_381", stream=torch.cuda.current_stream().cuda_stream)
+    assert ctx.plan_groups(n) == 1
+    ctx.tune_pipeline(groups=4)
     assert ctx.plan_groups(n) == 4
     for it in range(3):
         sc = synth.uniform_scalars(n, "bls12_381", seed=10 + it)

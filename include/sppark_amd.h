@@ -101,6 +101,15 @@ SppError cuda_func(void *ptr);
  * reference's tests do (poc/msm-cuda/tests/msm.rs:26-38). */
 void sppark_msm_release_cached(void);
 
+/* msm/batch_addition.cuh:25-132, the bitmap variants batch_addition / batch_diff (C++ templates in
+ * the reference, whose kernels leave one partial sum per warp for sum_up(), :167-181; here the total
+ * is returned).  out = sum of points[i] over the bits set in bitmap (bit k of word w = point 32*w+k,
+ * ceil(npoints/32) words).  refmap != NULL: the selection is bitmap XOR refmap and a point that is
+ * only in refmap is subtracted (batch_addition.cuh:60-61) -- the difference between two selections.
+ * points: Affine_t / Affine_inf_t records with stride ffi_affine_sz; all pointers host or device. */
+SppError sppark_batch_addition(void *out, const void *points, size_t npoints,
+                               const uint32_t *bitmap, const uint32_t *refmap, size_t ffi_affine_sz);
+
 /* number of usable devices = ngpus() of util/all_gpus.cpp:62-63 (the filtered list) */
 size_t sppark_ngpus(void);
 
@@ -211,6 +220,23 @@ SppError sppark_lde_powers(size_t device_id, void *d_inout, uint32_t lg_domain_s
  * grid-wide sync for it) the two buffers must not overlap: invalid-value error otherwise. */
 SppError sppark_lde_expand(size_t device_id, void *d_out, const void *d_in, uint32_t lg_domain_size,
                            uint32_t lg_blowup, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Polynomial primitives over the library's NTT field (every library)      */
+/*    C++ templates only in the reference (polynomial/*.cuh); buffers host or */
+/*    device, elements in the wire format of compute_ntt.                     */
+/* ------------------------------------------------------------------------ */
+
+/* polynomial/prefix_op.cuh:324-396 with the functors of :17-47: inclusive scan
+ * out[i] = inp[0] (op) ... (op) inp[i]; op: 0 = Add, 1 = Multiply.  out may equal inp. */
+SppError sppark_prefix_op(size_t device_id, void *out, const void *inp, size_t len, int op, void *stream);
+/* polynomial/evaluate.cuh:307-412: ret[j] = sum_{i < len} coeffs[i] * x[j]^i for j < n */
+SppError sppark_poly_evaluate(size_t device_id, void *ret, const void *x, size_t n,
+                              const void *coeffs, size_t len, void *stream);
+/* polynomial/div_by_x_minus_z.cuh:447-486: in-place division of sum_i inout[i] X^i by (X - z), z = one
+ * field element.  rotate == 0: inout[0] = remainder = p(z), inout[1..] = quotient; rotate != 0: the
+ * quotient in inout[0 .. len-2], the remainder in inout[len-1] (div_by_x_minus_z.cuh:152-157). */
+SppError sppark_div_by_x_minus_z(size_t device_id, void *inout, size_t len, const void *z, int rotate, void *stream);
 
 #ifdef __cplusplus
 }

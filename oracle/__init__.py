@@ -40,8 +40,9 @@ BB31_P = 0x78000001
 def build(force=False):
     """Compile liboracle.so (and _ref/ when /root/reference is present)."""
     so = os.path.join(_HERE, "liboracle.so")
-    if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
+    if force and os.path.exists(so):
+        os.remove(so)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])     # make: a no-op when up to date
     if os.path.isdir("/root/reference"):
         subprocess.check_call(["make", "-C", _HERE, "ref"])
     return so
@@ -75,6 +76,9 @@ def lib():
         L.oracle_lde.argtypes = [ci, vp, ctypes.c_uint, ctypes.c_uint, vp]
         L.oracle_lde_powers.argtypes = [ci, vp, ctypes.c_uint]
         L.oracle_lde_expand.argtypes = [ci, vp, vp, ctypes.c_uint, ctypes.c_uint]
+        L.oracle_prefix_op.argtypes = [ci, vp, vp, sz, ci]
+        L.oracle_poly_evaluate.argtypes = [ci, vp, vp, sz, vp, sz]
+        L.oracle_div_by_x_minus_z.argtypes = [ci, vp, sz, vp, ci]
         L.oracle_fr_root.argtypes = [ci, vp, ctypes.c_uint]
         L.oracle_gl64_root.argtypes = [ctypes.c_uint]; L.oracle_gl64_root.restype = u64
         L.oracle_bb31_root.argtypes = [ctypes.c_uint]; L.oracle_bb31_root.restype = ctypes.c_uint32
@@ -253,6 +257,38 @@ def lde_expand(field, x, lg_blowup):
     out = np.zeros((x.shape[0] << lg_blowup, w), dtype=dt)
     lib().oracle_lde_expand(fid, _ptr(out), _ptr(x), x.shape[0].bit_length() - 1, lg_blowup)
     return out.reshape(-1) if w == 1 else out
+
+
+# ------------------------------------------------- polynomial primitives -----
+def _poly_arr(field, x):
+    fid, dt, w = _LDE_FIELDS[field]
+    return fid, np.ascontiguousarray(x, dtype=dt).reshape(-1, w), w
+
+
+def prefix_op(field, x, op):
+    """inclusive scan; op 0 = Add, 1 = Multiply (polynomial/prefix_op.cuh)"""
+    fid, a, w = _poly_arr(field, x)
+    out = np.zeros_like(a)
+    lib().oracle_prefix_op(fid, _ptr(out), _ptr(a), a.shape[0], op)
+    return out.reshape(-1) if w == 1 else out
+
+
+def poly_evaluate(field, coeffs, xs):
+    """ret[j] = sum_i coeffs[i] * xs[j]^i (polynomial/evaluate.cuh)"""
+    fid, c, w = _poly_arr(field, coeffs)
+    _, x, _ = _poly_arr(field, xs)
+    ret = np.zeros_like(x)
+    lib().oracle_poly_evaluate(fid, _ptr(ret), _ptr(x), x.shape[0], _ptr(c), c.shape[0])
+    return ret.reshape(-1) if w == 1 else ret
+
+
+def div_by_x_minus_z(field, coeffs, z, rotate=False):
+    """synthetic division (polynomial/div_by_x_minus_z.cuh): remainder first / last (rotate)"""
+    fid, c, w = _poly_arr(field, coeffs)
+    c = c.copy()
+    _, zz, _ = _poly_arr(field, z)
+    lib().oracle_div_by_x_minus_z(fid, _ptr(c), c.shape[0], _ptr(zz), int(rotate))
+    return c.reshape(-1) if w == 1 else c
 
 
 def ntt_naive_fr(curve, a, inverse=False):

@@ -6,6 +6,7 @@
 #include "ec.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
+#include "poly.hpp"
 #include <vector>
 #include <cstring>
 
@@ -353,6 +354,21 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
         default: lde_expand(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg_domain, lg_blowup); break;
     }
 }
+
+// polynomial primitives; field: 0 gl64, 1 bb31, 2 bls12_381 fr, 3 alt_bn128 fr
+#define POLY_DISPATCH(field, CALL)                                          \
+    switch (field) {                                                        \
+        case 0: { typedef gl64 F; CALL; } break;                            \
+        case 1: { typedef bb31 F; CALL; } break;                            \
+        case 2: { typedef bls12_381_fr F; CALL; } break;                    \
+        default: { typedef alt_bn128_fr F; CALL; } break;                   \
+    }
+void oracle_prefix_op(int field, void* out, const void* in, size_t len, int op)
+{   POLY_DISPATCH(field, prefix_op((F*)out, (const F*)in, len, op))   }
+void oracle_poly_evaluate(int field, void* ret, const void* x, size_t n, const void* coeffs, size_t len)
+{   POLY_DISPATCH(field, poly_evaluate((F*)ret, (const F*)x, n, (const F*)coeffs, len))   }
+void oracle_div_by_x_minus_z(int field, void* inout, size_t len, const void* z, int rotate)
+{   POLY_DISPATCH(field, div_by_x_minus_z((F*)inout, len, *(const F*)z, rotate != 0))   }
 
 uint64_t oracle_gl64_root(unsigned lg) { return root_of_unity<gl64>(lg).raw(); }
 uint32_t oracle_bb31_root(unsigned lg) { return root_of_unity<bb31>(lg).raw(); }

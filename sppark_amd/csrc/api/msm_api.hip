@@ -13,6 +13,8 @@ extern template __global__ void k_accumulate<msm_fp_d, false>(bucket_m*, u32*, b
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_accumulate<msm_fp_d, true>(bucket_m*, u32*, bucket_m*, const unsigned char*, unsigned,
                                                          const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_bitmap_accumulate<msm_fp_d, false>(u32*, bucket_m*, const unsigned char*, unsigned, unsigned, const u32*, const u32*, unsigned);
+extern template __global__ void k_bitmap_accumulate<msm_fp_d, true>(u32*, bucket_m*, const unsigned char*, unsigned, unsigned, const u32*, const u32*, unsigned);
 extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                     unsigned, unsigned, unsigned, int);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
@@ -192,6 +194,23 @@ SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_
 // free the scratch memory kept by the idle one-shot contexts (all devices)
 SPPARK_FFI void sppark_msm_release_cached(void)
 {   ctx_pool<msm_impl>::get().release_idle(); ctx_pool<msm2_impl>::get().release_idle();   }
+
+// msm/batch_addition.cuh:25-132 (batch_addition / batch_diff, the bitmap variants; C++ templates in
+// the reference): out = sum of the points whose bit is set in |bitmap|; with |refmap| the points of
+// the symmetric difference, those only in |refmap| subtracted.  Maps: ceil(npoints/32) words, bit k
+// of word w = point 32*w + k.  points / maps: host or device pointers.
+SPPARK_FFI RustError sppark_batch_addition(void* out, const void* points, size_t npoints,
+                                           const uint32_t* bitmap, const uint32_t* refmap, size_t ffi_affine_sz)
+{
+    store_inf(out);
+    return guarded([&] {
+        borrowed<msm_impl> msm(-1);
+        if (is_device_pointer(points) || is_device_pointer(bitmap) || is_device_pointer(refmap)) HIP_OK(hipDeviceSynchronize());
+        point_t r;
+        msm->batch_add(r, points, npoints, bitmap, refmap, ffi_affine_sz);
+        store_point(out, r);
+    });
+}
 
 // number of usable devices (the filtered list of util/all_gpus.cpp:39-54; ngpus(), :62-63)
 SPPARK_FFI size_t sppark_ngpus(void) { return gpus_t::all().size(); }

@@ -7,4 +7,8 @@ template __global__ void k_accumulate<inst_fp, false>(inst_m*, u32*, inst_m*, co
                                                    const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 template __global__ void k_accumulate<inst_fp, true>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
                                                   const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
+#ifndef SPPARK_G2
+template __global__ void k_bitmap_accumulate<inst_fp, false>(u32*, inst_m*, const unsigned char*, unsigned, unsigned, const u32*, const u32*, unsigned);
+template __global__ void k_bitmap_accumulate<inst_fp, true>(u32*, inst_m*, const unsigned char*, unsigned, unsigned, const u32*, const u32*, unsigned);
+#endif
 }

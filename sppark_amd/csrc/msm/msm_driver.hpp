@@ -587,6 +587,75 @@ private:
     }
 
 public:
+    // Bitmap batch addition (msm/batch_addition.cuh:25-132): out = sum of the selected points.
+    // points / bitmap / refmap (nullable): host or device pointers; maps are ceil(n/32) words.
+    void batch_add(point_t& out, const void* points, size_t npoints, const uint32_t* bitmap, const uint32_t* refmap,
+                   size_t ffi_affine_sz)
+    {
+        out.set_inf();
+        if (npoints == 0) return;
+        if (npoints > (1u << 31) || !points || !bitmap || ffi_affine_sz < 2 * FP_BYTES) HIP_OK(hipErrorInvalidValue);
+        HIP_OK(hipSetDevice(gpu->hip_id));
+        join_default_stream();
+        const size_t nwords = (npoints + 31) / 32;
+        const unsigned span = 4;                                    // 128 points per lane
+        const size_t nrec = (nwords + span - 1) / span, F = 8;
+        size_t o = 0;
+        auto take = [&](size_t sz) { size_t r = o; o += align_up(sz); return r; };
+        const bool pts_dev = is_device_pointer(points), bm_dev = is_device_pointer(bitmap), rm_dev = refmap && is_device_pointer(refmap);
+        const size_t o_pts = take(pts_dev ? 0 : npoints * ffi_affine_sz), o_bm = take(bm_dev ? 0 : nwords * 4),
+                     o_rm = take(refmap && !rm_dev ? nwords * 4 : 0), o_conv = take(INTERNAL ? npoints * conv_stride() : 0),
+                     o_keyA = take(nrec * 4), o_ptA = take(nrec * sizeof(bucket_t)),
+                     o_keyB = take((nrec / F + 2) * 2 * 4), o_ptB = take((nrec / F + 2) * 2 * sizeof(bucket_t)),
+                     o_bucket = take(sizeof(bucket_t)), o_fin = take(sizeof(std_bucket_t));
+        reserve(o);
+        reserve_sums(1);
+        const unsigned char* d_points = (const unsigned char*)points;
+        const u32 *d_bm = bitmap, *d_rm = refmap;
+        if (!pts_dev) { HIP_OK(hipMemcpyAsync(blob + o_pts, points, npoints * ffi_affine_sz, hipMemcpyHostToDevice, stream)); d_points = blob + o_pts; }
+        if (!bm_dev) { HIP_OK(hipMemcpyAsync(blob + o_bm, bitmap, nwords * 4, hipMemcpyHostToDevice, stream)); d_bm = (const u32*)(blob + o_bm); }
+        if (refmap && !rm_dev) { HIP_OK(hipMemcpyAsync(blob + o_rm, refmap, nwords * 4, hipMemcpyHostToDevice, stream)); d_rm = (const u32*)(blob + o_rm); }
+        const bool flagged = ffi_affine_sz > 2 * FP_BYTES;
+        if constexpr (INTERNAL) {
+            launch_convert(blob + o_conv, d_points, (unsigned)npoints, ffi_affine_sz);
+            d_points = blob + o_conv;
+        }
+        bucket_t* bucket = (bucket_t*)(blob + o_bucket);
+        HIP_OK(hipMemsetAsync(bucket, 0, sizeof(bucket_t), stream));
+        u32* ik = (u32*)(blob + o_keyA); bucket_t* ip = (bucket_t*)(blob + o_ptA);
+        u32* ok = (u32*)(blob + o_keyB); bucket_t* op = (bucket_t*)(blob + o_ptB);
+        {
+            dim3 grid((unsigned)((nrec + 255) / 256));
+            if (flagged) hipLaunchKernelGGL((k_bitmap_accumulate<fp_d, true>), grid, dim3(256), 0, stream, ik, ip, d_points,
+                                            (unsigned)ffi_affine_sz, (unsigned)npoints, d_bm, d_rm, span);
+            else         hipLaunchKernelGGL((k_bitmap_accumulate<fp_d, false>), grid, dim3(256), 0, stream, ik, ip, d_points,
+                                            (unsigned)ffi_affine_sz, (unsigned)npoints, d_bm, d_rm, span);
+            HIP_OK(hipGetLastError());
+        }
+        for (size_t n = nrec;;) {                                   // the MSM's record tree, every key = 0
+            unsigned nthreads = (unsigned)((n + F - 1) / F);
+            int last = nthreads == 1;
+            hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
+                               bucket, ok, op, ik, ip, (unsigned)n, (unsigned)F, nthreads, last);
+            HIP_OK(hipGetLastError());
+            if (last) break;
+            n = (size_t)2 * nthreads;
+            std::swap(ik, ok); std::swap(ip, op);
+        }
+        if constexpr (INTERNAL) {
+            std_bucket_t* fin = (std_bucket_t*)(blob + o_fin);
+            hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3(1), dim3(64), 0, stream, fin, bucket, 1u);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipMemcpyAsync(h_sums, fin, sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        } else {
+            HIP_OK(hipMemcpyAsync(h_sums, bucket, sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+        }
+        HIP_OK(hipStreamSynchronize(stream));
+        fp_h c[4];
+        memcpy(c, h_sums, sizeof(c));
+        out = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
+    }
+
     // out: Jacobian X|Y|Z (Montgomery).  points: stride ffi_affine_sz, flagged
     // format iff ffi_affine_sz > 2*FP_BYTES.  scalars: SCALAR_BYTES each.
     void invoke(point_t& out, const void* points, size_t npoints, const void* scalars,

@@ -203,6 +203,49 @@ void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
 }
 
 // ---------------------------------------------------------------------------
+// Bitmap batch addition (msm/batch_addition.cuh:25-132): sum of the points whose bit is set.
+// With a reference map the selection is the symmetric difference and a point that is only in
+// the reference map is SUBTRACTED (bits ^= refs; refs &= bits, batch_addition.cuh:60-61), i.e.
+//     sum_{i in bitmap \ refmap} P_i  -  sum_{i in refmap \ bitmap} P_i.
+// The reference hands 32x32-bit chunks of the map to warps through a device-global atomic
+// counter and shuffles the selected indices to the lanes; here every lane owns a FIXED span of
+// |span_words| 32-bit words (so the number of additions per lane is bounded whatever the
+// density), and leaves one (key 0, partial sum) record for the same segmented record tree the
+// MSM uses (k_reduce_runs), whose last level stores the total into buckets[0].
+// ---------------------------------------------------------------------------
+template<class FP, bool FLAGGED>
+SPPARK_DEVFN void bitmap_accumulate_item(u32* rec_key, xyzz_mem<FP::N>* rec_pt,
+                                         const unsigned char* points, unsigned stride, unsigned npoints,
+                                         const u32* bitmap, const u32* refmap, unsigned span_words, size_t t)
+{
+    const size_t nwords = ((size_t)npoints + 31) / 32;
+    const size_t w0 = t * span_words;
+    if (w0 >= nwords) return;
+    xyzz_dev<FP> acc; acc.set_inf();
+    for (size_t w = w0; w < w0 + span_words && w < nwords; w++) {
+        u32 bits = bitmap[w], refs = refmap ? refmap[w] : 0;
+        bits ^= refs; refs &= bits;
+        if (w == nwords - 1 && (npoints & 31)) bits &= (1u << (npoints & 31)) - 1;     // bits past the last point
+        while (bits) {
+            const unsigned k = __builtin_ctz(bits);
+            bits &= bits - 1;
+            affine_dev<FP> p = load_affine<FP, FLAGGED>(points, w * 32 + k, stride);
+            acc.madd(p, (refs >> k) & 1);
+        }
+    }
+    acc.store(&rec_pt[t]); rec_key[t] = 0;
+}
+template<class FP, bool FLAGGED>
+__global__ __launch_bounds__(256)
+void k_bitmap_accumulate(u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict__ rec_pt,
+                         const unsigned char* __restrict__ points, unsigned stride, unsigned npoints,
+                         const u32* __restrict__ bitmap, const u32* __restrict__ refmap, unsigned span_words)
+{
+    bitmap_accumulate_item<FP, FLAGGED>(rec_key, rec_pt, points, stride, npoints, bitmap, refmap, span_words,
+                                        (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
 // reduce_runs (levels >= 1): same walk over F consecutive records.
 // |last| = this is the final level (single work item): every run is complete.
 // ---------------------------------------------------------------------------

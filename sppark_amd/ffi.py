@@ -88,6 +88,8 @@ def load(name):
         L.sppark_msm_last_chunks.restype = cu
         L.sppark_msm_plan_groups.argtypes = [vp, sz]
         L.sppark_msm_plan_groups.restype = cu
+        L.sppark_batch_addition.argtypes = [vp, vp, sz, vp, vp, sz]
+        L.sppark_batch_addition.restype = _Error
         L.sppark_ngpus.argtypes = []
         L.sppark_ngpus.restype = sz
         L.sppark_msm_multi.argtypes = [vp, vp, sz, vp, ci, sz, cu]
@@ -126,6 +128,12 @@ def load(name):
         L.sppark_lde_powers.restype = _Error
         L.sppark_lde_expand.argtypes = [sz, vp, vp, u32, u32, vp]
         L.sppark_lde_expand.restype = _Error
+        L.sppark_prefix_op.argtypes = [sz, vp, vp, sz, ci, vp]
+        L.sppark_prefix_op.restype = _Error
+        L.sppark_poly_evaluate.argtypes = [sz, vp, vp, sz, vp, sz, vp]
+        L.sppark_poly_evaluate.restype = _Error
+        L.sppark_div_by_x_minus_z.argtypes = [sz, vp, sz, vp, ci, vp]
+        L.sppark_div_by_x_minus_z.restype = _Error
     _LIBS[name] = L
     return L
 

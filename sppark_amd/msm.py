@@ -194,6 +194,25 @@ def msm_multi_shards(shards, curve="bls12_381", device_ids=None, mont=False, ffi
     return out
 
 
+def batch_addition(points, bitmap, refmap=None, curve="bls12_381", ffi_affine_sz=None):
+    """sppark_batch_addition (msm/batch_addition.cuh:25-132): sum of the points whose bit is set in
+    |bitmap| (uint32 words); with |refmap|: points of bitmap XOR refmap, those only in refmap
+    subtracted.  Returns the Jacobian sum."""
+    L = ffi.load(curve)
+    fb = FP_BYTES[curve]
+    stride = ffi_affine_sz or 2 * fb
+    n = _npoints(points, stride)
+    words = (n + 31) // 32
+    if _nbytes(bitmap) != 4 * words or (refmap is not None and _nbytes(refmap) != 4 * words):
+        raise ValueError("maps must hold ceil(npoints/32) 32-bit words")
+    pp, _k1 = ffi.as_pointer(points)
+    pb, _k2 = ffi.as_pointer(bitmap)
+    pr, _k3 = ffi.as_pointer(refmap) if refmap is not None else (None, None)
+    out = np.zeros(3 * fb, dtype=np.uint8)
+    ffi.check(L, L.sppark_batch_addition(out.ctypes.data, pp, n, pb, pr, stride))
+    return out
+
+
 def multi_scalar_mult_fp2_arkworks(points, scalars, curve="bls12_381", ffi_affine_sz=None):
     """mult_pippenger_fp2_inf (poc/msm-cuda/src/lib.rs:84-119): MSM over G2.
 

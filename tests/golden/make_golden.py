@@ -311,13 +311,63 @@ def make_lde():
     print("lde cases:", len(cases))
 
 
+# ---- polynomial primitives (polynomial/*.cuh), definition level -----------------------------
+def make_poly():
+    """prefix_op (Add / Multiply), evaluate, div_by_x_minus_z (both rotations) on canonical
+    Python integers, all four fields, lengths around the tile edges of the GPU kernels."""
+    R32, R256 = 1 << 32, 1 << 256
+    fields = {
+        "gl64": (O.GL64_P, 1, np.uint64, 8),
+        "bb31": (O.BB31_P, R32, np.uint32, 4),
+        "bls12_381": (O.FR_MODULUS[O.BLS12_381], R256, np.uint64, 32),
+        "bn254": (O.FR_MODULUS[O.BN254], R256, np.uint64, 32),
+    }
+    cases = []
+    rng = np.random.default_rng(0x901f)
+    for field, (p, R, dt, nb) in fields.items():
+        rinv = pow(R, -1, p)
+        enc = lambda vals: np.frombuffer(b"".join((v * R % p).to_bytes(nb, "little") for v in vals), dtype=dt)
+        for ln in ((1, 2, 7, 64, 257, 2049) if nb <= 8 else (1, 7, 257, 1030)):     # 2049 / 1030: one element past a GPU tile
+            c = [int.from_bytes(rng.bytes(40), "little") % p for _ in range(ln)]
+            if ln >= 7:
+                c[3] = 0; c[5] = p - 1; c[ln - 1] = 1
+            z = int.from_bytes(rng.bytes(40), "little") % p
+            xs = [0, 1, p - 1, z, (z * z + 7) % p]
+            add, mul, ra, rm = [], [], 0, 1
+            for v in c:
+                ra = (ra + v) % p; rm = rm * v % p
+                add.append(ra); mul.append(rm)
+            ev = [sum(v * pow(x, i, p) for i, v in enumerate(c)) % p for x in xs]
+            b = c[:]
+            for k in range(ln - 2, -1, -1):
+                b[k] = (b[k] + z * b[k + 1]) % p
+            assert b[0] == sum(v * pow(z, i, p) for i, v in enumerate(c)) % p      # remainder = p(z)
+            rot = b[1:] + b[:1]
+            cases.append({"field": field, "len": ln, "coeffs": hexs(enc(c)), "z": hexs(enc([z])), "xs": hexs(enc(xs)),
+                          "prefix_add": hexs(enc(add)), "prefix_mul": hexs(enc(mul)), "evaluate": hexs(enc(ev)),
+                          "div": hexs(enc(b)), "div_rotate": hexs(enc(rot))})
+        # z = 0 and z = 1
+        c = [int.from_bytes(rng.bytes(40), "little") % p for _ in range(300)]
+        for z in (0, 1):
+            b = c[:]
+            for k in range(298, -1, -1):
+                b[k] = (b[k] + z * b[k + 1]) % p
+            cases.append({"field": field, "len": 300, "coeffs": hexs(enc(c)), "z": hexs(enc([z])), "div": hexs(enc(b)),
+                          "div_rotate": hexs(enc(b[1:] + b[:1]))})
+    json.dump(cases, open(os.path.join(HERE, "poly_golden.json"), "w"), indent=0)
+    print("poly cases:", len(cases))
+
+
 if __name__ == "__main__":
     if "--g2-only" in sys.argv:
         make_msm_g2()
     elif "--lde-only" in sys.argv:
         make_lde()
+    elif "--poly-only" in sys.argv:
+        make_poly()
     else:
         make_msm()
         make_msm_g2()
         make_ntt()
         make_lde()
+        make_poly()

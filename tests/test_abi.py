@@ -24,8 +24,9 @@ def test_header_symbols_exported(libs):
     assert "mult_pippenger_inf" in syms and "compute_ntt" in syms and "cuda_available" in syms
     common = {"cuda_available", "drop_gpu_ptr_t", "clone_gpu_ptr_t", "drop_error_message", "cuda_func",
               "sppark_gpu_ptr_alloc", "sppark_gpu_ptr_get"}
-    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1") or s.startswith("sppark_g2")} | {"sppark_ngpus"}
-    ntt_only = {"compute_ntt", "sppark_ntt", "sppark_lde", "sppark_lde_powers", "sppark_lde_expand"}
+    msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1") or s.startswith("sppark_g2")} | {"sppark_ngpus", "sppark_batch_addition"}
+    ntt_only = {"compute_ntt", "sppark_ntt", "sppark_lde", "sppark_lde_powers", "sppark_lde_expand",
+                "sppark_prefix_op", "sppark_poly_evaluate", "sppark_div_by_x_minus_z"}
     assert set(syms) == common | msm_only | ntt_only
     for name, path in libs.items():
         L = ctypes.CDLL(path)

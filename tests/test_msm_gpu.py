@@ -764,3 +764,44 @@ def test_one_shot_pool_is_not_tied_to_threads(oracle, libs):
     assert not bad
     L.sppark_msm_release_cached()
     assert (sppark_amd.to_affine(sppark_amd.multi_scalar_mult_arkworks(pts, sc)) == exp).all()
+
+
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_batch_addition_bitmaps(oracle, libs, curve, name):
+    """sppark_batch_addition (msm/batch_addition.cuh:25-132): sum over a bitmap, and the difference
+    of two selections with a reference map.  Expectation = the oracle's MSM with scalars 1 / r-1 / 0
+    and, for the small case, the independent Python group law; densities from empty to full,
+    ragged tail, infinity inputs, duplicated points (doubling branch), host and device buffers."""
+    import torch
+    import pygroup
+    import sppark_amd
+    O = oracle
+    r = O.FR_MODULUS[curve]
+    one = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
+    neg = np.frombuffer((r - 1).to_bytes(32, "little"), dtype=np.uint8)
+    rng = np.random.default_rng(77 + curve)
+    for n, nd, flagged in ((1, 1, False), (31, 31, True), (32, 8, False), (33, 33, True), (1000, 3, False), (70001, 500, True)):
+        pts, _ = recipe.msm_inputs(curve, n, 900 + n, ndistinct=nd, flagged=flagged)
+        words = (n + 31) // 32
+        for density in (0.0, 0.03, 0.5, 1.0):
+            bm = (rng.random(words * 32) < density)
+            rm = (rng.random(words * 32) < 0.3)
+            for use_ref in (False, True):
+                sel = bm ^ rm if use_ref else bm
+                sc = np.zeros((n, 32), dtype=np.uint8)
+                sc[sel[:n]] = one
+                if use_ref:
+                    sc[(sel & rm)[:n]] = neg
+                exp = O.msm_affine(curve, pts, sc, algo=0, param=4)
+                bw = np.packbits(bm.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+                rw = np.packbits(rm.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+                assert all(((int(bw[i // 32]) >> (i % 32)) & 1) == int(bm[i]) for i in (0, min(n - 1, 37)))
+                out = sppark_amd.batch_addition(pts, bw, rw if use_ref else None, name, ffi_affine_sz=pts.shape[1])
+                assert (sppark_amd.to_affine(out, name) == exp).all(), (name, n, density, use_ref)
+                if n == 33:
+                    pin = pygroup.msm_affine_bytes(name, False, pts.tobytes(), pts.shape[1], flagged, sc.tobytes())
+                    assert pin == exp.tobytes()
+                if n == 70001 and density == 0.5:
+                    d = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+                    out = sppark_amd.batch_addition(d(pts), d(bw), d(rw) if use_ref else None, name, ffi_affine_sz=pts.shape[1])
+                    assert (sppark_amd.to_affine(out, name) == exp).all()

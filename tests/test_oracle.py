@@ -258,3 +258,22 @@ def test_ntt_properties(oracle, field):
         for order in (O.NN, O.RR):
             assert (f(f(v, order, O.FORWARD, O.COSET), order, O.INVERSE, O.COSET) == v).all()
         assert (f(f(v, O.NR, O.FORWARD, O.COSET), O.RN, O.INVERSE, O.COSET) == v).all()
+
+
+def test_poly_golden(oracle):
+    """oracle/poly.hpp against the definition-level Python big-int vectors (the reference has no CPU
+    version of polynomial/*.cuh and no tests for them)."""
+    O = oracle
+    for c in json.load(open(os.path.join(HERE, "golden", "poly_golden.json"))):
+        f = c["field"]
+        dt = np.uint32 if f == "bb31" else np.uint64
+        w = 4 if f in ("bls12_381", "bn254") else 1
+        arr = lambda key: np.frombuffer(bytes.fromhex(c[key]), dtype=dt).reshape(-1, w).squeeze(-1) if w == 1 else \
+            np.frombuffer(bytes.fromhex(c[key]), dtype=dt).reshape(-1, w)
+        coeffs, z = arr("coeffs"), arr("z")
+        assert (O.div_by_x_minus_z(f, coeffs, z) == arr("div")).all(), (f, c["len"])
+        assert (O.div_by_x_minus_z(f, coeffs, z, rotate=True) == arr("div_rotate")).all(), (f, c["len"])
+        if "prefix_add" in c:
+            assert (O.prefix_op(f, coeffs, 0) == arr("prefix_add")).all(), (f, c["len"])
+            assert (O.prefix_op(f, coeffs, 1) == arr("prefix_mul")).all(), (f, c["len"])
+            assert (O.poly_evaluate(f, coeffs, arr("xs")) == arr("evaluate")).all(), (f, c["len"])

@@ -76,6 +76,7 @@ def lib():
         L.oracle_lde.argtypes = [ci, vp, ctypes.c_uint, ctypes.c_uint, vp]
         L.oracle_lde_powers.argtypes = [ci, vp, ctypes.c_uint]
         L.oracle_lde_expand.argtypes = [ci, vp, vp, ctypes.c_uint, ctypes.c_uint]
+        L.oracle_set_root_conventions.argtypes = [ci, ci]
         L.oracle_prefix_op.argtypes = [ci, vp, vp, sz, ci]
         L.oracle_poly_evaluate.argtypes = [ci, vp, vp, sz, vp, sz]
         L.oracle_div_by_x_minus_z.argtypes = [ci, vp, sz, vp, ci]
@@ -257,6 +258,11 @@ def lde_expand(field, x, lg_blowup):
     out = np.zeros((x.shape[0] << lg_blowup, w), dtype=dt)
     lib().oracle_lde_expand(fid, _ptr(out), _ptr(x), x.shape[0].bit_length() - 1, lg_blowup)
     return out.reshape(-1) if w == 1 else out
+
+
+def set_root_conventions(goldilocks_plonky2=False, baby_bear_canonical=False):
+    """the reference's compile-time NTT root conventions (-DGOLDILOCKS_PLONKY2, -DBABY_BEAR_CANONICAL)"""
+    lib().oracle_set_root_conventions(int(goldilocks_plonky2), int(baby_bear_canonical))
 
 
 # ------------------------------------------------- polynomial primitives -----

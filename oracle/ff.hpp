@@ -287,9 +287,12 @@ struct gl64 {
     // reference NTT root tables, ntt/parameters/goldilocks.h:84-159 (default
     // "canonical" generator branch): group_gen = 7, the 2^32-th root below;
     // every other entry of forward_roots_of_unity[] is a repeated square of it.
+    // plonky2() = true selects the -DGOLDILOCKS_PLONKY2 branch (goldilocks.h:7-82):
+    // group_gen = 0xc65c18b67785d900, forward_roots_of_unity[32] = 0x64fdd1a46201e246.
     static const unsigned TWO_ADICITY = 32;
-    static gl64 group_gen()   { return gl64(7); }
-    static gl64 top_root()    { return gl64(0x185629dcda58878cULL); }
+    static bool& plonky2()    { static bool on = false; return on; }
+    static gl64 group_gen()   { return plonky2() ? gl64(0xc65c18b67785d900ULL) : gl64(7); }
+    static gl64 top_root()    { return plonky2() ? gl64(0x64fdd1a46201e246ULL) : gl64(0x185629dcda58878cULL); }
 };
 
 // ---------------------------------------------------------------------------
@@ -326,9 +329,12 @@ struct bb31 {
     friend bool operator==(bb31 a, bb31 b) { return a.v == b.v; }
     // ntt/parameters/baby_bear.h:76-175 (default branch): group_gen = 3,
     // forward_roots_of_unity[27] = 0x1ffffedc (Montgomery).
+    // canonical_roots() = true selects the -DBABY_BEAR_CANONICAL branch (baby_bear.h:7-74):
+    // group_gen = 31 (the smallest primitive root), forward_roots_of_unity[27] = 0x57fab6ee.
     static const unsigned TWO_ADICITY = 27;
-    static bb31 group_gen()   { return from_canonical(3); }
-    static bb31 top_root()    { return from_raw(0x1ffffedcu); }
+    static bool& canonical_roots() { static bool on = false; return on; }
+    static bb31 group_gen()   { return from_canonical(canonical_roots() ? 31 : 3); }
+    static bb31 top_root()    { return from_raw(canonical_roots() ? 0x57fab6eeu : 0x1ffffedcu); }
 };
 
 template<class F> static inline F fpow(F b, uint64_t e)

@@ -370,6 +370,11 @@ void oracle_poly_evaluate(int field, void* ret, const void* x, size_t n, const v
 void oracle_div_by_x_minus_z(int field, void* inout, size_t len, const void* z, int rotate)
 {   POLY_DISPATCH(field, div_by_x_minus_z((F*)inout, len, *(const F*)z, rotate != 0))   }
 
+// compile-time root conventions of the reference, as a run-time switch of the oracle:
+// GOLDILOCKS_PLONKY2 (ntt/parameters/goldilocks.h:7-82), BABY_BEAR_CANONICAL (baby_bear.h:7-74)
+void oracle_set_root_conventions(int goldilocks_plonky2, int baby_bear_canonical)
+{   gl64::plonky2() = goldilocks_plonky2 != 0; bb31::canonical_roots() = baby_bear_canonical != 0;   }
+
 uint64_t oracle_gl64_root(unsigned lg) { return root_of_unity<gl64>(lg).raw(); }
 uint32_t oracle_bb31_root(unsigned lg) { return root_of_unity<bb31>(lg).raw(); }
 uint64_t oracle_gl64_mul(uint64_t a, uint64_t b) { return (gl64::from_raw(a) * gl64::from_raw(b)).raw(); }

@@ -34,13 +34,16 @@ TARGETS = {
     "bn254":     ("FEATURE_BN254", MSM_TUS),
     "gl64":      ("FEATURE_GOLDILOCKS", NTT_TUS),
     "bb31":      ("FEATURE_BABY_BEAR", NTT_TUS),
+    # the reference's compile-time root conventions (ntt/parameters/goldilocks.h:7-82, baby_bear.h:7-74)
+    "gl64_plonky2":   ("FEATURE_GOLDILOCKS -DGOLDILOCKS_PLONKY2", NTT_TUS),
+    "bb31_canonical": ("FEATURE_BABY_BEAR -DBABY_BEAR_CANONICAL", NTT_TUS),
     # test-only libraries (device test hooks + micro-benchmarks): never linked into the product ones
     "bls12_381_devtest": ("FEATURE_BLS12_381", ["api/devtest_api.hip"]),
     "bn254_devtest":     ("FEATURE_BN254", ["api/devtest_api.hip"]),
     "gl64_devtest":      ("FEATURE_GOLDILOCKS", ["api/devtest_small_api.hip"]),
     "bb31_devtest":      ("FEATURE_BABY_BEAR", ["api/devtest_small_api.hip"]),
 }
-PRODUCT = ("bls12_381", "bn254", "gl64", "bb31")
+PRODUCT = ("bls12_381", "bn254", "gl64", "bb31", "gl64_plonky2", "bb31_canonical")
 
 
 def lib_path(name):
@@ -82,7 +85,7 @@ def _compile(job):
     src, obj, feature = job
     t0 = time.time()
     src, _, extra = src.partition(":")
-    cmd = [HIPCC] + FLAGS + ["-D" + feature] + (["-D" + extra] if extra else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + FLAGS + ("-D" + feature).split() + (["-D" + extra] if extra else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
     cmdline = " ".join(cmd)
     if not _deps_changed(obj, cmdline):
         return src, feature, 0.0, 0, "", False

@@ -25,8 +25,15 @@ namespace sppark_amd {
 struct gl64_dev {
     static constexpr u64 MOD = 0xffffffff00000001ULL;
     static constexpr unsigned TWO_ADICITY = 32;
+    // root convention: ntt/parameters/goldilocks.h:84-159 by default, :7-82 with -DGOLDILOCKS_PLONKY2
+    // (plonky2's generator; libsppark_gl64_plonky2.so)
+#ifdef GOLDILOCKS_PLONKY2
+    static constexpr u64 TOP_ROOT = 0x64fdd1a46201e246ULL;      // 0xc65c18b67785d900^((p-1)/2^32)
+    static constexpr u64 GROUP_GEN = 0xc65c18b67785d900ULL;
+#else
     static constexpr u64 TOP_ROOT = 0x185629dcda58878cULL;      // 7^((p-1)/2^32)
     static constexpr u64 GROUP_GEN = 7;
+#endif
     typedef u64 word_t;
     u64 v;
 
@@ -229,7 +236,11 @@ struct gl64_dev {
     template<bool INV>
     SPPARK_DEVFN static constexpr unsigned root_exp(unsigned R, unsigned k)
     {
+#ifdef GOLDILOCKS_PLONKY2
+        constexpr unsigned ER[7] = {0, 96, 48, 24, 12, 6, 3};       // w_{2^R} = 2^(192 / 2^R): w_64 = 8 (goldilocks.h:13-19)
+#else
         constexpr unsigned ER[7] = {0, 96, 48, 120, 156, 78, 39};   // w_{2^R} = 2^ER[R]
+#endif
         unsigned e = (ER[R] * k) % 192;
         if (INV) e = (192 - e) % 192;
         return e;
@@ -248,14 +259,22 @@ struct gl64_dev {
 struct bb31_dev {
     static constexpr u32 MOD = 0x78000001u, M = 0x77ffffffu, RR = 0x45dddde3u, ONE = 0x0ffffffeu;
     static constexpr unsigned TWO_ADICITY = 27;
+    // root convention: ntt/parameters/baby_bear.h:76-175 by default (group_gen 3, e.g. RISC Zero),
+    // :7-74 with -DBABY_BEAR_CANONICAL (group_gen 31; libsppark_bb31_canonical.so)
+#ifdef BABY_BEAR_CANONICAL
+    static constexpr u32 TOP_ROOT = 0x57fab6eeu;                // Montgomery form of 31^((p-1)/2^27)
+    static constexpr u32 GROUP_GEN = 31;
+#else
     static constexpr u32 TOP_ROOT = 0x1ffffedcu;                // Montgomery form
+    static constexpr u32 GROUP_GEN = 3;
+#endif
     typedef u32 word_t;
     u32 v;
 
     SPPARK_DEVFN static bb31_dev from_raw(u32 x) { bb31_dev r; r.v = x; return r; }
     SPPARK_DEVFN static bb31_dev one() { return from_raw(ONE); }
     SPPARK_DEVFN static bb31_dev top_root() { return from_raw(TOP_ROOT); }
-    SPPARK_DEVFN static bb31_dev group_gen() { return from_raw(3) * from_raw(RR); }    // 3 in Montgomery form
+    SPPARK_DEVFN static bb31_dev group_gen() { return from_raw(GROUP_GEN) * from_raw(RR); }    // in Montgomery form
 
     SPPARK_DEVFN friend bb31_dev operator+(bb31_dev a, bb31_dev b)
     {   u32 s = a.v + b.v; s -= (s >= MOD) ? MOD : 0; return from_raw(s);   }

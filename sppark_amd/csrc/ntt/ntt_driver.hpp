@@ -35,7 +35,7 @@ template<> struct host_field<bb31_dev> {                        // canonical ari
     static u64 pow(u64 b, u64 e) { u64 r = 1; while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; } return r; }
     static u64 inv(u64 a) { return pow(a, P - 2); }
     static u64 top_root() { return mul(bb31_dev::TOP_ROOT, inv((1ULL << 32) % P)); }   // out of Montgomery form
-    static u64 gen() { return 3; }
+    static u64 gen() { return bb31_dev::GROUP_GEN; }
     static u64 two_pow(unsigned lg) { return pow(2, lg); }
     static bb31_dev wire(u64 canonical) { bb31_dev r; r.v = (u32)((canonical << 32) % P); return r; }
 };

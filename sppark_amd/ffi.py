@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 CURVES = ("bls12_381", "bn254")
-NTT_FIELDS = ("gl64", "bb31")
+NTT_FIELDS = ("gl64", "bb31", "gl64_plonky2", "bb31_canonical")      # the last two: root-convention variants
 
 
 class _Error(ctypes.Structure):                 # util/rusterror.h:18-36

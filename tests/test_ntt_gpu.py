@@ -336,3 +336,35 @@ def test_lde_sweep_vs_oracle(oracle, libs, field):
             sppark_amd.LDE(0, buf, lg, lgb, field, aux_out=aux)
             assert (buf.reshape(exp.shape) == exp).all(), (field, lg, lgb)
             assert (aux.reshape(aux_exp.shape) == aux_exp).all(), (field, lg, lgb)
+
+
+@pytest.mark.parametrize("lib,field", [("gl64_plonky2", "gl64"), ("bb31_canonical", "bb31")])
+def test_ntt_root_convention_variants(oracle, libs, lib, field):
+    """libsppark_gl64_plonky2.so (-DGOLDILOCKS_PLONKY2, ntt/parameters/goldilocks.h:7-82) and
+    libsppark_bb31_canonical.so (-DBABY_BEAR_CANONICAL, baby_bear.h:7-74): every order / direction /
+    type against the oracle switched to the same convention (pinned against the reference's table
+    entries in tests/test_oracle.py), and the LDE (uses the variant's coset generator)."""
+    import sppark_amd
+    O = oracle
+    f = _oracle_fn(O, field)
+    try:
+        O.set_root_conventions(True, True)
+        for lg in list(range(1, 13)) + [16, 20]:
+            x = recipe.ntt_input(field, lg, 70 + lg)
+            for order in range(4):
+                for direction in range(2):
+                    for typ in range(2):
+                        if lg > 12 and (typ == 1 or direction == 1) and order != 1:
+                            continue
+                        y = x.copy()
+                        sppark_amd.compute_ntt(0, y, order, direction, typ, lib)
+                        assert (y == f(x, order, direction, typ)).all(), (lib, lg, order, direction, typ)
+        x = recipe.ntt_input(field, 10, 5)
+        ext = np.zeros(1 << 12, dtype=x.dtype); ext[:1 << 10] = x
+        sppark_amd.LDE(0, ext, 10, 2, lib)
+        assert (ext == O.lde(field, x, 2)).all()
+        # and the default libraries do NOT use these roots
+        y = x.copy(); sppark_amd.compute_ntt(0, y, 0, 0, 0, field)
+        assert not (y == f(x, 0, 0, 0)).all()
+    finally:
+        O.set_root_conventions(False, False)

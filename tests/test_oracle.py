@@ -277,3 +277,28 @@ def test_poly_golden(oracle):
             assert (O.prefix_op(f, coeffs, 0) == arr("prefix_add")).all(), (f, c["len"])
             assert (O.prefix_op(f, coeffs, 1) == arr("prefix_mul")).all(), (f, c["len"])
             assert (O.poly_evaluate(f, coeffs, arr("xs")) == arr("evaluate")).all(), (f, c["len"])
+
+
+def test_root_convention_variants(oracle):
+    """-DGOLDILOCKS_PLONKY2 / -DBABY_BEAR_CANONICAL: the oracle's switchable conventions against the
+    first entries of the reference's own tables (ntt/parameters/goldilocks.h:12-19,
+    ntt/parameters/baby_bear.h:14-18: forward_roots_of_unity[0..7] / [0..4]) and its group generators
+    (goldilocks.h:9-10, baby_bear.h:9-10)."""
+    O = oracle
+    L = O.lib()
+    try:
+        O.set_root_conventions(True, True)
+        assert [L.oracle_gl64_root(k) for k in range(8)] == [1, 0xffffffff00000000, 0x0001000000000000, 0x0000000001000000,
+                                                              0x1000, 0x40, 0x8, 0x000001fffdfffe00]
+        assert L.oracle_gl64_root(32) == 0x64fdd1a46201e246
+        assert [L.oracle_bb31_root(k) for k in range(5)] == [0x0ffffffe, 0x68000003, 0x1c38d511, 0x3d85298f, 0x5f06e481]
+        assert L.oracle_bb31_root(27) == 0x57fab6ee
+        p = O.BB31_P
+        assert 31 * 0x03def7be % p == 1 and 0xc65c18b67785d900 * 0xb1ddc963fcd29ccc % O.GL64_P == 1     # group_gen * group_gen_inverse
+        # coset transform uses the variant's generator: x = delta_1 -> X[k] = g * w^k
+        x = np.zeros(8, dtype=np.uint64); x[1] = 1
+        y = O.ntt_gl64(x, O.NN, O.FORWARD, O.COSET)
+        assert int(y[0]) == 0xc65c18b67785d900 and int(y[1]) == 0xc65c18b67785d900 * 0x0000000001000000 % O.GL64_P
+    finally:
+        O.set_root_conventions(False, False)
+    assert L.oracle_gl64_root(32) == 0x185629dcda58878c and L.oracle_bb31_root(27) == 0x1ffffedc

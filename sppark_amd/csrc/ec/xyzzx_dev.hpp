@@ -85,14 +85,17 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         F Rd = F::template sub<6, 4>(S2, Y).norm();         // +-S2 - Y    < 9p, n
 
         if (!Pd.template is_zero_mod<13>()) {               // fast path
-            F PP, RR, PPP, Q, M1, M2;
+            F PP, RR, PPP, Q;
             F::sqr2(PP, RR, Pd, Rd);                        // n, < 2p
             F::mul2(PPP, Q, Pd, PP, X, PP);                 // left operand of the second one fat: allowed
             F T   = PPP + Q + Q;                            // < 6p, limbs <= 3*(2^LB - 1)
             F X3  = F::template sub<8, 3>(RR, T);           // < 10p, limbs <= 5*2^LB
             F D   = F::template sub<11, 6>(Q, X3);          // Q - X3      < 13p, limbs < 2^31
-            F::mul2(M1, M2, D, Rd, Y, PPP);
-            Y   = F::template sub<3>(M1, M2);               // < 5p, limbs <= 3*2^LB
+            // Y3 = R*(Q - X3) - Y1*PPP as ONE reduced sum of two products: D*Rd + (6p - Y)*PPP
+            // (6p - Y: Y < 5p with limbs < 3*2^LB, negated against the fat 6p whose limbs are >= 4*2^LB - 4;
+            // the result's limbs are < 5*2^LB)
+            F nY  = F::template neg<6, 4>(Y);               // < 6p
+            Y   = F::mul_add(D, Rd, nY, PPP);               // < (13*9 + 6*2)p/rho + p < 2p, n
             F::mul2(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);
             X = X3;
         } else if (Rd.template is_zero_mod<9>()) {          // same point: 2*p
@@ -124,7 +127,7 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
             F T   = PPP + Q + Q;
             F X3  = F::template sub<8, 3>(Rd.sqr(), T);
             F D   = F::template sub<11, 6>(Q, X3);
-            Y   = F::template sub<3>(D * Rd, S1 * PPP);
+            Y   = F::mul_add(D, Rd, F::template neg<3>(S1), PPP);      // one reduction (see madd); n, < 2p
             ZZ  = (ZZ * PP) * q.ZZ;
             ZZZ = (ZZZ * PPP) * q.ZZZ;
             X = X3;
@@ -157,7 +160,7 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         F M3 = (M + M + M).norm();                          // < 6p
         F X3 = F::template sub<5, 2>(M3.sqr(), S + S);      // < 7p, limbs <= 4*2^LB
         F D  = F::template sub<8, 4>(S, X3);                // < 10p
-        Y = F::template sub<3>(D * M3, W * Yn);
+        Y = F::mul_add(D, M3, F::template neg<3>(W), Yn);
         ZZ = ZZ * V; ZZZ = ZZZ * W;
         X = X3;
     }
@@ -210,7 +213,7 @@ private:
         F M3 = (M + M + M).norm();
         F X3 = F::template sub<5, 2>(M3.sqr(), S + S);
         F D  = F::template sub<8, 4>(S, X3);
-        Y = F::template sub<3>(D * M3, W * y);
+        Y = F::mul_add(D, M3, F::template neg<3>(W), y);
         X = X3; ZZ = V; ZZZ = W;
     }
 };

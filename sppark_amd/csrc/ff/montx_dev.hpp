@@ -295,6 +295,53 @@ template<class P, int LB> struct montx_dev {
             A0 = shift_down(A0); A1 = shift_down(A1);
         }
     }
+    // (a0*b0 + a1*b1) / 2^RBITS with ONE Montgomery reduction (a sum of two products needs no more
+    // than one: NL^2 multiply-adds saved against two separate products and a subtraction).
+    // Contract: b0, b1 normalised; a0's limbs < 2^31, a1's limbs < 6*2^LB, so that a column of both
+    // products and the m*p terms stays below NL*(8 + 6 + 1)*2^(2*LB) < 2^64.  The two products run
+    // in two accumulators (their chains interleave like mul2's) that are joined once per column.
+    // Output normalised, value < (a0*b0 + a1*b1)/2^RBITS + p.
+    SPPARK_DEVFN static montx_dev mul_add(const montx_dev& a0, const montx_dev& b0,
+                                          const montx_dev& a1, const montx_dev& b1)
+    {
+        static_assert((double)NL * ((double)(1ull << 31) + 6.0 * (double)(1ull << LB) + (double)(1ull << LB)) * (double)(1ull << LB)
+                      < 18446744073709551616.0, "a column of two products must fit the 64-bit accumulator");
+        constexpr u32 PINV = P::M0 & MASK;
+        u32 m[NL];
+        montx_dev r;
+        u64 A = 0;
+        #pragma unroll
+        for (int k = 0; k < 2 * NL; k++) {
+            const int lo = k < NL ? 0 : k - NL + 1, hi = k < NL ? k : NL - 1;
+            if (k <= 2 * NL - 2) {
+                u64 B = 0;
+                #pragma unroll
+                for (int i = lo; i <= hi; i++) macx2(A, a0.l[i], b0.l[k - i], B, a1.l[i], b1.l[k - i]);
+                // m[i] is known for i < k; the m*p terms alternate between the two chains
+                const int mhi = hi < k ? hi : k - 1;
+                #pragma unroll
+                for (int i = lo; i + 1 <= mhi; i += 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm("v_mad_u64_u32 %0, vcc, %2, %4, %0\n\tv_mad_u64_u32 %1, vcc, %3, %5, %1"
+                        : "+v"(A), "+v"(B) : "v"(m[i]), "v"(m[i + 1]), "s"(mod_limb(k - i)), "s"(mod_limb(k - i - 1)) : "vcc");
+#else
+                    A += (u64)m[i] * mod_limb(k - i); B += (u64)m[i + 1] * mod_limb(k - i - 1);
+#endif
+                }
+                if (mhi >= lo && ((mhi - lo + 1) & 1)) macxs(A, m[mhi], mod_limb(k - mhi));
+                A += B;
+            }
+            if (k < NL) {
+                m[k] = ((u32)A * PINV) & MASK;
+                macxs(A, m[k], mod_limb(0));
+            } else {
+                r.l[k - NL] = (u32)A & MASK;
+            }
+            A = shift_down(A);
+        }
+        return r;
+    }
+
     // two squares, interleaved likewise (inputs normalised)
     SPPARK_DEVFN static void sqr2(montx_dev& r0, montx_dev& r1, const montx_dev& a0, const montx_dev& a1)
     {

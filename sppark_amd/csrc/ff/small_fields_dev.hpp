@@ -225,10 +225,74 @@ struct gl64_dev {
         const u32 y0 = x0 << sh;
         const u32 y1 = sh ? (x1 << sh) | (x0 >> (32 - sh)) : x1;
         const u32 y2 = sh ? x1 >> (32 - sh) : 0;
-        if (q == 0) return reduce128(y0, y1, y2, 0);
-        if (q == 1) return reduce128(0, y0, y1, y2);
-        // y0*2^64 + y1*2^96 + y2*2^128, and 2^128 = -2^32
-        return reduce128(0, 0, y0, y1) - from_raw((u64)y2 << 32);
+        if (q == 0) return fold_u96(y0, y1, y2);
+        if (q == 1) {                                   // (x*2^sh) * 2^32: two folds (2 mads + 8) beat reduce128's 1 + 17
+            const gl64_dev z = fold_u96(y0, y1, y2);
+            return fold_u96(0, (u32)z.v, (u32)(z.v >> 32));
+        }
+        // y0*2^64 + y1*2^96 + y2*2^128, and 2^96 = -1, 2^128 = -2^32:  y0*E - (y2:y1)
+        return fold_hi(y0, y1, y2);
+    }
+    // (w1:w0) + w2*E, canonical, for w2 < 2^31 (a 64-bit value shifted left by < 32 bits) or for
+    // w0 = 0 and any w2 (a canonical value times 2^32).  The multiply-add wraps at most once and the
+    // wrapped value + E is below p in both cases (V < 2^64 + 2^63, resp. V <= (2^32-1)(2^33-1)); the
+    // two possible corrections -- "it wrapped" and "it is >= p" -- are the same addition of E,
+    // exactly as in operator+: one mad, two carry instructions and two selects instead of
+    // reduce128's seventeen.
+    SPPARK_DEVFN static gl64_dev fold_u96(u32 w0, u32 w1, u32 w2)
+    {
+#if defined(SPPARK_GL64_ASM)
+        u64 t, c, c2;
+        const u64 lo64 = ((u64)w1 << 32) | w0;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=&s"(c) : "v"(w2), "v"(lo64));
+        const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
+        u32 x0, x1, r0, r1;
+        asm("v_add_co_u32 %[x0], %[c2], -1, %[t0]\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %[x1], %[c2], 0, %[t1], %[c2]\n\t"
+            "s_nop 1\n\t"
+            "s_or_b64 %[c2], %[c2], %[c]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32 %[r0], %[t0], %[x0], %[c2]\n\t"
+            "v_cndmask_b32 %[r1], %[t1], %[x1], %[c2]"
+            : [x0]"=&v"(x0), [x1]"=&v"(x1), [r0]"=&v"(r0), [r1]"=&v"(r1), [c2]"=&s"(c2)
+            : [t0]"v"(t0), [t1]"v"(t1), [c]"s"(c) : "scc");
+        return from_raw(((u64)r1 << 32) | r0);
+#else
+        const u64 lo64 = ((u64)w1 << 32) | w0, E = 0xffffffffULL;
+        u64 t = lo64 + (u64)w2 * E;
+        if (t < lo64) return from_raw(t + E);           // wrapped once: + 2^64 = + E, result < 2^63 + 2^32
+        return from_raw(t >= MOD ? t - MOD : t);
+#endif
+    }
+    // w0*E - (w2:w1), canonical, for w2 < 2^31 (the words of a value shifted to 2^64 and above).
+    // w0*E <= (2^32-1)^2 < p and (w2:w1) < 2^63: one multiply, one 64-bit subtraction, and + p on
+    // borrow (the tail of operator-).
+    SPPARK_DEVFN static gl64_dev fold_hi(u32 w0, u32 w1, u32 w2)
+    {
+#if defined(SPPARK_GL64_ASM)
+        u64 t, c;
+        const u64 zero = 0;
+        asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=&s"(c) : "v"(w0), "v"(zero));
+        const u32 t0 = (u32)t, t1 = (u32)(t >> 32);
+        u32 u0, u1, k;
+        asm("v_sub_co_u32 %[u0], vcc, %[t0], %[w1]\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32 %[u1], vcc, %[t1], %[w2], vcc\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %[k], 0, -1, vcc\n\t"
+            "v_sub_co_u32 %[u0], vcc, %[u0], %[k]\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %[u1], vcc, 0, %[u1], vcc"
+            : [u0]"=&v"(u0), [u1]"=&v"(u1), [k]"=&v"(k)
+            : [t0]"v"(t0), [t1]"v"(t1), [w1]"v"(w1), [w2]"v"(w2) : "vcc");
+        return from_raw(((u64)u1 << 32) | u0);
+#else
+        const u64 t = (u64)w0 * 0xffffffffULL, s = ((u64)w2 << 32) | w1;
+        u64 u = t - s;
+        if (t < s) u -= 0xffffffffULL;                  // + p  (mod 2^64)
+        return from_raw(u);
+#endif
     }
     // w_{2^R}^k (w^-1 for INV) = +-2^e with the reference's root convention:
     // root_neg() says whether the sign is minus, mul_root() multiplies by 2^e only.

@@ -68,7 +68,11 @@ template<class P> struct host_field<fr256_dev<P>> {
 
 template<class F>
 class ntt_engine {
-    struct table_set { F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale; };
+    struct table_set {
+        F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale;
+        std::map<std::pair<unsigned, unsigned>, F*> pass_tw;    // (lg_cur, S) -> inter-pass twiddle table of that pass
+    };
+    static constexpr unsigned PASS_TABLE_MAX_LG = 16;          // tables of <= 2^16 elements (512 KB for Goldilocks): L2-resident
     std::map<std::tuple<int, unsigned, int>, table_set> cache;     // (hip device, lg, inverse)
     std::mutex mtx;
 
@@ -80,6 +84,27 @@ class ntt_engine {
     // 8 or 16 eight-word elements per lane (152 VGPRs, scratch) and measured slower in spite of
     // fewer passes: 2^24 in 2.8 ms with S = 4, 3.3 ms with S = 6 (tools/gpu_ntt_wide_knobs.py).
     static constexpr unsigned S_MAX = sizeof(F) > 8 ? 4 : 8;
+
+    // the inter-pass twiddle table of a pass on sub-problems of 2^lg_cur elements (built once per
+    // (device, size, direction, pass shape); null when the pass generates its twiddles instead)
+    const F* pass_table(int hip_dev, unsigned lg, int inverse, unsigned lg_cur, unsigned S, const ntt_tables<F>& T, hipStream_t stream)
+    {
+        if (!ntt_gen_twiddles<F>::value || lg_cur > PASS_TABLE_MAX_LG || lg_cur <= S || S / 2 == 0) return nullptr;
+        std::lock_guard<std::mutex> lk(mtx);
+        table_set& ts = cache.find(std::make_tuple(hip_dev, lg, inverse))->second;
+        auto key = std::make_pair(lg_cur, S);
+        auto it = ts.pass_tw.find(key);
+        if (it != ts.pass_tw.end()) return it->second;
+        F* tw = nullptr;
+        const size_t n = (size_t)1 << lg_cur;
+        HIP_OK(hipMalloc((void**)&tw, n * sizeof(F)));
+        hipLaunchKernelGGL(k_pass_table<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, T, lg_cur, S);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);      // visible to every later call on any stream
+        if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
+        ts.pass_tw.emplace(key, tw);
+        return tw;
+    }
 
     const table_set& tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
     {
@@ -118,7 +143,7 @@ public:
         if (lg > F::TWO_ADICITY || order < 0 || order > 3) HIP_OK(hipErrorInvalidValue);
         const int inverse = direction == NTT_INVERSE;
         const table_set& ts = tables(gpu.hip_id, lg, inverse, stream);
-        ntt_tables<F> T{ts.lo, ts.hi, ts.inner, lg, ts.h, ts.scale}, G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale};
+        ntt_tables<F> T{ts.lo, ts.hi, ts.inner, lg, ts.h, ts.scale, nullptr}, G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale, nullptr};
         const size_t n = (size_t)1 << lg;
         const unsigned egrid = (unsigned)((n + 255) / 256);
 
@@ -143,6 +168,7 @@ public:
         for (unsigned i = 0; i < pl.npass; i++) {
             ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
             P.apply_scale = inverse && i == pl.npass - 1;
+            T.pass_tw = pass_table(gpu.hip_id, lg, inverse, P.lg_cur, P.S, T, stream);
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);
             size_t lds = ntt_lds_elems(P) * sizeof(F);
@@ -191,7 +217,7 @@ public:
     {
         if (lg > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
         const table_set& ts = tables(gpu.hip_id, lg, 0, stream);
-        ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale};
+        ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale, nullptr};
         const size_t n = (size_t)1 << lg;
         hipLaunchKernelGGL(k_coset<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d, G, 1);
         HIP_OK(hipGetLastError());
@@ -206,7 +232,7 @@ public:
         const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
         if ((d_in < d_out + ext) && (d_out < d_in + dom)) HIP_OK(hipErrorInvalidValue);
         const table_set& ts = tables(gpu.hip_id, lg_domain, 0, stream);
-        ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg_domain, ts.h, ts.scale};
+        ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg_domain, ts.h, ts.scale, nullptr};
         hipLaunchKernelGGL(k_lde_spread<F>, dim3((unsigned)((ext + 255) / 256)), dim3(256), 0, stream,
                            d_out, d_in, G, lg_domain, lg_blowup, (int)shift);
         HIP_OK(hipGetLastError());

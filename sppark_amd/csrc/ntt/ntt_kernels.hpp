@@ -39,6 +39,11 @@ template<class F> struct ntt_tables {
     const F* inner;     // inner[(1 << R) + k] = w_{2^R}^k, R <= 8, k < 2^R
     unsigned lg_n, h;
     F scale;            // 1/n for the inverse transform (Montgomery form where applicable)
+    // Inter-pass twiddles of THIS pass as a table, pass_tw[(mid << lgQ) + col] = w_{n_cur}^(col * rev_S(mid)),
+    // or null.  A pass on sub-problems of n_cur <= 2^16 elements has at most 2^16 distinct twiddles,
+    // shared by all its 2^(lg_n - lg_cur) sub-problems: one L2-resident table read in whole rows
+    // (16 coalesced loads per work item) replaces their generation (2 look-ups + 18 products).
+    const F* pass_tw;
 };
 
 struct ntt_pass {
@@ -226,10 +231,17 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
         // w^(col * rev_S(a*2^R2 + b)) = w^(col*rev(a)) * (w^(col << R1))^rev(b)
         constexpr bool GEN = ntt_gen_twiddles<F>::value;
         F pw[GEN ? (1u << R2) : 1];
+        const bool tabled = GEN && T.pass_tw != nullptr;        // uniform over the launch
         if (GEN && geo.lgQ) {
-            const unsigned sh = T.lg_n - P.lg_cur;
-            const size_t col = geo.c0 + c;
-            ntt_twiddle_powers<F, R2, true>(pw, T, (col * bit_rev32(a, R1)) << sh, (col << R1) << sh);
+            if (tabled) {
+                #pragma unroll
+                for (unsigned b = 0; b < (1u << R2); b++)        // natural b here; used as pw[b] below
+                    pw[b] = T.pass_tw[((size_t)((a << R2) + b) << geo.lgQ) + geo.c0 + c];
+            } else {
+                const unsigned sh = T.lg_n - P.lg_cur;
+                const size_t col = geo.c0 + c;
+                ntt_twiddle_powers<F, R2, true>(pw, T, (col * bit_rev32(a, R1)) << sh, (col << R1) << sh);
+            }
         }
         #pragma unroll
         for (unsigned b = 0; b < (1u << R2); b++) {
@@ -238,7 +250,7 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
             else {
                 x[b] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
                 if (geo.lgQ) {
-                    if (GEN) x[b] = x[b] * pw[GEN ? bit_rev32(b, R2) : 0];
+                    if (GEN) x[b] = x[b] * pw[GEN ? (tabled ? b : bit_rev32(b, R2)) : 0];
                     else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
             }
@@ -248,7 +260,7 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
             #pragma unroll
             for (unsigned b = 0; b < (1u << R2); b++) {
                 if (geo.lgQ) {
-                    if (GEN) x[b] = x[b] * pw[GEN ? bit_rev32(b, R2) : 0];
+                    if (GEN) x[b] = x[b] * pw[GEN ? (tabled ? b : bit_rev32(b, R2)) : 0];
                     else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
                 if (P.apply_scale) x[b] = x[b] * T.scale;
@@ -436,6 +448,19 @@ SPPARK_DEVFN void table_item(F* lo, F* hi, F* inner, F base, unsigned lg_n, unsi
 template<class F>
 __global__ __launch_bounds__(256) void k_tables(F* lo, F* hi, F* inner, F base, unsigned lg_n, unsigned h)
 {   table_item(lo, hi, inner, base, lg_n, h, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+
+// pass_tw[(mid << lgQ) + col] = w_{n_cur}^(col * rev_S(mid)), n_cur = 2^lg_cur, lgQ = lg_cur - S
+template<class F>
+SPPARK_DEVFN void pass_table_item(F* tw, const ntt_tables<F>& T, unsigned lg_cur, unsigned S, size_t i)
+{
+    const unsigned lgQ = lg_cur - S;
+    if (i >= ((size_t)1 << lg_cur)) return;
+    const size_t col = i & (((size_t)1 << lgQ) - 1), mid = i >> lgQ;
+    tw[i] = ntt_twiddle(T, (col * bit_rev32((unsigned)mid, S)) << (T.lg_n - lg_cur));
+}
+template<class F>
+__global__ __launch_bounds__(256) void k_pass_table(F* tw, ntt_tables<F> T, unsigned lg_cur, unsigned S)
+{   pass_table_item(tw, T, lg_cur, S, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // ---- planning (host) ---------------------------------------------------------
 struct ntt_plan { ntt_pass pass[16]; unsigned npass; };

@@ -93,6 +93,15 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
         P.apply_scale = inverse && i == pl.npass - 1;
         size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
         std::vector<F> tile(ntt_lds_elems(P) + 1);
+        // as ntt_engine::pass_table(): passes on sub-problems of <= 2^16 elements read their inter-pass
+        // twiddles from a table instead of generating them
+        std::vector<F> pass_tw;
+        T.pass_tw = nullptr;
+        if (ntt_gen_twiddles<F>::value && P.lg_cur <= 16 && P.lg_cur > P.S && P.S / 2 != 0) {
+            pass_tw.resize((size_t)1 << P.lg_cur);
+            for (size_t k = 0; k < pass_tw.size(); k++) pass_table_item(pass_tw.data(), T, P.lg_cur, P.S, k);
+            T.pass_tw = pass_tw.data();
+        }
         for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {
 #define EMU_ROUNDS(R1, R2)                                                                                         \
             do {                                                                                                   \

@@ -84,7 +84,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.HB = p.wbits - 1 - p.LB;
     p.NA = 1u << p.HB;
     size_t entries = (size_t)p.n * p.nwins;
-    unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(64, std::max<size_t>(4, entries / 262144));
+    // run length: 64 entries per lane, 128 from 2^24 points on (half the run records for the tree,
+    // still > 10^5 lanes per window; 2^26: 162.9 -> 161.3 ms, profiles/r02_msm_L_sweep.log)
+    unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(lg >= 24 ? 128 : 64, std::max<size_t>(4, entries / 262144));
     p.L = L;
     p.chunks_per_win = (p.n + L - 1) / L;
     p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));

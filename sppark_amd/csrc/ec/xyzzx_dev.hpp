@@ -27,14 +27,19 @@ template<class P, int LB> struct field_is_internal<montx_dev<P, LB>> { static co
 // stride); the infinity flag rides in bit 31 of X's top limb (a value < 2p leaves it free).
 template<class P, int LB> struct affine_loader<montx_dev<P, LB>> {
     typedef montx_dev<P, LB> F;
-    static constexpr unsigned STRIDE = ((2 * F::NL * 4 + 15) / 16) * 16;
+    // record = X | Y limbs (2*NL words = 112 bytes for BLS12-381) padded to a power of two: a 128-byte
+    // record at a 128-byte-aligned offset is exactly one L2 line / two 64-byte sectors per gather; at
+    // its natural 112-byte stride a record straddles 2.5 sectors on average (measured:
+    // profiles/r02_pmc_traffic.json)
+    static constexpr unsigned RAW = 2 * F::NL * 4;
+    static constexpr unsigned STRIDE = RAW <= 64 ? 64 : RAW <= 128 ? 128 : ((RAW + 15) / 16) * 16;
     template<bool FLAGGED>
     SPPARK_DEVFN static affine_dev<F> load(const unsigned char* base, size_t idx, unsigned)
     {
         const uint4* q = reinterpret_cast<const uint4*>(base + idx * (size_t)STRIDE);
-        u32 w[STRIDE / 4];
+        u32 w[(RAW + 15) / 16 * 4];
         #pragma unroll
-        for (unsigned i = 0; i < STRIDE / 16; i++) { uint4 v = q[i]; w[4*i] = v.x; w[4*i+1] = v.y; w[4*i+2] = v.z; w[4*i+3] = v.w; }
+        for (unsigned i = 0; i < (RAW + 15) / 16; i++) { uint4 v = q[i]; w[4*i] = v.x; w[4*i+1] = v.y; w[4*i+2] = v.z; w[4*i+3] = v.w; }
         affine_dev<F> a;
         a.X = F::from_wire(w); a.Y = F::from_wire(w + F::NL);
         a.inf = (a.X.l[F::NL - 1] >> 31) != 0;

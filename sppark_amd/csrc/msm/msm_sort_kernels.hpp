@@ -20,13 +20,12 @@
 
 namespace sppark_amd {
 
-// Work-group size of the three bulk kernels (k_histA, k_scatterA, k_sortB).  512 lanes = 2 waves
-// per SIMD at <= 24 VGPRs each: such a work-group fits NEXT TO the two 232-VGPR waves per SIMD
-// of k_accumulate (2*232 + 2*24 = 512 registers per lane), so the sort of window group g+1
-// runs on the same CUs, at the same time, as the accumulation of group g (msm_driver.hpp): the
-// one is bound by scattered memory transactions, the other by the integer multiplier.
-static constexpr unsigned SORT_NT = 512;
-#define SORT_VGPRS 24
+// Work-group size of the three bulk kernels (k_histA, k_scatterA, k_sortB): 1024 lanes.  (512-lane,
+// 16-VGPR work-groups, which fit beside the two 232-VGPR waves per SIMD of k_accumulate, were built
+// for the window-group overlap experiment; the overlap gained nothing and the smaller groups cost
+// 3.6 ms per 2^26 MSM: k_sortB 6.7 -> 9.3 ms, k_scatterA 8.6 -> 9.6 ms, profiles/r02_msm_groups.log.)
+static constexpr unsigned SORT_NT = 1024;
+#define SORT_VGPRS 32
 static constexpr int SORTB_UNROLL = 4;       // loads in flight per lane in k_sortB
 
 // H[(w*nslabs + slab)*NA + k_hi] = count of the slab's window-w digits in partition k_hi

@@ -17,12 +17,18 @@ _LIB = None
 
 BLS12_381, BN254 = 0, 1
 BLS12_381_G2, BN254_G2 = 2, 3          # same curves, group G2 (coordinates in Fp2 = c0 | c1)
+BLS12_377, BLS12_377_G2 = 4, 5
 FIELD_BLS_FP, FIELD_BLS_FR, FIELD_BN_FP, FIELD_BN_FR = 0, 1, 2, 3
+FIELD_BLS377_FP, FIELD_BLS377_FR = 4, 5
+CURVE_ID = {"bls12_381": BLS12_381, "bn254": BN254, "bls12_377": BLS12_377}
+CURVE_ID_G2 = {"bls12_381": BLS12_381_G2, "bn254": BN254_G2, "bls12_377": BLS12_377_G2}
+FP_FIELD_ID = {BLS12_381: FIELD_BLS_FP, BN254: FIELD_BN_FP, BLS12_377: FIELD_BLS377_FP}
+FR_FIELD_ID = {BLS12_381: FIELD_BLS_FR, BN254: FIELD_BN_FR, BLS12_377: FIELD_BLS377_FR}
 NN, NR, RN, RR = 0, 1, 2, 3
 FORWARD, INVERSE = 0, 1
 STANDARD, COSET = 0, 1
 
-FP_BYTES = {BLS12_381: 48, BN254: 32, BLS12_381_G2: 96, BN254_G2: 64}      # bytes per coordinate
+FP_BYTES = {BLS12_381: 48, BN254: 32, BLS12_381_G2: 96, BN254_G2: 64, BLS12_377: 48, BLS12_377_G2: 96}      # bytes per coordinate
 FR_MODULUS = {
     BLS12_381: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
     BN254: int("30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", 16),
@@ -31,8 +37,11 @@ FP_MODULUS = {
     BLS12_381: int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16),
     BN254: int("30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47", 16),
 }
+FR_MODULUS[BLS12_377] = 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001
+FP_MODULUS[BLS12_377] = int("01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001", 16)
 FR_MODULUS[BLS12_381_G2] = FR_MODULUS[BLS12_381]; FR_MODULUS[BN254_G2] = FR_MODULUS[BN254]
 FP_MODULUS[BLS12_381_G2] = FP_MODULUS[BLS12_381]; FP_MODULUS[BN254_G2] = FP_MODULUS[BN254]
+FR_MODULUS[BLS12_377_G2] = FR_MODULUS[BLS12_377]; FP_MODULUS[BLS12_377_G2] = FP_MODULUS[BLS12_377]
 GL64_P = 0xffffffff00000001
 BB31_P = 0x78000001
 
@@ -105,7 +114,7 @@ def limbs_to_int(a):
 
 
 def field_op(field, op, a, b=None):
-    nbytes = 48 if field == FIELD_BLS_FP else 32
+    nbytes = 48 if field in (FIELD_BLS_FP, FIELD_BLS377_FP) else 32
     out = np.zeros(nbytes // 8, dtype=np.uint64)
     a = np.ascontiguousarray(a, dtype=np.uint64)
     bp = _ptr(np.ascontiguousarray(b, dtype=np.uint64)) if b is not None else None
@@ -224,7 +233,8 @@ def ntt_fr(curve, a, order=NN, direction=FORWARD, type=STANDARD):
     return a
 
 
-_LDE_FIELDS = {"gl64": (0, np.uint64, 1), "bb31": (1, np.uint32, 1), "bls12_381": (2, np.uint64, 4), "bn254": (3, np.uint64, 4)}
+_LDE_FIELDS = {"gl64": (0, np.uint64, 1), "bb31": (1, np.uint32, 1), "bls12_381": (2, np.uint64, 4), "bn254": (3, np.uint64, 4),
+               "bls12_377": (4, np.uint64, 4)}
 
 
 def lde(field, x, lg_blowup, want_aux=False):

@@ -265,6 +265,30 @@ struct alt_bn128_fr_params {
     static const uint64_t M0 = 0xc2e1f593efffffff;
 };
 
+struct bls12_377_fp_params {
+    static const unsigned TWO_ADICITY = 0, GEN = 0;   // NTT domain (scalar fields only)        // ff/bls12-377.hpp:13-33
+    static const size_t N = 6, NBITS = 377;
+    static const unsigned FP2_NR = 5;                  // Fp2 = Fp[u]/(u^2 + 5), ff/bls12-377-fp2.hpp
+    static constexpr uint64_t MOD[6] = {
+        0x8508c00000000001, 0x170b5d4430000000, 0x1ef3622fba094800, 0x1a22d9f300f5138f, 0xc63b05c06ca1493b, 0x01ae3a4617c510ea };
+    static constexpr uint64_t RR[6] = {
+        0xb786686c9400cd22, 0x0329fcaab00431b1, 0x22a5f11162d6b46d, 0xbfdf7d03827dc3ac, 0x837e92f041790bf9, 0x006dfccb1e914b88 };
+    static constexpr uint64_t ONE[6] = {
+        0x02cdffffffffff68, 0x51409f837fffffb1, 0x9f7db3a98a7d3ff2, 0x7b4e97b76e7c6305, 0x4cf495bf803c84e8, 0x008d6661e2fdf49a };
+    static const uint64_t M0 = 0x8508bfffffffffff;
+};
+struct bls12_377_fr_params {
+    static const unsigned TWO_ADICITY = 47, GEN = 22;   // NTT domain (scalar fields only)        // ff/bls12-377.hpp:35-51, ntt/parameters/bls12_377.h:11-16
+    static const size_t N = 4, NBITS = 253;
+    static constexpr uint64_t MOD[4] = {
+        0x0a11800000000001, 0x59aa76fed0000001, 0x60b44d1e5c37b001, 0x12ab655e9a2ca556 };
+    static constexpr uint64_t RR[4] = {
+        0x25d577bab861857b, 0xcc2c27b58860591f, 0xa7cc008fe5dc8593, 0x011fdae7eff1c939 };
+    static constexpr uint64_t ONE[4] = {
+        0x7d1c7ffffffffff3, 0x7257f50f6ffffff2, 0x16d81575512c0fee, 0x0d4bda322bbb9a9d };
+    static const uint64_t M0 = 0x0a117fffffffffff;
+};
+
 // ---------------------------------------------------------------------------
 // Goldilocks (ff/gl64_t.cuh:39-587): canonical residues in a u64.
 // ---------------------------------------------------------------------------
@@ -350,7 +374,11 @@ template<class F> static inline F fpow(F b, uint64_t e)
 // (not vendored); this class offers the same interface mont_t does, so that the reference's
 // point templates (and this oracle's) instantiate over it.  Schoolbook products on purpose
 // (the device code uses Karatsuba).
+// Fp2 = Fp[u]/(u^2 + NR): NR = 1 for BLS12-381 and alt_bn128 (ff/bls12-381-fp2.hpp, ff/alt_bn128-fp2.hpp),
+// 5 for BLS12-377 (ff/bls12-377-fp2.hpp)
+template<class FP> struct fp2_nonresidue { static const unsigned value = 1; };
 template<class FP> class fp2_t {
+    static FP mul_nr(const FP& x) { FP r = x; for (unsigned k = 1; k < fp2_nonresidue<FP>::value; k++) r += x; return r; }
 public:
     static const unsigned int degree = 2;
     using mem_t = fp2_t;
@@ -368,7 +396,7 @@ public:
     fp2_t& operator-=(const fp2_t& b) { c0 -= b.c0; c1 -= b.c1; return *this; }
     fp2_t& operator*=(const fp2_t& b)
     {
-        FP r0 = c0 * b.c0 - c1 * b.c1, r1 = c0 * b.c1 + c1 * b.c0;
+        FP r0 = c0 * b.c0 - mul_nr(c1 * b.c1), r1 = c0 * b.c1 + c1 * b.c0;
         c0 = r0; c1 = r1;
         return *this;
     }
@@ -381,10 +409,10 @@ public:
     friend fp2_t operator<<(fp2_t a, unsigned l) { return a <<= l; }
     fp2_t& cneg(bool flag) { c0.cneg(flag); c1.cneg(flag); return *this; }
     friend fp2_t czero(const fp2_t& a, int set_z) { fp2_t r; r.c0 = czero(a.c0, set_z); r.c1 = czero(a.c1, set_z); return r; }
-    // 1/(a0 + a1 u) = (a0 - a1 u)/(a0^2 + a1^2)
+    // 1/(a0 + a1 u) = (a0 - a1 u)/(a0^2 + NR a1^2)
     fp2_t reciprocal() const
     {
-        FP n = (c0 * c0 + c1 * c1).reciprocal();
+        FP n = (c0 * c0 + mul_nr(c1 * c1)).reciprocal();
         fp2_t r; r.c0 = c0 * n; r.c1 = c1 * n; r.c1.cneg(true);
         return r;
     }
@@ -395,6 +423,10 @@ typedef mont_t<bls12_381_fp_params> bls12_381_fp;
 typedef mont_t<bls12_381_fr_params> bls12_381_fr;
 typedef mont_t<alt_bn128_fp_params> alt_bn128_fp;
 typedef mont_t<alt_bn128_fr_params> alt_bn128_fr;
+typedef mont_t<bls12_377_fp_params> bls12_377_fp;
+typedef mont_t<bls12_377_fr_params> bls12_377_fr;
+template<> struct fp2_nonresidue<bls12_377_fp> { static const unsigned value = 5; };
+typedef fp2_t<bls12_377_fp> bls12_377_fp2;
 typedef fp2_t<bls12_381_fp> bls12_381_fp2;
 typedef fp2_t<alt_bn128_fp> alt_bn128_fp2;
 

@@ -144,6 +144,33 @@ struct alt_bn128_g2 : curve_t<alt_bn128_fp2, alt_bn128_fr> {
                                          "009713b03af0fed4cd2cafadeed8fdf4a74fa084e52d1852e4a2bd0685c315d2");   }
 };
 
+// BLS12-377 (ff/bls12-377.hpp): y^2 = x^3 + 1; the twist over Fp2 = Fp[u]/(u^2 + 5) is y^2 = x^3 + 1/u.
+// G1: the standard generator (ark-bls12-377); G2: a point of order r derived and checked with Python
+// big-ints (cofactor clearing of the first twist point with x = k + u)
+struct bls12_377_g1 : curve_t<bls12_377_fp, bls12_377_fr> {
+    static affine<fp> generator()
+    {
+        affine<fp> g;
+        g.X = from_hex<fp>("008848defe740a67c8fc6225bf87ff5485951e2caa9d41bb188282c8bd37cb5cd5481512ffcd394eeab9b16eb21be9ef");
+        g.Y = from_hex<fp>("01914a69c5102eff1f674f5d30afeec4bd7fb348ca3e52d96d182ad44fb82305c2fe3d3634a9591afd82de55559c8ea6");
+        return g;
+    }
+    static fp b() { return from_hex<fp>("1"); }
+};
+struct bls12_377_g2 : curve_t<bls12_377_fp2, bls12_377_fr> {
+    static affine<fp> generator()
+    {
+        affine<fp> g;
+        g.X = fp2_hex<fp, bls12_377_fp>("6f72205595a839df693176b247c2fa251f7e02a29061e50540dc9e1c2bf1957bf1bab2288c257c2cb36b58f2418bc9",
+                                        "138c24b2b4e17888beed0a9802aac837cdea39890effe00072f754ecb0152dd6cb524f281298966dbaeca23d3e462b8");
+        g.Y = fp2_hex<fp, bls12_377_fp>("16235fdea6c3faf2a83d3730f6ab2c033ef6c2739002946f7dc48e4688bca1af1c9b417d58220817e0dc644b5e7d916",
+                                        "707ac6cc7d192827fc54eb83267f3bed8511bd3c74f63a1ea75eabb66476769c8786f2af2a75166f33142379b4963c");
+        return g;
+    }
+    static fp b()                                                               // (0, -1/5) = 1/u
+    {   return fp2_hex<fp, bls12_377_fp>("0", "010222f6db0fd6f343bd03737460c589dc7b4f91cd5fd889129207b63c6bf8000dd39e5c1ccccccd1c9ed9999999999a");   }
+};
+
 template<class C>
 std::vector<unsigned char> plain_scalars(const unsigned char* scalars, size_t n, int mont)
 {
@@ -235,23 +262,25 @@ template<class C> void store_generator(unsigned char* out, size_t stride)
 
 } // namespace
 
-// curve: 0 BLS12-381 G1, 1 alt_bn128 G1, 2 BLS12-381 G2, 3 alt_bn128 G2
+// curve: 0 BLS12-381 G1, 1 alt_bn128 G1, 2 BLS12-381 G2, 3 alt_bn128 G2, 4 BLS12-377 G1, 5 BLS12-377 G2
 #define CURVE_DO(curve, FN, ...)                                                         \
     switch (curve) {                                                                     \
         case 0: FN<bls12_381_g1>(__VA_ARGS__); break; case 1: FN<alt_bn128_g1>(__VA_ARGS__); break; \
         case 2: FN<bls12_381_g2>(__VA_ARGS__); break; case 3: FN<alt_bn128_g2>(__VA_ARGS__); break; \
+        case 4: FN<bls12_377_g1>(__VA_ARGS__); break; case 5: FN<bls12_377_g2>(__VA_ARGS__); break; \
         default: return -1;                                                              \
     }
 #define CURVE_RET(curve, FN, ...)                                                        \
     switch (curve) {                                                                     \
         case 0: return FN<bls12_381_g1>(__VA_ARGS__); case 1: return FN<alt_bn128_g1>(__VA_ARGS__); \
         case 2: return FN<bls12_381_g2>(__VA_ARGS__); case 3: return FN<alt_bn128_g2>(__VA_ARGS__); \
+        case 4: return FN<bls12_377_g1>(__VA_ARGS__); case 5: return FN<bls12_377_g2>(__VA_ARGS__); \
         default: return -1;                                                              \
     }
 
 extern "C" {
 
-// field: 0 bls12_381 fp, 1 bls12_381 fr, 2 alt_bn128 fp, 3 alt_bn128 fr
+// field: 0 bls12_381 fp, 1 bls12_381 fr, 2 alt_bn128 fp, 3 alt_bn128 fr, 4 bls12_377 fp, 5 bls12_377 fr
 // op: 0 add 1 sub 2 montmul 3 inverse 4 to_mont 5 from_mont 6 neg 7 sqr
 int oracle_field_op(int field, int op, uint64_t* out, const uint64_t* a, const uint64_t* b)
 {
@@ -260,6 +289,8 @@ int oracle_field_op(int field, int op, uint64_t* out, const uint64_t* a, const u
         case 1: return field_op<bls12_381_fr>(op, out, a, b);
         case 2: return field_op<alt_bn128_fp>(op, out, a, b);
         case 3: return field_op<alt_bn128_fr>(op, out, a, b);
+        case 4: return field_op<bls12_377_fp>(op, out, a, b);
+        case 5: return field_op<bls12_377_fr>(op, out, a, b);
     }
     return -1;
 }
@@ -309,20 +340,23 @@ void oracle_ntt_naive_gl64(uint64_t* out, const uint64_t* in, unsigned lg, int i
 void oracle_ntt_naive_bb31(uint32_t* out, const uint32_t* in, unsigned lg, int inv)
 {   ntt_naive(reinterpret_cast<bb31*>(out), reinterpret_cast<const bb31*>(in), lg, inv != 0);   }
 
-// 256-bit scalar fields: field 0 = BLS12-381 Fr, 1 = alt_bn128 Fr; elements are 4 x u64 Montgomery limbs
+// 256-bit scalar fields: field 0 = BLS12-381 Fr, 1 = alt_bn128 Fr, 4 = BLS12-377 Fr (the curve ids); elements are 4 x u64 Montgomery limbs
 void oracle_ntt_fr(int field, uint64_t* inout, unsigned lg, int order, int direction, int type)
 {
-    if (field == 0) ntt(reinterpret_cast<bls12_381_fr*>(inout), lg, order, direction, type);
-    else            ntt(reinterpret_cast<alt_bn128_fr*>(inout), lg, order, direction, type);
+    if (field == 0)      ntt(reinterpret_cast<bls12_381_fr*>(inout), lg, order, direction, type);
+    else if (field == 4) ntt(reinterpret_cast<bls12_377_fr*>(inout), lg, order, direction, type);
+    else                 ntt(reinterpret_cast<alt_bn128_fr*>(inout), lg, order, direction, type);
 }
 void oracle_ntt_naive_fr(int field, uint64_t* out, const uint64_t* in, unsigned lg, int inv)
 {
-    if (field == 0) ntt_naive(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg, inv != 0);
-    else            ntt_naive(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg, inv != 0);
+    if (field == 0)      ntt_naive(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg, inv != 0);
+    else if (field == 4) ntt_naive(reinterpret_cast<bls12_377_fr*>(out), reinterpret_cast<const bls12_377_fr*>(in), lg, inv != 0);
+    else                 ntt_naive(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg, inv != 0);
 }
 void oracle_fr_root(int field, uint64_t* out, unsigned lg)
 {
     if (field == 0) { auto w = root_of_unity<bls12_381_fr>(lg); memcpy(out, w.v, 32); }
+    else if (field == 4) { auto w = root_of_unity<bls12_377_fr>(lg); memcpy(out, w.v, 32); }
 
     else            { auto w = root_of_unity<alt_bn128_fr>(lg); memcpy(out, w.v, 32); }
 }
@@ -333,6 +367,7 @@ void oracle_lde(int field, void* inout, unsigned lg_domain, unsigned lg_blowup, 
         case 0: lde(reinterpret_cast<gl64*>(inout), lg_domain, lg_blowup, reinterpret_cast<gl64*>(aux)); break;
         case 1: lde(reinterpret_cast<bb31*>(inout), lg_domain, lg_blowup, reinterpret_cast<bb31*>(aux)); break;
         case 2: lde(reinterpret_cast<bls12_381_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<bls12_381_fr*>(aux)); break;
+        case 4: lde(reinterpret_cast<bls12_377_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<bls12_377_fr*>(aux)); break;
         default: lde(reinterpret_cast<alt_bn128_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<alt_bn128_fr*>(aux)); break;
     }
 }
@@ -342,6 +377,7 @@ void oracle_lde_powers(int field, void* inout, unsigned lg)
         case 0: lde_powers_bitrev(reinterpret_cast<gl64*>(inout), lg); break;
         case 1: lde_powers_bitrev(reinterpret_cast<bb31*>(inout), lg); break;
         case 2: lde_powers_bitrev(reinterpret_cast<bls12_381_fr*>(inout), lg); break;
+        case 4: lde_powers_bitrev(reinterpret_cast<bls12_377_fr*>(inout), lg); break;
         default: lde_powers_bitrev(reinterpret_cast<alt_bn128_fr*>(inout), lg); break;
     }
 }
@@ -351,6 +387,7 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
         case 0: lde_expand(reinterpret_cast<gl64*>(out), reinterpret_cast<const gl64*>(in), lg_domain, lg_blowup); break;
         case 1: lde_expand(reinterpret_cast<bb31*>(out), reinterpret_cast<const bb31*>(in), lg_domain, lg_blowup); break;
         case 2: lde_expand(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg_domain, lg_blowup); break;
+        case 4: lde_expand(reinterpret_cast<bls12_377_fr*>(out), reinterpret_cast<const bls12_377_fr*>(in), lg_domain, lg_blowup); break;
         default: lde_expand(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg_domain, lg_blowup); break;
     }
 }
@@ -361,6 +398,7 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
         case 0: { typedef gl64 F; CALL; } break;                            \
         case 1: { typedef bb31 F; CALL; } break;                            \
         case 2: { typedef bls12_381_fr F; CALL; } break;                    \
+        case 4: { typedef bls12_377_fr F; CALL; } break;                    \
         default: { typedef alt_bn128_fr F; CALL; } break;                   \
     }
 void oracle_prefix_op(int field, void* out, const void* in, size_t len, int op)

@@ -71,6 +71,9 @@ int ref_mult_pippenger(int curve, unsigned char* out_affine, const unsigned char
         // as poc/msm-cuda/cuda/pippenger_inf.cu:36-47 instantiates them on the device)
         case 2: return ref_msm<bls12_381_fp2, bls12_381_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
         case 3: return ref_msm<alt_bn128_fp2, alt_bn128_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
+        // BLS12-377 (poc/msm-cuda/cuda/pippenger_inf.cu:9-10), G1 and G2
+        case 4: return ref_msm<bls12_377_fp, bls12_377_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
+        case 5: return ref_msm<bls12_377_fp2, bls12_377_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
     }
     return -1;
 }

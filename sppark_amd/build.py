@@ -32,6 +32,7 @@ NTT_TUS = ["api/ntt_api.hip", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_
 TARGETS = {
     "bls12_381": ("FEATURE_BLS12_381", MSM_TUS),
     "bn254":     ("FEATURE_BN254", MSM_TUS),
+    "bls12_377": ("FEATURE_BLS12_377", MSM_TUS),
     "gl64":      ("FEATURE_GOLDILOCKS", NTT_TUS),
     "bb31":      ("FEATURE_BABY_BEAR", NTT_TUS),
     # the reference's compile-time root conventions (ntt/parameters/goldilocks.h:7-82, baby_bear.h:7-74)
@@ -40,10 +41,11 @@ TARGETS = {
     # test-only libraries (device test hooks + micro-benchmarks): never linked into the product ones
     "bls12_381_devtest": ("FEATURE_BLS12_381", ["api/devtest_api.hip"]),
     "bn254_devtest":     ("FEATURE_BN254", ["api/devtest_api.hip"]),
+    "bls12_377_devtest": ("FEATURE_BLS12_377", ["api/devtest_api.hip"]),
     "gl64_devtest":      ("FEATURE_GOLDILOCKS", ["api/devtest_small_api.hip"]),
     "bb31_devtest":      ("FEATURE_BABY_BEAR", ["api/devtest_small_api.hip"]),
 }
-PRODUCT = ("bls12_381", "bn254", "gl64", "bb31", "gl64_plonky2", "bb31_canonical")
+PRODUCT = ("bls12_381", "bn254", "bls12_377", "gl64", "bb31", "gl64_plonky2", "bb31_canonical")
 
 
 def lib_path(name):

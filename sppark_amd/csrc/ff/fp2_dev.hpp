@@ -1,5 +1,6 @@
-// Quadratic extension Fp2 = Fp[u]/(u^2 + 1) on the device: the coordinate field of
-// G2 for BLS12-381 and alt_bn128 (both use the non-residue -1).
+// Quadratic extension Fp2 = Fp[u]/(u^2 + NR) on the device: the coordinate field of G2.
+// NR = P::FP2_NR: 1 for BLS12-381 and alt_bn128 (u^2 = -1), 5 for BLS12-377 (u^2 = -5,
+// ff/bls12-377-fp2.hpp).
 //
 // The reference splits one Fp2 element over two adjacent lanes and exchanges halves
 // with warp shuffles (ff/bls12-381-fp2.hpp:25-150, `degree = 2`); here one lane owns
@@ -33,21 +34,30 @@ template<class P> struct fp2_dev {
     SPPARK_DEVFN fp2_dev neg() const { fp2_dev r; r.c0 = c0.neg(); r.c1 = c1.neg(); return r; }
     SPPARK_DEVFN fp2_dev cneg(bool flag) const { fp2_dev r; r.c0 = c0.cneg(flag); r.c1 = c1.cneg(flag); return r; }
 
-    // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0 - a1 b1) u
+    // x * NR for the small non-residues in use
+    SPPARK_DEVFN static fp mul_nr(const fp& x)
+    {
+        if constexpr (P::FP2_NR == 1) return x;
+        else { static_assert(P::FP2_NR == 5, "non-residue"); return x.dbl().dbl() + x; }
+    }
+    // (a0 + a1 u)(b0 + b1 u) = (a0 b0 - NR a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0 - a1 b1) u
     SPPARK_DEVFN friend fp2_dev operator*(const fp2_dev& a, const fp2_dev& b)
     {
         fp t0 = a.c0 * b.c0, t1 = a.c1 * b.c1;
         fp2_dev r;
         r.c1 = (a.c0 + a.c1) * (b.c0 + b.c1) - t0 - t1;
-        r.c0 = t0 - t1;
+        r.c0 = t0 - mul_nr(t1);
         return r;
     }
-    // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u
+    // (a0 + a1 u)^2 = (a0^2 - NR a1^2) + 2 a0 a1 u, with
+    // a0^2 - NR a1^2 = (a0 + a1)(a0 - NR a1) + (NR - 1) a0 a1: two base products for any NR
     SPPARK_DEVFN fp2_dev sqr() const
     {
         fp2_dev r;
-        r.c1 = (c0 * c1).dbl();
-        r.c0 = (c0 + c1) * (c0 - c1);
+        const fp m = c0 * c1;
+        r.c1 = m.dbl();
+        if constexpr (P::FP2_NR == 1) r.c0 = (c0 + c1) * (c0 - c1);
+        else                          r.c0 = (c0 + c1) * (c0 - mul_nr(c1)) + m.dbl().dbl();     // NR - 1 = 4
         return r;
     }
 };

@@ -15,6 +15,7 @@ namespace sppark_amd {
 // BLS12-381 base field, ff/bls12-381.hpp:13-33 (device) / :100-116 (host)
 struct bls12_381_fp_p {
     static constexpr int N = 12, N64 = 6, NBITS = 381;
+    static constexpr unsigned FP2_NR = 1;               // Fp2 = Fp[u]/(u^2 + 1)  (ff/bls12-381-fp2.hpp)
     static constexpr uint64_t MOD64[6] = {
         0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
         0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL };
@@ -61,6 +62,7 @@ struct bls12_381_fr_p {
 // alt_bn128 (BN254) base field, ff/alt_bn128.hpp:13-30 / :88-101
 struct alt_bn128_fp_p {
     static constexpr int N = 8, N64 = 4, NBITS = 254;
+    static constexpr unsigned FP2_NR = 1;               // Fp2 = Fp[u]/(u^2 + 1)  (ff/alt_bn128-fp2.hpp)
     static constexpr uint64_t MOD64[4] = {
         0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL };
     static constexpr uint64_t RR64[4] = {
@@ -98,6 +100,40 @@ struct alt_bn128_fr_p {
         SPPARK_L2(ONE64[0]), SPPARK_L2(ONE64[1]), SPPARK_L2(ONE64[2]), SPPARK_L2(ONE64[3]) };
 };
 
+// BLS12-377 base field, ff/bls12-377.hpp:13-33
+struct bls12_377_fp_p {
+    static constexpr int N = 12, N64 = 6, NBITS = 377;
+    static constexpr unsigned FP2_NR = 5;               // Fp2 = Fp[u]/(u^2 + 5)  (ff/bls12-377-fp2.hpp)
+    static constexpr uint64_t MOD64[6] = {
+        0x8508c00000000001ULL, 0x170b5d4430000000ULL, 0x1ef3622fba094800ULL, 0x1a22d9f300f5138fULL, 0xc63b05c06ca1493bULL, 0x01ae3a4617c510eaULL };
+    static constexpr uint64_t RR64[6] = {
+        0xb786686c9400cd22ULL, 0x0329fcaab00431b1ULL, 0x22a5f11162d6b46dULL, 0xbfdf7d03827dc3acULL, 0x837e92f041790bf9ULL, 0x006dfccb1e914b88ULL };
+    static constexpr uint64_t ONE64[6] = {
+        0x02cdffffffffff68ULL, 0x51409f837fffffb1ULL, 0x9f7db3a98a7d3ff2ULL, 0x7b4e97b76e7c6305ULL, 0x4cf495bf803c84e8ULL, 0x008d6661e2fdf49aULL };
+    static constexpr uint64_t M0_64 = 0x8508bfffffffffffULL;
+    static constexpr uint32_t M0 = 0xffffffffu;
+    static constexpr uint32_t MOD[12] = { SPPARK_L2(MOD64[0]), SPPARK_L2(MOD64[1]), SPPARK_L2(MOD64[2]), SPPARK_L2(MOD64[3]), SPPARK_L2(MOD64[4]), SPPARK_L2(MOD64[5]) };
+    static constexpr uint32_t RR[12] = { SPPARK_L2(RR64[0]), SPPARK_L2(RR64[1]), SPPARK_L2(RR64[2]), SPPARK_L2(RR64[3]), SPPARK_L2(RR64[4]), SPPARK_L2(RR64[5]) };
+    static constexpr uint32_t ONE[12] = { SPPARK_L2(ONE64[0]), SPPARK_L2(ONE64[1]), SPPARK_L2(ONE64[2]), SPPARK_L2(ONE64[3]), SPPARK_L2(ONE64[4]), SPPARK_L2(ONE64[5]) };
+};
+// BLS12-377 scalar field, ff/bls12-377.hpp:35-51
+struct bls12_377_fr_p {
+    static constexpr int N = 8, N64 = 4, NBITS = 253;
+    // NTT: group_gen = 22, roots[k] = 22^((r-1)/2^k), S = 47 (ntt/parameters/bls12_377.h:11-16)
+    static constexpr unsigned TWO_ADICITY = 47, GROUP_GEN = 22;
+    static constexpr uint64_t MOD64[4] = {
+        0x0a11800000000001ULL, 0x59aa76fed0000001ULL, 0x60b44d1e5c37b001ULL, 0x12ab655e9a2ca556ULL };
+    static constexpr uint64_t RR64[4] = {
+        0x25d577bab861857bULL, 0xcc2c27b58860591fULL, 0xa7cc008fe5dc8593ULL, 0x011fdae7eff1c939ULL };
+    static constexpr uint64_t ONE64[4] = {
+        0x7d1c7ffffffffff3ULL, 0x7257f50f6ffffff2ULL, 0x16d81575512c0feeULL, 0x0d4bda322bbb9a9dULL };
+    static constexpr uint64_t M0_64 = 0x0a117fffffffffffULL;
+    static constexpr uint32_t M0 = 0xffffffffu;
+    static constexpr uint32_t MOD[8] = { SPPARK_L2(MOD64[0]), SPPARK_L2(MOD64[1]), SPPARK_L2(MOD64[2]), SPPARK_L2(MOD64[3]) };
+    static constexpr uint32_t RR[8] = { SPPARK_L2(RR64[0]), SPPARK_L2(RR64[1]), SPPARK_L2(RR64[2]), SPPARK_L2(RR64[3]) };
+    static constexpr uint32_t ONE[8] = { SPPARK_L2(ONE64[0]), SPPARK_L2(ONE64[1]), SPPARK_L2(ONE64[2]), SPPARK_L2(ONE64[3]) };
+};
+
 // G1 curve descriptions: y^2 = x^3 + b, generator in Montgomery form.
 // The reference stores no generator (its tests take points from arkworks);
 // these are the standard generators, used only by the synthetic-input
@@ -117,6 +153,15 @@ struct alt_bn128_g1_p {
         0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL };
     static constexpr uint64_t GY64[4] = {       // 2 * R
         0xa6ba871b8b1e1b3aULL, 0x14f1d651eb8e167bULL, 0xccdd46def0f28c58ULL, 0x1c14ef83340fbe5eULL };
+};
+
+// y^2 = x^3 + 1; the standard generator (arkworks ark-bls12-377 G1_GENERATOR_X/Y), Montgomery form
+struct bls12_377_g1_p {
+    typedef bls12_377_fp_p fp; typedef bls12_377_fr_p fr;
+    static constexpr uint64_t GX64[6] = {
+        0x260f33b9772451f4ULL, 0xc54dd773169d5658ULL, 0x5c1551c469a510ddULL, 0x761662e4425e1698ULL, 0xc97d78cc6f065272ULL, 0x00a41206b361fd4dULL };
+    static constexpr uint64_t GY64[6] = {
+        0x8193961fb8cb81f3ULL, 0x00638d4c5f44adb8ULL, 0xfafaf3dad4daf54aULL, 0xc27849e2d655cd18ULL, 0x2ec3ddb401d52814ULL, 0x007da93326303c71ULL };
 };
 
 } // namespace sppark_amd

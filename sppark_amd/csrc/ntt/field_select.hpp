@@ -15,6 +15,8 @@ typedef bb31_dev ntt_fr_t;
 typedef fr256_dev<bls12_381_fr_p> ntt_fr_t;
 #elif defined(FEATURE_BN254)           // ntt_api.cu:15-16 -> ff/alt_bn128.hpp fr_t
 typedef fr256_dev<alt_bn128_fr_p> ntt_fr_t;
+#elif defined(FEATURE_BLS12_377)       // ntt_api.cu:7-8 -> ff/bls12-377.hpp fr_t (2-adicity 47)
+typedef fr256_dev<bls12_377_fr_p> ntt_fr_t;
 #else
 # error "no FEATURE"
 #endif

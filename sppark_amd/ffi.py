@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
-CURVES = ("bls12_381", "bn254")
+CURVES = ("bls12_381", "bn254", "bls12_377")
 NTT_FIELDS = ("gl64", "bb31", "gl64_plonky2", "bb31_canonical")      # the last two: root-convention variants
 
 

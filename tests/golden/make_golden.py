@@ -87,7 +87,7 @@ def edge_cases(curve, cname, g2):
 def make_msm():
     assert O.ref_available(), "oracle/_ref not built (needs /root/reference)"
     cases = []
-    for curve, cname in ((O.BLS12_381, "bls12_381"), (O.BN254, "bn254")):
+    for curve, cname in ((O.BLS12_381, "bls12_381"), (O.BN254, "bn254"), (O.BLS12_377, "bls12_377")):
         for n, flagged in ((1, False), (2, False), (4, True), (31, False), (32, True), (33, False),
                            (1000, True), (1024, False), (65536 if curve == O.BLS12_381 else 4096, False)):
             seed = 0x5eed5eed0001 + n
@@ -167,9 +167,10 @@ def g2_wire(P, p, base):
 def make_msm_g2():
     assert O.ref_available(), "oracle/_ref not built (needs /root/reference)"
     cases = []
-    for curve, cname, base in ((O.BLS12_381_G2, "bls12_381", 48), (O.BN254_G2, "bn254", 32)):
+    for curve, cname, base in ((O.BLS12_381_G2, "bls12_381", 48), (O.BN254_G2, "bn254", 32), (O.BLS12_377_G2, "bls12_377", 48)):
         p = O.FP_MODULUS[curve]
-        assert (O.g1_generator(curve) == g2_wire(G2_GEN[cname], p, base)).all()
+        if cname in G2_GEN:
+            assert (O.g1_generator(curve) == g2_wire(G2_GEN[cname], p, base)).all()
         for n, flagged in ((1, True), (2, False), (31, True), (33, True), (1000, True), (4096, False)):
             seed = 0x5eed5eed0101 + n
             pts, sc = recipe.msm_inputs(curve, n, seed, ndistinct=64, flagged=flagged)
@@ -185,9 +186,12 @@ def make_msm_g2():
             cases.append(case)
         cases += edge_cases(curve, cname, True)
         # KAT by the independent Python group law: sum_{i=1..4} i*(i*G2) = 30*G2
-        pts = np.stack([g2_wire(g2_mul(G2_GEN[cname], i, p), p, base) for i in range(1, 5)])
+        F2 = pygroup.Fp2(p, pygroup.FP2_NR[cname])
+        gen = pygroup.decode_points(cname, True, O.g1_generator(curve).tobytes(), 4 * base, False)[0]
+        assert pygroup.on_curve(F2, gen, pygroup._b_g2(cname))
+        pts = np.stack([np.frombuffer(pygroup.encode_affine(cname, True, pygroup.ec_mul(F2, gen, i)), dtype=np.uint8) for i in range(1, 5)])
         sc = np.stack([np.frombuffer(int(i).to_bytes(32, "little"), dtype=np.uint8) for i in range(1, 5)])
-        e = g2_wire(g2_mul(G2_GEN[cname], 30, p), p, base)
+        e = np.frombuffer(pygroup.encode_affine(cname, True, pygroup.ec_mul(F2, gen, 30)), dtype=np.uint8)
         assert (O.ref_msm_affine(curve, pts, sc, nthreads=0) == e).all()
         cases.append({"curve": cname, "n": 4, "kat": "30*G2 (Python big-int group law)", "points": hexs(pts),
                       "scalars": hexs(sc), "flagged": False, "expect_affine": hexs(e)})
@@ -248,7 +252,7 @@ def make_ntt():
                                       "type": typ, "input": hexs(x), "expect": hexs(out)})
     # 256-bit scalar fields (wire format: Montgomery, R = 2^256); roots g^((r-1)/2^S), g = 7 / 5
     R256 = 1 << 256
-    for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28)):
+    for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28), ("bls12_377", O.BLS12_377, 22, 47)):
         p = O.FR_MODULUS[curve]
         rinv = pow(R256, p - 2, p)
         top = pow(gen, (p - 1) >> S, p)
@@ -298,7 +302,7 @@ def make_lde():
         cases.append({"field": "bb31", "lg": lg, "lg_blowup": lgb, "input": hexs(x),
                       "expect": hexs(np.array([v * R % p for v in y], dtype=np.uint32)),
                       "aux": hexs(np.array([v * R % p for v in c], dtype=np.uint32))})
-        for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28)):
+        for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28), ("bls12_377", O.BLS12_377, 22, 47)):
             p = O.FR_MODULUS[curve]
             rinv = pow(R256, p - 2, p)
             x = recipe.ntt_input(field, lg, 0x5eed5eed0005 + lg)
@@ -321,6 +325,7 @@ def make_poly():
         "bb31": (O.BB31_P, R32, np.uint32, 4),
         "bls12_381": (O.FR_MODULUS[O.BLS12_381], R256, np.uint64, 32),
         "bn254": (O.FR_MODULUS[O.BN254], R256, np.uint64, 32),
+        "bls12_377": (O.FR_MODULUS[O.BLS12_377], R256, np.uint64, 32),
     }
     cases = []
     rng = np.random.default_rng(0x901f)

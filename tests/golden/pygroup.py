@@ -12,27 +12,31 @@ with the reference build) and by tests/test_oracle.py.
 FP = {
     "bls12_381": int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16),
     "bn254": int("30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47", 16),
+    "bls12_377": int("01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001", 16),
 }
-FP_BYTES = {"bls12_381": 48, "bn254": 32}
-B_G1 = {"bls12_381": 4, "bn254": 3}                     # y^2 = x^3 + b
-# twists: y^2 = x^3 + b', b' = 4(1+u) (BLS12-381, M-type), 3/(9+u) (alt_bn128, D-type); Fp2 = Fp[u]/(u^2+1)
+FP_BYTES = {"bls12_381": 48, "bn254": 32, "bls12_377": 48}
+B_G1 = {"bls12_381": 4, "bn254": 3, "bls12_377": 1}     # y^2 = x^3 + b
+FP2_NR = {"bls12_381": 1, "bn254": 1, "bls12_377": 5}   # Fp2 = Fp[u]/(u^2 + NR)
+# twists: y^2 = x^3 + b', b' = 4(1+u) (BLS12-381, M-type), 3/(9+u) (alt_bn128, D-type), 1/u (BLS12-377)
 
 
 def _b_g2(curve):
     p = FP[curve]
     if curve == "bls12_381":
         return (4, 4)
+    if curve == "bls12_377":
+        return f2_inv((0, 1), p, 5)
     return f2_mul((3, 0), f2_inv((9, 1), p), p)
 
 
 # ---- Fp2 ---------------------------------------------------------------------
 def f2_add(a, b, p): return ((a[0] + b[0]) % p, (a[1] + b[1]) % p)
 def f2_sub(a, b, p): return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
-def f2_mul(a, b, p): return ((a[0] * b[0] - a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
+def f2_mul(a, b, p, nr=1): return ((a[0] * b[0] - nr * a[1] * b[1]) % p, (a[0] * b[1] + a[1] * b[0]) % p)
 
 
-def f2_inv(a, p):
-    n = pow((a[0] * a[0] + a[1] * a[1]) % p, -1, p)
+def f2_inv(a, p, nr=1):
+    n = pow((a[0] * a[0] + nr * a[1] * a[1]) % p, -1, p)
     return (a[0] * n % p, -a[1] * n % p)
 
 
@@ -47,12 +51,12 @@ class Fp:
 
 
 class Fp2:
-    """field ops on (c0, c1) tuples"""
-    def __init__(self, p): self.p = p; self.zero = (0, 0)
+    """field ops on (c0, c1) tuples; u^2 = -nr"""
+    def __init__(self, p, nr=1): self.p = p; self.nr = nr; self.zero = (0, 0)
     def add(self, a, b): return f2_add(a, b, self.p)
     def sub(self, a, b): return f2_sub(a, b, self.p)
-    def mul(self, a, b): return f2_mul(a, b, self.p)
-    def inv(self, a): return f2_inv(a, self.p)
+    def mul(self, a, b): return f2_mul(a, b, self.p, self.nr)
+    def inv(self, a): return f2_inv(a, self.p, self.nr)
     def small(self, k): return (k % self.p, 0)
 
 
@@ -121,7 +125,7 @@ def encode_affine(curve, g2, P):
 
 def msm_affine_bytes(curve, g2, points_raw, stride, flagged, scalars_raw):
     """sum_i s_i*P_i, textbook arithmetic only.  points_raw/scalars_raw: bytes."""
-    F = Fp2(FP[curve]) if g2 else Fp(FP[curve])
+    F = Fp2(FP[curve], FP2_NR[curve]) if g2 else Fp(FP[curve])
     b = _b_g2(curve) if g2 else B_G1[curve]
     pts = decode_points(curve, g2, points_raw, stride, flagged)
     acc = None

@@ -42,8 +42,8 @@ def msm_inputs(curve, n, seed, ndistinct=64, flagged=False, edge=True):
 def ntt_input(field, lg, seed):
     rng = np.random.default_rng(seed)
     n = 1 << lg
-    if field in ("bls12_381", "bn254"):                     # 256-bit scalar field: (n, 4) u64 limbs < r
-        r = O.FR_MODULUS[O.BLS12_381 if field == "bls12_381" else O.BN254]
+    if field in O.CURVE_ID:                                 # 256-bit scalar field: (n, 4) u64 limbs < r
+        r = O.FR_MODULUS[O.CURVE_ID[field]]
         vals = [int.from_bytes(rng.bytes(40), "little") % r for _ in range(n)]
         return np.array([[(v >> (64 * k)) & 0xffffffffffffffff for k in range(4)] for v in vals], dtype=np.uint64)
     if field == "gl64":

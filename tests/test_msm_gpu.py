@@ -12,7 +12,7 @@ import recipe
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-CURVES = [(0, "bls12_381"), (1, "bn254")]
+CURVES = [(0, "bls12_381"), (1, "bn254"), (4, "bls12_377")]
 
 
 def P(a):
@@ -26,8 +26,8 @@ def test_device_field_ops(oracle, libs, curve, name):
     O = oracle
     L = ffi.load_devtest(name)
     rng = np.random.default_rng(curve + 10)
-    for which, p, nb, ofield in ((0, O.FP_MODULUS[curve], O.FP_BYTES[curve], O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP),
-                                 (1, O.FR_MODULUS[curve], 32, O.FIELD_BLS_FR if curve == 0 else O.FIELD_BN_FR)):
+    for which, p, nb, ofield in ((0, O.FP_MODULUS[curve], O.FP_BYTES[curve], O.FP_FIELD_ID[curve]),
+                                 (1, O.FR_MODULUS[curve], 32, O.FR_FIELD_ID[curve])):
         n = 512
         va = [int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(n)]
         vb = [int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(n)]
@@ -57,7 +57,7 @@ def test_device_point_ops(oracle, libs, curve, name):
     y = int.from_bytes(A[1, fb:].tobytes(), "little")
     B[1] = A[1]; B[1, fb:] = np.frombuffer(((pmod - y) % pmod).to_bytes(fb, "little"), dtype=np.uint8)   # opposite
     B[2] = 0                                                 # infinity operand
-    one = O.field_op(O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP, 4, O.int_to_limbs(1, fb)).view(np.uint8)
+    one = O.field_op(O.FP_FIELD_ID[curve], 4, O.int_to_limbs(1, fb)).view(np.uint8)
 
     def to_xyzz(aff):
         x = np.zeros((aff.shape[0], 4 * fb), dtype=np.uint8)
@@ -210,7 +210,7 @@ def test_msm_golden_vectors(oracle, libs):
     import sppark_amd
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "msm_golden.json"))):
-        curve = O.BLS12_381 if c["curve"] == "bls12_381" else O.BN254
+        curve = O.CURVE_ID[c["curve"]]
         fb = O.FP_BYTES[curve]
         stride = 2 * fb + 8 if c["flagged"] else 2 * fb
         if "points" in c:
@@ -403,7 +403,7 @@ def test_go_bridge_smoke_and_gpu_ptr(libs):
 
 
 # ------------------------------------------------------------------- G2 --------
-G2 = [("bls12_381", 2), ("bn254", 3)]
+G2 = [("bls12_381", 2), ("bn254", 3), ("bls12_377", 5)]
 
 
 def test_msm_g2_golden_vectors(oracle, libs):
@@ -412,7 +412,7 @@ def test_msm_g2_golden_vectors(oracle, libs):
     import sppark_amd
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "msm_g2_golden.json"))):
-        curve = O.BLS12_381_G2 if c["curve"] == "bls12_381" else O.BN254_G2
+        curve = O.CURVE_ID_G2[c["curve"]]
         fb = O.FP_BYTES[curve]
         stride = 2 * fb + 8 if c["flagged"] else 2 * fb
         if "points" in c:

@@ -11,12 +11,12 @@ import recipe
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIELDS = ["gl64", "bb31"]
-WIDE = ["bls12_381", "bn254"]
+WIDE = ["bls12_381", "bn254", "bls12_377"]
 
 
 def _oracle_fn(O, field):
     if field in WIDE:
-        curve = O.BLS12_381 if field == "bls12_381" else O.BN254
+        curve = O.CURVE_ID[field]
         return lambda x, order, direction, typ: O.ntt_fr(curve, x, order, direction, typ)
     return O.ntt_gl64 if field == "gl64" else O.ntt_bb31
 
@@ -216,7 +216,7 @@ def test_ntt_lg0_noop_and_errors(libs):
 
 def _field_views(field):
     dt = np.uint32 if field == "bb31" else np.uint64
-    w = 4 if field in ("bls12_381", "bn254") else 1
+    w = 4 if field in WIDE else 1
     return dt, w
 
 

@@ -72,7 +72,7 @@ def test_msm_golden(oracle):
     evaluators."""
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "msm_golden.json"))):
-        curve = O.BLS12_381 if c["curve"] == "bls12_381" else O.BN254
+        curve = O.CURVE_ID[c["curve"]]
         fb = O.FP_BYTES[curve]
         stride = 2 * fb + 8 if c["flagged"] else 2 * fb
         if "points" in c:
@@ -100,10 +100,7 @@ def test_msm_golden_vs_independent_python_group_law(oracle, fname, g2):
     O = oracle
     big_done = set()
     for c in json.load(open(os.path.join(HERE, "golden", fname))):
-        if g2:
-            curve = O.BLS12_381_G2 if c["curve"] == "bls12_381" else O.BN254_G2
-        else:
-            curve = O.BLS12_381 if c["curve"] == "bls12_381" else O.BN254
+        curve = (O.CURVE_ID_G2 if g2 else O.CURVE_ID)[c["curve"]]
         fb = O.FP_BYTES[curve]
         stride = 2 * fb + 8 if c["flagged"] else 2 * fb
         if "points" in c:
@@ -146,7 +143,7 @@ def test_msm_g2_golden_and_reference_build(oracle):
     through the naive and the signed-window algorithms."""
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "msm_g2_golden.json"))):
-        curve = O.BLS12_381_G2 if c["curve"] == "bls12_381" else O.BN254_G2
+        curve = O.CURVE_ID_G2[c["curve"]]
         fb = O.FP_BYTES[curve]
         stride = 2 * fb + 8 if c["flagged"] else 2 * fb
         if "points" in c:
@@ -181,8 +178,8 @@ def test_ntt_golden(oracle):
         dt = np.uint32 if c["field"] == "bb31" else np.uint64
         x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt)
         e = np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)
-        if c["field"] in ("bls12_381", "bn254"):
-            curve = O.BLS12_381 if c["field"] == "bls12_381" else O.BN254
+        if c["field"] in O.CURVE_ID:
+            curve = O.CURVE_ID[c["field"]]
             got = O.ntt_fr(curve, x.reshape(-1, 4), c["order"], c["direction"], c["type"]).reshape(-1)
         else:
             got = (O.ntt_gl64 if c["field"] == "gl64" else O.ntt_bb31)(x, c["order"], c["direction"], c["type"])
@@ -196,7 +193,7 @@ def test_lde_golden(oracle):
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "lde_golden.json"))):
         dt = np.uint32 if c["field"] == "bb31" else np.uint64
-        w = 4 if c["field"] in ("bls12_381", "bn254") else 1
+        w = 4 if c["field"] in O.CURVE_ID else 1
         x = np.frombuffer(bytes.fromhex(c["input"]), dtype=dt).reshape(-1, w)
         got, aux = O.lde(c["field"], x, c["lg_blowup"], want_aux=True)
         assert (got.reshape(-1) == np.frombuffer(bytes.fromhex(c["expect"]), dtype=dt)).all(), c
@@ -267,7 +264,7 @@ def test_poly_golden(oracle):
     for c in json.load(open(os.path.join(HERE, "golden", "poly_golden.json"))):
         f = c["field"]
         dt = np.uint32 if f == "bb31" else np.uint64
-        w = 4 if f in ("bls12_381", "bn254") else 1
+        w = 4 if f in ("bls12_381", "bn254", "bls12_377") else 1
         arr = lambda key: np.frombuffer(bytes.fromhex(c[key]), dtype=dt).reshape(-1, w).squeeze(-1) if w == 1 else \
             np.frombuffer(bytes.fromhex(c[key]), dtype=dt).reshape(-1, w)
         coeffs, z = arr("coeffs"), arr("z")

@@ -11,14 +11,14 @@ import recipe
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIELDS = ["gl64", "bb31", "bls12_381", "bn254"]
+FIELDS = ["gl64", "bb31", "bls12_381", "bn254", "bls12_377"]
 
 
 def _arr(c, key):
     f = c["field"]
     dt = np.uint32 if f == "bb31" else np.uint64
     a = np.frombuffer(bytes.fromhex(c[key]), dtype=dt).copy()
-    return a.reshape(-1, 4) if f in ("bls12_381", "bn254") else a
+    return a.reshape(-1, 4) if f in ("bls12_381", "bn254", "bls12_377") else a
 
 
 def test_poly_golden_vectors(libs):
@@ -51,7 +51,7 @@ def test_poly_vs_oracle(oracle, libs, field):
     import torch
     from sppark_amd import poly
     O = oracle
-    wide = field in ("bls12_381", "bn254")
+    wide = field in ("bls12_381", "bn254", "bls12_377")
     tile = 1024 if wide else 2048
     lens = [1, 3, 255, 256, 257, tile - 1, tile, tile + 1, 3 * tile + 5, 256 * tile, 256 * tile + 1, 257 * tile + 77]
     lens.append((1 << 20) + 3 if wide else (1 << 22) + 3)

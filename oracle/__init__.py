@@ -18,17 +18,19 @@ _LIB = None
 BLS12_381, BN254 = 0, 1
 BLS12_381_G2, BN254_G2 = 2, 3          # same curves, group G2 (coordinates in Fp2 = c0 | c1)
 BLS12_377, BLS12_377_G2 = 4, 5
+PALLAS, VESTA = 6, 7                   # the Pasta cycle: no G2
 FIELD_BLS_FP, FIELD_BLS_FR, FIELD_BN_FP, FIELD_BN_FR = 0, 1, 2, 3
 FIELD_BLS377_FP, FIELD_BLS377_FR = 4, 5
-CURVE_ID = {"bls12_381": BLS12_381, "bn254": BN254, "bls12_377": BLS12_377}
+FIELD_PASTA_P, FIELD_PASTA_Q = 6, 7
+CURVE_ID = {"bls12_381": BLS12_381, "bn254": BN254, "bls12_377": BLS12_377, "pallas": PALLAS, "vesta": VESTA}
 CURVE_ID_G2 = {"bls12_381": BLS12_381_G2, "bn254": BN254_G2, "bls12_377": BLS12_377_G2}
-FP_FIELD_ID = {BLS12_381: FIELD_BLS_FP, BN254: FIELD_BN_FP, BLS12_377: FIELD_BLS377_FP}
-FR_FIELD_ID = {BLS12_381: FIELD_BLS_FR, BN254: FIELD_BN_FR, BLS12_377: FIELD_BLS377_FR}
+FP_FIELD_ID = {BLS12_381: FIELD_BLS_FP, BN254: FIELD_BN_FP, BLS12_377: FIELD_BLS377_FP, PALLAS: FIELD_PASTA_P, VESTA: FIELD_PASTA_Q}
+FR_FIELD_ID = {BLS12_381: FIELD_BLS_FR, BN254: FIELD_BN_FR, BLS12_377: FIELD_BLS377_FR, PALLAS: FIELD_PASTA_Q, VESTA: FIELD_PASTA_P}
 NN, NR, RN, RR = 0, 1, 2, 3
 FORWARD, INVERSE = 0, 1
 STANDARD, COSET = 0, 1
 
-FP_BYTES = {BLS12_381: 48, BN254: 32, BLS12_381_G2: 96, BN254_G2: 64, BLS12_377: 48, BLS12_377_G2: 96}      # bytes per coordinate
+FP_BYTES = {BLS12_381: 48, BN254: 32, BLS12_381_G2: 96, BN254_G2: 64, BLS12_377: 48, BLS12_377_G2: 96, PALLAS: 32, VESTA: 32}      # bytes per coordinate
 FR_MODULUS = {
     BLS12_381: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
     BN254: int("30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001", 16),
@@ -42,6 +44,8 @@ FP_MODULUS[BLS12_377] = int("01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef
 FR_MODULUS[BLS12_381_G2] = FR_MODULUS[BLS12_381]; FR_MODULUS[BN254_G2] = FR_MODULUS[BN254]
 FP_MODULUS[BLS12_381_G2] = FP_MODULUS[BLS12_381]; FP_MODULUS[BN254_G2] = FP_MODULUS[BN254]
 FR_MODULUS[BLS12_377_G2] = FR_MODULUS[BLS12_377]; FP_MODULUS[BLS12_377_G2] = FP_MODULUS[BLS12_377]
+FP_MODULUS[PALLAS] = FR_MODULUS[VESTA] = 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001
+FP_MODULUS[VESTA] = FR_MODULUS[PALLAS] = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
 GL64_P = 0xffffffff00000001
 BB31_P = 0x78000001
 
@@ -234,7 +238,7 @@ def ntt_fr(curve, a, order=NN, direction=FORWARD, type=STANDARD):
 
 
 _LDE_FIELDS = {"gl64": (0, np.uint64, 1), "bb31": (1, np.uint32, 1), "bls12_381": (2, np.uint64, 4), "bn254": (3, np.uint64, 4),
-               "bls12_377": (4, np.uint64, 4)}
+               "bls12_377": (4, np.uint64, 4), "pallas": (6, np.uint64, 4), "vesta": (7, np.uint64, 4)}
 
 
 def lde(field, x, lg_blowup, want_aux=False):

@@ -289,6 +289,29 @@ struct bls12_377_fr_params {
     static const uint64_t M0 = 0x0a117fffffffffff;
 };
 
+struct pasta_p_params {
+    static const unsigned TWO_ADICITY = 32, GEN = 5;   // the Pallas base field = the Vesta scalar field (ff/pasta.hpp: Pallas_P; roots: ntt/parameters/pallas.h)
+    static const size_t N = 4, NBITS = 255;
+    static constexpr uint64_t MOD[4] = {
+        0x992d30ed00000001, 0x224698fc094cf91b, 0x0000000000000000, 0x4000000000000000 };
+    static constexpr uint64_t RR[4] = {
+        0x8c78ecb30000000f, 0xd7d30dbd8b0de0e7, 0x7797a99bc3c95d18, 0x096d41af7b9cb714 };
+    static constexpr uint64_t ONE[4] = {
+        0x34786d38fffffffd, 0x992c350be41914ad, 0xffffffffffffffff, 0x3fffffffffffffff };
+    static const uint64_t M0 = 0x992d30ecffffffff;
+};
+struct pasta_q_params {
+    static const unsigned TWO_ADICITY = 32, GEN = 5;   // the Vesta base field = the Pallas scalar field (ff/pasta.hpp: Vesta_P; roots: ntt/parameters/vesta.h)
+    static const size_t N = 4, NBITS = 255;
+    static constexpr uint64_t MOD[4] = {
+        0x8c46eb2100000001, 0x224698fc0994a8dd, 0x0000000000000000, 0x4000000000000000 };
+    static constexpr uint64_t RR[4] = {
+        0xfc9678ff0000000f, 0x67bb433d891a16e3, 0x7fae231004ccf590, 0x096d41af7ccfdaa9 };
+    static constexpr uint64_t ONE[4] = {
+        0x5b2b3e9cfffffffd, 0x992c350be3420567, 0xffffffffffffffff, 0x3fffffffffffffff };
+    static const uint64_t M0 = 0x8c46eb20ffffffff;
+};
+
 // ---------------------------------------------------------------------------
 // Goldilocks (ff/gl64_t.cuh:39-587): canonical residues in a u64.
 // ---------------------------------------------------------------------------
@@ -427,6 +450,8 @@ typedef mont_t<bls12_377_fp_params> bls12_377_fp;
 typedef mont_t<bls12_377_fr_params> bls12_377_fr;
 template<> struct fp2_nonresidue<bls12_377_fp> { static const unsigned value = 5; };
 typedef fp2_t<bls12_377_fp> bls12_377_fp2;
+typedef mont_t<pasta_p_params> pasta_p;          // Pallas base field = Vesta scalar field
+typedef mont_t<pasta_q_params> pasta_q;          // Vesta base field = Pallas scalar field
 typedef fp2_t<bls12_381_fp> bls12_381_fp2;
 typedef fp2_t<alt_bn128_fp> alt_bn128_fp2;
 

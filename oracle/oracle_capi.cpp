@@ -171,6 +171,19 @@ struct bls12_377_g2 : curve_t<bls12_377_fp2, bls12_377_fr> {
     {   return fp2_hex<fp, bls12_377_fp>("0", "010222f6db0fd6f343bd03737460c589dc7b4f91cd5fd889129207b63c6bf8000dd39e5c1ccccccd1c9ed9999999999a");   }
 };
 
+// The Pasta cycle (ff/pasta.hpp): y^2 = x^3 + 5 over each of the two fields, generator (-1, 2);
+// Pallas over pasta_p with scalars in pasta_q, Vesta the other way round.
+struct pallas_g1 : curve_t<pasta_p, pasta_q> {
+    static affine<fp> generator()
+    {   affine<fp> g; g.X = from_hex<fp>("1"); g.X.cneg(true); g.Y = from_hex<fp>("2"); return g;   }
+    static fp b() { return from_hex<fp>("5"); }
+};
+struct vesta_g1 : curve_t<pasta_q, pasta_p> {
+    static affine<fp> generator()
+    {   affine<fp> g; g.X = from_hex<fp>("1"); g.X.cneg(true); g.Y = from_hex<fp>("2"); return g;   }
+    static fp b() { return from_hex<fp>("5"); }
+};
+
 template<class C>
 std::vector<unsigned char> plain_scalars(const unsigned char* scalars, size_t n, int mont)
 {
@@ -262,12 +275,13 @@ template<class C> void store_generator(unsigned char* out, size_t stride)
 
 } // namespace
 
-// curve: 0 BLS12-381 G1, 1 alt_bn128 G1, 2 BLS12-381 G2, 3 alt_bn128 G2, 4 BLS12-377 G1, 5 BLS12-377 G2
+// curve: 0 BLS12-381 G1, 1 alt_bn128 G1, 2 BLS12-381 G2, 3 alt_bn128 G2, 4 BLS12-377 G1, 5 BLS12-377 G2, 6 Pallas, 7 Vesta
 #define CURVE_DO(curve, FN, ...)                                                         \
     switch (curve) {                                                                     \
         case 0: FN<bls12_381_g1>(__VA_ARGS__); break; case 1: FN<alt_bn128_g1>(__VA_ARGS__); break; \
         case 2: FN<bls12_381_g2>(__VA_ARGS__); break; case 3: FN<alt_bn128_g2>(__VA_ARGS__); break; \
         case 4: FN<bls12_377_g1>(__VA_ARGS__); break; case 5: FN<bls12_377_g2>(__VA_ARGS__); break; \
+        case 6: FN<pallas_g1>(__VA_ARGS__); break; case 7: FN<vesta_g1>(__VA_ARGS__); break; \
         default: return -1;                                                              \
     }
 #define CURVE_RET(curve, FN, ...)                                                        \
@@ -275,6 +289,7 @@ template<class C> void store_generator(unsigned char* out, size_t stride)
         case 0: return FN<bls12_381_g1>(__VA_ARGS__); case 1: return FN<alt_bn128_g1>(__VA_ARGS__); \
         case 2: return FN<bls12_381_g2>(__VA_ARGS__); case 3: return FN<alt_bn128_g2>(__VA_ARGS__); \
         case 4: return FN<bls12_377_g1>(__VA_ARGS__); case 5: return FN<bls12_377_g2>(__VA_ARGS__); \
+        case 6: return FN<pallas_g1>(__VA_ARGS__); case 7: return FN<vesta_g1>(__VA_ARGS__); \
         default: return -1;                                                              \
     }
 
@@ -291,6 +306,8 @@ int oracle_field_op(int field, int op, uint64_t* out, const uint64_t* a, const u
         case 3: return field_op<alt_bn128_fr>(op, out, a, b);
         case 4: return field_op<bls12_377_fp>(op, out, a, b);
         case 5: return field_op<bls12_377_fr>(op, out, a, b);
+        case 6: return field_op<pasta_p>(op, out, a, b);
+        case 7: return field_op<pasta_q>(op, out, a, b);
     }
     return -1;
 }
@@ -345,18 +362,24 @@ void oracle_ntt_fr(int field, uint64_t* inout, unsigned lg, int order, int direc
 {
     if (field == 0)      ntt(reinterpret_cast<bls12_381_fr*>(inout), lg, order, direction, type);
     else if (field == 4) ntt(reinterpret_cast<bls12_377_fr*>(inout), lg, order, direction, type);
+    else if (field == 6) ntt(reinterpret_cast<pasta_q*>(inout), lg, order, direction, type);       // Pallas: Fr = pasta_q
+    else if (field == 7) ntt(reinterpret_cast<pasta_p*>(inout), lg, order, direction, type);       // Vesta:  Fr = pasta_p
     else                 ntt(reinterpret_cast<alt_bn128_fr*>(inout), lg, order, direction, type);
 }
 void oracle_ntt_naive_fr(int field, uint64_t* out, const uint64_t* in, unsigned lg, int inv)
 {
     if (field == 0)      ntt_naive(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg, inv != 0);
     else if (field == 4) ntt_naive(reinterpret_cast<bls12_377_fr*>(out), reinterpret_cast<const bls12_377_fr*>(in), lg, inv != 0);
+    else if (field == 6) ntt_naive(reinterpret_cast<pasta_q*>(out), reinterpret_cast<const pasta_q*>(in), lg, inv != 0);
+    else if (field == 7) ntt_naive(reinterpret_cast<pasta_p*>(out), reinterpret_cast<const pasta_p*>(in), lg, inv != 0);
     else                 ntt_naive(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg, inv != 0);
 }
 void oracle_fr_root(int field, uint64_t* out, unsigned lg)
 {
     if (field == 0) { auto w = root_of_unity<bls12_381_fr>(lg); memcpy(out, w.v, 32); }
     else if (field == 4) { auto w = root_of_unity<bls12_377_fr>(lg); memcpy(out, w.v, 32); }
+    else if (field == 6) { auto w = root_of_unity<pasta_q>(lg); memcpy(out, w.v, 32); }
+    else if (field == 7) { auto w = root_of_unity<pasta_p>(lg); memcpy(out, w.v, 32); }
 
     else            { auto w = root_of_unity<alt_bn128_fr>(lg); memcpy(out, w.v, 32); }
 }
@@ -368,6 +391,8 @@ void oracle_lde(int field, void* inout, unsigned lg_domain, unsigned lg_blowup, 
         case 1: lde(reinterpret_cast<bb31*>(inout), lg_domain, lg_blowup, reinterpret_cast<bb31*>(aux)); break;
         case 2: lde(reinterpret_cast<bls12_381_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<bls12_381_fr*>(aux)); break;
         case 4: lde(reinterpret_cast<bls12_377_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<bls12_377_fr*>(aux)); break;
+        case 6: lde(reinterpret_cast<pasta_q*>(inout), lg_domain, lg_blowup, reinterpret_cast<pasta_q*>(aux)); break;
+        case 7: lde(reinterpret_cast<pasta_p*>(inout), lg_domain, lg_blowup, reinterpret_cast<pasta_p*>(aux)); break;
         default: lde(reinterpret_cast<alt_bn128_fr*>(inout), lg_domain, lg_blowup, reinterpret_cast<alt_bn128_fr*>(aux)); break;
     }
 }
@@ -378,6 +403,8 @@ void oracle_lde_powers(int field, void* inout, unsigned lg)
         case 1: lde_powers_bitrev(reinterpret_cast<bb31*>(inout), lg); break;
         case 2: lde_powers_bitrev(reinterpret_cast<bls12_381_fr*>(inout), lg); break;
         case 4: lde_powers_bitrev(reinterpret_cast<bls12_377_fr*>(inout), lg); break;
+        case 6: lde_powers_bitrev(reinterpret_cast<pasta_q*>(inout), lg); break;
+        case 7: lde_powers_bitrev(reinterpret_cast<pasta_p*>(inout), lg); break;
         default: lde_powers_bitrev(reinterpret_cast<alt_bn128_fr*>(inout), lg); break;
     }
 }
@@ -388,6 +415,8 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
         case 1: lde_expand(reinterpret_cast<bb31*>(out), reinterpret_cast<const bb31*>(in), lg_domain, lg_blowup); break;
         case 2: lde_expand(reinterpret_cast<bls12_381_fr*>(out), reinterpret_cast<const bls12_381_fr*>(in), lg_domain, lg_blowup); break;
         case 4: lde_expand(reinterpret_cast<bls12_377_fr*>(out), reinterpret_cast<const bls12_377_fr*>(in), lg_domain, lg_blowup); break;
+        case 6: lde_expand(reinterpret_cast<pasta_q*>(out), reinterpret_cast<const pasta_q*>(in), lg_domain, lg_blowup); break;
+        case 7: lde_expand(reinterpret_cast<pasta_p*>(out), reinterpret_cast<const pasta_p*>(in), lg_domain, lg_blowup); break;
         default: lde_expand(reinterpret_cast<alt_bn128_fr*>(out), reinterpret_cast<const alt_bn128_fr*>(in), lg_domain, lg_blowup); break;
     }
 }
@@ -399,6 +428,8 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
         case 1: { typedef bb31 F; CALL; } break;                            \
         case 2: { typedef bls12_381_fr F; CALL; } break;                    \
         case 4: { typedef bls12_377_fr F; CALL; } break;                    \
+        case 6: { typedef pasta_q F; CALL; } break;                         \
+        case 7: { typedef pasta_p F; CALL; } break;                         \
         default: { typedef alt_bn128_fr F; CALL; } break;                   \
     }
 void oracle_prefix_op(int field, void* out, const void* in, size_t len, int op)

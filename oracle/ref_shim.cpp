@@ -74,6 +74,9 @@ int ref_mult_pippenger(int curve, unsigned char* out_affine, const unsigned char
         // BLS12-377 (poc/msm-cuda/cuda/pippenger_inf.cu:9-10), G1 and G2
         case 4: return ref_msm<bls12_377_fp, bls12_377_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
         case 5: return ref_msm<bls12_377_fp2, bls12_377_fr>(out_affine, points, stride, npoints, scalars, mont, nthreads);
+        // the Pasta cycle (ff/pasta.hpp:93-104)
+        case 6: return ref_msm<pasta_p, pasta_q>(out_affine, points, stride, npoints, scalars, mont, nthreads);
+        case 7: return ref_msm<pasta_q, pasta_p>(out_affine, points, stride, npoints, scalars, mont, nthreads);
     }
     return -1;
 }

@@ -27,12 +27,15 @@ MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
            "msm/k_bucket1.hip:SPPARK_G2", "msm/k_bucketN.hip:SPPARK_G2",
            "api/ntt_api.hip:SPPARK_NTT_WITH_MSM",          # compute_ntt over the curve's scalar field
            "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0"]
+MSM_G1_TUS = [t for t in MSM_TUS if "SPPARK_G2" not in t]      # curves without a G2 (Pasta)
 NTT_TUS = ["api/ntt_api.hip", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0"]
 
 TARGETS = {
     "bls12_381": ("FEATURE_BLS12_381", MSM_TUS),
     "bn254":     ("FEATURE_BN254", MSM_TUS),
     "bls12_377": ("FEATURE_BLS12_377", MSM_TUS),
+    "pallas":    ("FEATURE_PALLAS", MSM_G1_TUS),
+    "vesta":     ("FEATURE_VESTA", MSM_G1_TUS),
     "gl64":      ("FEATURE_GOLDILOCKS", NTT_TUS),
     "bb31":      ("FEATURE_BABY_BEAR", NTT_TUS),
     # the reference's compile-time root conventions (ntt/parameters/goldilocks.h:7-82, baby_bear.h:7-74)
@@ -42,10 +45,12 @@ TARGETS = {
     "bls12_381_devtest": ("FEATURE_BLS12_381", ["api/devtest_api.hip"]),
     "bn254_devtest":     ("FEATURE_BN254", ["api/devtest_api.hip"]),
     "bls12_377_devtest": ("FEATURE_BLS12_377", ["api/devtest_api.hip"]),
+    "pallas_devtest":    ("FEATURE_PALLAS", ["api/devtest_api.hip"]),
+    "vesta_devtest":     ("FEATURE_VESTA", ["api/devtest_api.hip"]),
     "gl64_devtest":      ("FEATURE_GOLDILOCKS", ["api/devtest_small_api.hip"]),
     "bb31_devtest":      ("FEATURE_BABY_BEAR", ["api/devtest_small_api.hip"]),
 }
-PRODUCT = ("bls12_381", "bn254", "bls12_377", "gl64", "bb31", "gl64_plonky2", "bb31_canonical")
+PRODUCT = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta", "gl64", "bb31", "gl64_plonky2", "bb31_canonical")
 
 
 def lib_path(name):

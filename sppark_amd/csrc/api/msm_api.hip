@@ -21,6 +21,7 @@ extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, 
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
 // ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)
+#ifndef SPPARK_NO_G2
 extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
                                                            const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
@@ -30,6 +31,7 @@ extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m
 extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
                                                        unsigned, unsigned, unsigned, unsigned);
+#endif
 }
 
 #include "../ff/fp2_host.hpp"
@@ -43,9 +45,11 @@ using namespace sppark_amd;
 typedef msm_t<msm_fp_d, mont_host<curve_p::fp>, curve_p::fr> msm_impl;
 typedef msm_impl::point_t point_t;
 typedef msm_impl::fp_h fp_h;
+#ifndef SPPARK_NO_G2                     // (the Pasta curves have no pairing and no G2)
 typedef msm_t<fp2_d, fp2_host<curve_p::fp>, curve_p::fr> msm2_impl;       // G2
 typedef msm2_impl::point_t point2_t;
 typedef msm2_impl::fp_h fp2_h;
+#endif
 
 struct sppark_msm_ctx { msm_impl impl; sppark_msm_ctx(int id, hipStream_t s) : impl(id, s) {} };
 
@@ -177,6 +181,7 @@ SPPARK_FFI RustError mult_pippenger_inf(void* out, const void* points, size_t np
 SPPARK_FFI RustError mult_pippenger(void* out, const void* points, size_t npoints, const void* scalars)
 {   return one_shot(out, points, npoints, scalars, false, 2 * sizeof(fp_d));   }
 
+#ifndef SPPARK_NO_G2
 // poc/msm-cuda/cuda/pippenger_inf.cu:41-47: the same over G2 (coordinates in Fp2)
 SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_t npoints,
                                             const void* scalars, size_t ffi_affine_sz)
@@ -191,9 +196,16 @@ SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_
     });
 }
 
+#endif
+
 // free the scratch memory kept by the idle one-shot contexts (all devices)
 SPPARK_FFI void sppark_msm_release_cached(void)
-{   ctx_pool<msm_impl>::get().release_idle(); ctx_pool<msm2_impl>::get().release_idle();   }
+{
+    ctx_pool<msm_impl>::get().release_idle();
+#ifndef SPPARK_NO_G2
+    ctx_pool<msm2_impl>::get().release_idle();
+#endif
+}
 
 // msm/batch_addition.cuh:25-132 (batch_addition / batch_diff, the bitmap variants; C++ templates in
 // the reference): out = sum of the points whose bit is set in |bitmap|; with |refmap| the points of
@@ -341,6 +353,7 @@ SPPARK_FFI void sppark_g1_to_affine(void* out_xy, const void* jacobian)
     memcpy(out_xy, xy, sizeof(xy));
 }
 
+#ifndef SPPARK_NO_G2
 // G2 twins of the host helpers
 SPPARK_FFI void sppark_g2_jacobian_sum(void* out, const void* points, size_t n)
 {
@@ -358,6 +371,8 @@ SPPARK_FFI void sppark_g2_to_affine(void* out_xy, const void* jacobian)
     p.to_affine(xy[0], xy[1]);
     memcpy(out_xy, xy, sizeof(xy));
 }
+
+#endif
 
 } // extern "C"
 

@@ -6,7 +6,7 @@ namespace sppark_amd {
 #define SPPARK_NTT_EXTERN(DIF, INV, R1, R2) \
     extern template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, false)
-#if !defined(FEATURE_BLS12_381) && !defined(FEATURE_BN254) && !defined(FEATURE_BLS12_377)
+#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, false)
 #endif
 }

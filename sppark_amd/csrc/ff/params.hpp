@@ -134,6 +134,43 @@ struct bls12_377_fr_p {
     static constexpr uint32_t ONE[8] = { SPPARK_L2(ONE64[0]), SPPARK_L2(ONE64[1]), SPPARK_L2(ONE64[2]), SPPARK_L2(ONE64[3]) };
 };
 
+// the Pallas base field = the Vesta scalar field (ff/pasta.hpp: Pallas_P; roots: ntt/parameters/pallas.h)
+struct pasta_p_p {
+    static constexpr int N = 8, N64 = 4, NBITS = 255;
+    static constexpr unsigned FP2_NR = 1;               // (no pairing, no G2: unused)
+    // NTT: group_gen = 5, roots[k] = 5^((p-1)/2^k), S = 32
+    static constexpr unsigned TWO_ADICITY = 32, GROUP_GEN = 5;
+    static constexpr uint64_t MOD64[4] = {
+        0x992d30ed00000001ULL, 0x224698fc094cf91bULL, 0x0000000000000000ULL, 0x4000000000000000ULL };
+    static constexpr uint64_t RR64[4] = {
+        0x8c78ecb30000000fULL, 0xd7d30dbd8b0de0e7ULL, 0x7797a99bc3c95d18ULL, 0x096d41af7b9cb714ULL };
+    static constexpr uint64_t ONE64[4] = {
+        0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL };
+    static constexpr uint64_t M0_64 = 0x992d30ecffffffffULL;
+    static constexpr uint32_t M0 = 0xffffffffu;
+    static constexpr uint32_t MOD[8] = { SPPARK_L2(MOD64[0]), SPPARK_L2(MOD64[1]), SPPARK_L2(MOD64[2]), SPPARK_L2(MOD64[3]) };
+    static constexpr uint32_t RR[8] = { SPPARK_L2(RR64[0]), SPPARK_L2(RR64[1]), SPPARK_L2(RR64[2]), SPPARK_L2(RR64[3]) };
+    static constexpr uint32_t ONE[8] = { SPPARK_L2(ONE64[0]), SPPARK_L2(ONE64[1]), SPPARK_L2(ONE64[2]), SPPARK_L2(ONE64[3]) };
+};
+// the Vesta base field = the Pallas scalar field (ff/pasta.hpp: Vesta_P; roots: ntt/parameters/vesta.h)
+struct pasta_q_p {
+    static constexpr int N = 8, N64 = 4, NBITS = 255;
+    static constexpr unsigned FP2_NR = 1;               // (no pairing, no G2: unused)
+    // NTT: group_gen = 5, roots[k] = 5^((p-1)/2^k), S = 32
+    static constexpr unsigned TWO_ADICITY = 32, GROUP_GEN = 5;
+    static constexpr uint64_t MOD64[4] = {
+        0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0000000000000000ULL, 0x4000000000000000ULL };
+    static constexpr uint64_t RR64[4] = {
+        0xfc9678ff0000000fULL, 0x67bb433d891a16e3ULL, 0x7fae231004ccf590ULL, 0x096d41af7ccfdaa9ULL };
+    static constexpr uint64_t ONE64[4] = {
+        0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL };
+    static constexpr uint64_t M0_64 = 0x8c46eb20ffffffffULL;
+    static constexpr uint32_t M0 = 0xffffffffu;
+    static constexpr uint32_t MOD[8] = { SPPARK_L2(MOD64[0]), SPPARK_L2(MOD64[1]), SPPARK_L2(MOD64[2]), SPPARK_L2(MOD64[3]) };
+    static constexpr uint32_t RR[8] = { SPPARK_L2(RR64[0]), SPPARK_L2(RR64[1]), SPPARK_L2(RR64[2]), SPPARK_L2(RR64[3]) };
+    static constexpr uint32_t ONE[8] = { SPPARK_L2(ONE64[0]), SPPARK_L2(ONE64[1]), SPPARK_L2(ONE64[2]), SPPARK_L2(ONE64[3]) };
+};
+
 // G1 curve descriptions: y^2 = x^3 + b, generator in Montgomery form.
 // The reference stores no generator (its tests take points from arkworks);
 // these are the standard generators, used only by the synthetic-input
@@ -162,6 +199,23 @@ struct bls12_377_g1_p {
         0x260f33b9772451f4ULL, 0xc54dd773169d5658ULL, 0x5c1551c469a510ddULL, 0x761662e4425e1698ULL, 0xc97d78cc6f065272ULL, 0x00a41206b361fd4dULL };
     static constexpr uint64_t GY64[6] = {
         0x8193961fb8cb81f3ULL, 0x00638d4c5f44adb8ULL, 0xfafaf3dad4daf54aULL, 0xc27849e2d655cd18ULL, 0x2ec3ddb401d52814ULL, 0x007da93326303c71ULL };
+};
+
+// Pallas: y^2 = x^3 + 5 over pasta_p_p, generator (-1, 2), Montgomery form
+struct pallas_g1_p {
+    typedef pasta_p_p fp; typedef pasta_q_p fr;
+    static constexpr uint64_t GX64[4] = {
+        0x64b4c3b400000004ULL, 0x891a63f02533e46eULL, 0x0000000000000000ULL, 0x0000000000000000ULL };
+    static constexpr uint64_t GY64[4] = {
+        0xcfc3a984fffffff9ULL, 0x1011d11bbee5303eULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL };
+};
+// Vesta: y^2 = x^3 + 5 over pasta_q_p, generator (-1, 2), Montgomery form
+struct vesta_g1_p {
+    typedef pasta_q_p fp; typedef pasta_p_p fr;
+    static constexpr uint64_t GX64[4] = {
+        0x311bac8400000004ULL, 0x891a63f02652a376ULL, 0x0000000000000000ULL, 0x0000000000000000ULL };
+    static constexpr uint64_t GY64[4] = {
+        0x2a0f9218fffffff9ULL, 0x1011d11bbcef61f1ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL };
 };
 
 } // namespace sppark_amd

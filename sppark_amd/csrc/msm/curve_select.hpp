@@ -14,6 +14,12 @@ typedef bls12_381_g1_p curve_p;
 typedef alt_bn128_g1_p curve_p;
 #elif defined(FEATURE_BLS12_377)         // poc/msm-cuda/cuda/pippenger_inf.cu:9-10, ff/bls12-377.hpp
 typedef bls12_377_g1_p curve_p;
+#elif defined(FEATURE_PALLAS)            // ff/pasta.hpp:93-98 (fp_t = pallas_t, fr_t = vesta_t); no pairing, no G2
+typedef pallas_g1_p curve_p;
+# define SPPARK_NO_G2 1
+#elif defined(FEATURE_VESTA)             // ff/pasta.hpp:99-104
+typedef vesta_g1_p curve_p;
+# define SPPARK_NO_G2 1
 #else
 # error "no FEATURE"
 #endif

@@ -17,6 +17,10 @@ typedef fr256_dev<bls12_381_fr_p> ntt_fr_t;
 typedef fr256_dev<alt_bn128_fr_p> ntt_fr_t;
 #elif defined(FEATURE_BLS12_377)       // ntt_api.cu:7-8 -> ff/bls12-377.hpp fr_t (2-adicity 47)
 typedef fr256_dev<bls12_377_fr_p> ntt_fr_t;
+#elif defined(FEATURE_PALLAS)          // ntt_api.cu:9-10; "Fr for Pallas curve is Vesta" (ntt/parameters.cuh:54-55)
+typedef fr256_dev<pasta_q_p> ntt_fr_t;
+#elif defined(FEATURE_VESTA)           // ntt_api.cu:11-12; "Fr for Vesta curve is Pallas" (ntt/parameters.cuh:56-57)
+typedef fr256_dev<pasta_p_p> ntt_fr_t;
 #else
 # error "no FEATURE"
 #endif

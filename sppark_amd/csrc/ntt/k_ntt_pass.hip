@@ -8,7 +8,7 @@ namespace sppark_amd {
 #define SPPARK_NTT_DEFINE(DIF, INV, R1, R2) \
     template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
-#if !defined(FEATURE_BLS12_381) && !defined(FEATURE_BN254) && !defined(FEATURE_BLS12_377)      // wide fields stop at 4 stages per pass
+#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // wide fields stop at 4 stages per pass
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
 #endif
 }

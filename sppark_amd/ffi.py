@@ -14,7 +14,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
-CURVES = ("bls12_381", "bn254", "bls12_377")
+CURVES = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta")
+NO_G2 = ("pallas", "vesta")                          # no pairing: no mult_pippenger_fp2_inf / sppark_g2_*
 NTT_FIELDS = ("gl64", "bb31", "gl64_plonky2", "bb31_canonical")      # the last two: root-convention variants
 
 
@@ -61,12 +62,13 @@ def load(name):
     if name in CURVES:
         L.mult_pippenger_inf.argtypes = [vp, vp, sz, vp, sz]
         L.mult_pippenger_inf.restype = _Error
-        L.mult_pippenger_fp2_inf.argtypes = [vp, vp, sz, vp, sz]
-        L.mult_pippenger_fp2_inf.restype = _Error
-        L.sppark_g2_jacobian_sum.argtypes = [vp, vp, sz]
-        L.sppark_g2_jacobian_sum.restype = None
-        L.sppark_g2_to_affine.argtypes = [vp, vp]
-        L.sppark_g2_to_affine.restype = None
+        if name not in NO_G2:
+            L.mult_pippenger_fp2_inf.argtypes = [vp, vp, sz, vp, sz]
+            L.mult_pippenger_fp2_inf.restype = _Error
+            L.sppark_g2_jacobian_sum.argtypes = [vp, vp, sz]
+            L.sppark_g2_jacobian_sum.restype = None
+            L.sppark_g2_to_affine.argtypes = [vp, vp]
+            L.sppark_g2_to_affine.restype = None
         L.mult_pippenger.argtypes = [vp, vp, sz, vp]
         L.mult_pippenger.restype = _Error
         L.sppark_msm_create.argtypes = [ctypes.POINTER(vp), ci, vp]

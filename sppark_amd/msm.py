@@ -9,7 +9,7 @@ import numpy as np
 
 from . import ffi
 
-FP_BYTES = {"bls12_381": 48, "bn254": 32, "bls12_377": 48}
+FP_BYTES = {"bls12_381": 48, "bn254": 32, "bls12_377": 48, "pallas": 32, "vesta": 32}
 
 
 def _nbytes(x):

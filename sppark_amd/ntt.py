@@ -24,7 +24,7 @@ class NTTType(enum.IntEnum):
 
 # one library per field (poc/ntt-cuda/build.rs features): gl64, bb31, and the scalar
 # fields of the two curves (256-bit Montgomery elements)
-_ELEM_BYTES = {"gl64": 8, "bb31": 4, "bls12_381": 32, "bn254": 32, "bls12_377": 32, "gl64_plonky2": 8, "bb31_canonical": 4}
+_ELEM_BYTES = {"gl64": 8, "bb31": 4, "bls12_381": 32, "bn254": 32, "bls12_377": 32, "pallas": 32, "vesta": 32, "gl64_plonky2": 8, "bb31_canonical": 4}
 
 
 def compute_ntt(device_id, inout, order, direction, ntt_type, field="gl64", stream=None):

@@ -87,7 +87,7 @@ def edge_cases(curve, cname, g2):
 def make_msm():
     assert O.ref_available(), "oracle/_ref not built (needs /root/reference)"
     cases = []
-    for curve, cname in ((O.BLS12_381, "bls12_381"), (O.BN254, "bn254"), (O.BLS12_377, "bls12_377")):
+    for curve, cname in ((O.BLS12_381, "bls12_381"), (O.BN254, "bn254"), (O.BLS12_377, "bls12_377"), (O.PALLAS, "pallas"), (O.VESTA, "vesta")):
         for n, flagged in ((1, False), (2, False), (4, True), (31, False), (32, True), (33, False),
                            (1000, True), (1024, False), (65536 if curve == O.BLS12_381 else 4096, False)):
             seed = 0x5eed5eed0001 + n
@@ -252,7 +252,8 @@ def make_ntt():
                                       "type": typ, "input": hexs(x), "expect": hexs(out)})
     # 256-bit scalar fields (wire format: Montgomery, R = 2^256); roots g^((r-1)/2^S), g = 7 / 5
     R256 = 1 << 256
-    for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28), ("bls12_377", O.BLS12_377, 22, 47)):
+    for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28), ("bls12_377", O.BLS12_377, 22, 47),
+                                 ("pallas", O.PALLAS, 5, 32), ("vesta", O.VESTA, 5, 32)):
         p = O.FR_MODULUS[curve]
         rinv = pow(R256, p - 2, p)
         top = pow(gen, (p - 1) >> S, p)
@@ -302,7 +303,8 @@ def make_lde():
         cases.append({"field": "bb31", "lg": lg, "lg_blowup": lgb, "input": hexs(x),
                       "expect": hexs(np.array([v * R % p for v in y], dtype=np.uint32)),
                       "aux": hexs(np.array([v * R % p for v in c], dtype=np.uint32))})
-        for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28), ("bls12_377", O.BLS12_377, 22, 47)):
+        for field, curve, gen, S in (("bls12_381", O.BLS12_381, 7, 32), ("bn254", O.BN254, 5, 28), ("bls12_377", O.BLS12_377, 22, 47),
+                                 ("pallas", O.PALLAS, 5, 32), ("vesta", O.VESTA, 5, 32)):
             p = O.FR_MODULUS[curve]
             rinv = pow(R256, p - 2, p)
             x = recipe.ntt_input(field, lg, 0x5eed5eed0005 + lg)
@@ -326,13 +328,16 @@ def make_poly():
         "bls12_381": (O.FR_MODULUS[O.BLS12_381], R256, np.uint64, 32),
         "bn254": (O.FR_MODULUS[O.BN254], R256, np.uint64, 32),
         "bls12_377": (O.FR_MODULUS[O.BLS12_377], R256, np.uint64, 32),
+        "pallas": (O.FR_MODULUS[O.PALLAS], R256, np.uint64, 32),
+        "vesta": (O.FR_MODULUS[O.VESTA], R256, np.uint64, 32),
     }
     cases = []
     rng = np.random.default_rng(0x901f)
     for field, (p, R, dt, nb) in fields.items():
         rinv = pow(R, -1, p)
         enc = lambda vals: np.frombuffer(b"".join((v * R % p).to_bytes(nb, "little") for v in vals), dtype=dt)
-        for ln in ((1, 2, 7, 64, 257, 2049) if nb <= 8 else (1, 7, 257, 1030)):     # 2049 / 1030: one element past a GPU tile
+        # 2049 / 1030: one element past a GPU tile (the long wide case for one curve only: fixture size)
+        for ln in ((1, 2, 7, 64, 257, 2049) if nb <= 8 else (1, 7, 257, 1030) if field == "bls12_381" else (1, 7, 130)):
             c = [int.from_bytes(rng.bytes(40), "little") % p for _ in range(ln)]
             if ln >= 7:
                 c[3] = 0; c[5] = p - 1; c[ln - 1] = 1

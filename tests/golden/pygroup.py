@@ -13,9 +13,11 @@ FP = {
     "bls12_381": int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16),
     "bn254": int("30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47", 16),
     "bls12_377": int("01ae3a4617c510eac63b05c06ca1493b1a22d9f300f5138f1ef3622fba094800170b5d44300000008508c00000000001", 16),
+    "pallas": 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+    "vesta": 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,
 }
-FP_BYTES = {"bls12_381": 48, "bn254": 32, "bls12_377": 48}
-B_G1 = {"bls12_381": 4, "bn254": 3, "bls12_377": 1}     # y^2 = x^3 + b
+FP_BYTES = {"bls12_381": 48, "bn254": 32, "bls12_377": 48, "pallas": 32, "vesta": 32}
+B_G1 = {"bls12_381": 4, "bn254": 3, "bls12_377": 1, "pallas": 5, "vesta": 5}     # y^2 = x^3 + b
 FP2_NR = {"bls12_381": 1, "bn254": 1, "bls12_377": 5}   # Fp2 = Fp[u]/(u^2 + NR)
 # twists: y^2 = x^3 + b', b' = 4(1+u) (BLS12-381, M-type), 3/(9+u) (alt_bn128, D-type), 1/u (BLS12-377)
 

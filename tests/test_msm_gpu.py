@@ -12,7 +12,7 @@ import recipe
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-CURVES = [(0, "bls12_381"), (1, "bn254"), (4, "bls12_377")]
+CURVES = [(0, "bls12_381"), (1, "bn254"), (4, "bls12_377"), (6, "pallas"), (7, "vesta")]
 
 
 def P(a):

@@ -11,7 +11,7 @@ import recipe
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIELDS = ["gl64", "bb31"]
-WIDE = ["bls12_381", "bn254", "bls12_377"]
+WIDE = ["bls12_381", "bn254", "bls12_377", "pallas", "vesta"]
 
 
 def _oracle_fn(O, field):

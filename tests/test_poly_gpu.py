@@ -11,14 +11,15 @@ import recipe
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIELDS = ["gl64", "bb31", "bls12_381", "bn254", "bls12_377"]
+WIDE = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta")
+FIELDS = ["gl64", "bb31"] + list(WIDE)
 
 
 def _arr(c, key):
     f = c["field"]
     dt = np.uint32 if f == "bb31" else np.uint64
     a = np.frombuffer(bytes.fromhex(c[key]), dtype=dt).copy()
-    return a.reshape(-1, 4) if f in ("bls12_381", "bn254", "bls12_377") else a
+    return a.reshape(-1, 4) if f in WIDE else a
 
 
 def test_poly_golden_vectors(libs):
@@ -51,7 +52,7 @@ def test_poly_vs_oracle(oracle, libs, field):
     import torch
     from sppark_amd import poly
     O = oracle
-    wide = field in ("bls12_381", "bn254", "bls12_377")
+    wide = field in WIDE
     tile = 1024 if wide else 2048
     lens = [1, 3, 255, 256, 257, tile - 1, tile, tile + 1, 3 * tile + 5, 256 * tile, 256 * tile + 1, 257 * tile + 77]
     lens.append((1 << 20) + 3 if wide else (1 << 22) + 3)

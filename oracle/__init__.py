@@ -238,7 +238,8 @@ def ntt_fr(curve, a, order=NN, direction=FORWARD, type=STANDARD):
 
 
 _LDE_FIELDS = {"gl64": (0, np.uint64, 1), "bb31": (1, np.uint32, 1), "bls12_381": (2, np.uint64, 4), "bn254": (3, np.uint64, 4),
-               "bls12_377": (4, np.uint64, 4), "pallas": (6, np.uint64, 4), "vesta": (7, np.uint64, 4)}
+               "bls12_377": (4, np.uint64, 4), "pallas": (6, np.uint64, 4), "vesta": (7, np.uint64, 4),
+               "m31": (8, np.uint32, 1), "bb31x4": (9, np.uint32, 4)}          # polynomial primitives only
 
 
 def lde(field, x, lg_blowup, want_aux=False):

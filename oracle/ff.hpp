@@ -384,6 +384,41 @@ struct bb31 {
     static bb31 top_root()    { return from_raw(canonical_roots() ? 0x57fab6eeu : 0x1ffffedcu); }
 };
 
+// ---------------------------------------------------------------------------
+// Mersenne31 (ff/mersenne31.hpp:13-60), p = 2^31 - 1: canonical residues, the reference's memory form
+// (mrs31_t::mem_t); and the BabyBear quartic extension F_p[x]/(x^4 - beta), beta = -11 (default) or
+// +11 (-DBABY_BEAR_CANONICAL) (bb31_4_t, ff/baby_bear.hpp:70-446): four Montgomery residues.
+// Field types only in the reference (no NTT parameters); here: operands of the polynomial primitives.
+// ---------------------------------------------------------------------------
+struct mrs31 {
+    static const uint32_t MOD = 0x7fffffffu;
+    uint32_t v;
+    mrs31() = default;
+    static mrs31 from_raw(uint32_t x) { mrs31 r; r.v = x; return r; }
+    static mrs31 one() { return from_raw(1); }
+    friend mrs31 operator+(mrs31 a, mrs31 b) { return from_raw((uint32_t)(((uint64_t)a.v + b.v) % MOD)); }
+    friend mrs31 operator-(mrs31 a, mrs31 b) { return from_raw((uint32_t)(((uint64_t)a.v + MOD - b.v) % MOD)); }
+    friend mrs31 operator*(mrs31 a, mrs31 b) { return from_raw((uint32_t)(((uint64_t)a.v * b.v) % MOD)); }
+};
+struct bb31_4 {
+    bb31 c[4];
+    static bool& canonical_beta() { static bool on = false; return on; }        // -DBABY_BEAR_CANONICAL
+    static bb31 beta() { return canonical_beta() ? bb31::from_canonical(11) : bb31::from_canonical(bb31::MOD - 11); }
+    static bb31_4 one() { bb31_4 r; r.c[0] = bb31::one(); r.c[1] = r.c[2] = r.c[3] = bb31::from_raw(0); return r; }
+    friend bb31_4 operator+(const bb31_4& a, const bb31_4& b) { bb31_4 r; for (int i = 0; i < 4; i++) r.c[i] = a.c[i] + b.c[i]; return r; }
+    friend bb31_4 operator-(const bb31_4& a, const bb31_4& b) { bb31_4 r; for (int i = 0; i < 4; i++) r.c[i] = a.c[i] - b.c[i]; return r; }
+    friend bb31_4 operator*(const bb31_4& a, const bb31_4& b)
+    {
+        bb31 t[7];
+        for (int k = 0; k < 7; k++) t[k] = bb31::from_raw(0);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) t[i + j] = t[i + j] + a.c[i] * b.c[j];
+        bb31_4 r;
+        for (int k = 0; k < 3; k++) r.c[k] = t[k] + beta() * t[k + 4];
+        r.c[3] = t[3];
+        return r;
+    }
+};
+
 template<class F> static inline F fpow(F b, uint64_t e)
 {
     F r = F::one();

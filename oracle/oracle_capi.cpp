@@ -421,7 +421,7 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
     }
 }
 
-// polynomial primitives; field: 0 gl64, 1 bb31, 2 bls12_381 fr, 3 alt_bn128 fr
+// polynomial primitives; field: 0 gl64, 1 bb31, 2 bls12_381 fr, 3 alt_bn128 fr, 4 bls12_377 fr, 6 / 7 Pasta, 8 Mersenne31, 9 bb31_4
 #define POLY_DISPATCH(field, CALL)                                          \
     switch (field) {                                                        \
         case 0: { typedef gl64 F; CALL; } break;                            \
@@ -430,6 +430,8 @@ void oracle_lde_expand(int field, void* out, const void* in, unsigned lg_domain,
         case 4: { typedef bls12_377_fr F; CALL; } break;                    \
         case 6: { typedef pasta_q F; CALL; } break;                         \
         case 7: { typedef pasta_p F; CALL; } break;                         \
+        case 8: { typedef mrs31 F; CALL; } break;                           \
+        case 9: { typedef bb31_4 F; CALL; } break;                          \
         default: { typedef alt_bn128_fr F; CALL; } break;                   \
     }
 void oracle_prefix_op(int field, void* out, const void* in, size_t len, int op)

@@ -38,6 +38,9 @@ TARGETS = {
     "vesta":     ("FEATURE_VESTA", MSM_G1_TUS),
     "gl64":      ("FEATURE_GOLDILOCKS", NTT_TUS),
     "bb31":      ("FEATURE_BABY_BEAR", NTT_TUS),
+    # field types without NTT parameters in the reference: polynomial primitives only
+    "m31":       ("FEATURE_MERSENNE31", ["api/poly_only_api.hip"]),
+    "bb31x4":    ("FEATURE_BABY_BEAR_X4", ["api/poly_only_api.hip"]),
     # the reference's compile-time root conventions (ntt/parameters/goldilocks.h:7-82, baby_bear.h:7-74)
     "gl64_plonky2":   ("FEATURE_GOLDILOCKS -DGOLDILOCKS_PLONKY2", NTT_TUS),
     "bb31_canonical": ("FEATURE_BABY_BEAR -DBABY_BEAR_CANONICAL", NTT_TUS),
@@ -50,7 +53,7 @@ TARGETS = {
     "gl64_devtest":      ("FEATURE_GOLDILOCKS", ["api/devtest_small_api.hip"]),
     "bb31_devtest":      ("FEATURE_BABY_BEAR", ["api/devtest_small_api.hip"]),
 }
-PRODUCT = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta", "gl64", "bb31", "gl64_plonky2", "bb31_canonical")
+PRODUCT = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta", "gl64", "bb31", "gl64_plonky2", "bb31_canonical", "m31", "bb31x4")
 
 
 def lib_path(name):

@@ -362,6 +362,69 @@ struct bb31_dev {
     static constexpr bool SHIFT_ROOTS = false;
 };
 
+// Mersenne31, p = 2^31 - 1 (ff/mersenne31.hpp:13-60): the reference computes on Montgomery residues
+// (R = 2^32 = 2 mod p, so to/from Montgomery is a shift by one) and stores CANONICAL residues
+// (mrs31_t::mem_t); here the canonical residue is also the register form -- a product is one
+// 31x31 multiply and two folds of 2^31 = 1.
+struct mrs31_dev {
+    static constexpr u32 MOD = 0x7fffffffu;
+    typedef u32 word_t;
+    u32 v;                                                      // [0, p)
+    SPPARK_DEVFN static mrs31_dev from_raw(u32 x) { mrs31_dev r; r.v = x; return r; }
+    SPPARK_DEVFN static mrs31_dev one() { return from_raw(1); }
+    SPPARK_DEVFN friend mrs31_dev operator+(mrs31_dev a, mrs31_dev b)
+    {   u32 s = a.v + b.v; s -= (s >= MOD) ? MOD : 0; return from_raw(s);   }
+    SPPARK_DEVFN friend mrs31_dev operator-(mrs31_dev a, mrs31_dev b)
+    {   u32 d = a.v - b.v; d += (a.v < b.v) ? MOD : 0; return from_raw(d);   }
+    SPPARK_DEVFN friend mrs31_dev operator*(mrs31_dev a, mrs31_dev b)
+    {
+        const u64 t = (u64)a.v * b.v;                           // < 2^62
+        u32 r = (u32)(t & MOD) + (u32)(t >> 31);                // < 2^32
+        r = (r & MOD) + (r >> 31);                              // <= p
+        r -= (r >= MOD) ? MOD : 0;
+        return from_raw(r);
+    }
+};
+
+// BabyBear quartic extension F_p[x]/(x^4 - beta) (bb31_4_t, ff/baby_bear.hpp:70-446): four Montgomery
+// residues c0 | c1 | c2 | c3, the reference's memory image.  beta = -11 by default (x^4 + 11, as RISC Zero),
+// +11 with -DBABY_BEAR_CANONICAL (ff/baby_bear.hpp:75-79).
+struct alignas(16) bb31_4_dev {
+#ifdef BABY_BEAR_CANONICAL
+    static constexpr u32 BETA = 0x37ffffe9u;                    // (11 << 32) % p
+#else
+    static constexpr u32 BETA = 0x40000018u;                    // (-11 << 32) % p
+#endif
+    bb31_dev c[4];
+    SPPARK_DEVFN static bb31_4_dev one()
+    {   bb31_4_dev r; r.c[0] = bb31_dev::one(); r.c[1] = r.c[2] = r.c[3] = bb31_dev::from_raw(0); return r;   }
+    SPPARK_DEVFN friend bb31_4_dev operator+(const bb31_4_dev& a, const bb31_4_dev& b)
+    {   bb31_4_dev r; for (int i = 0; i < 4; i++) r.c[i] = a.c[i] + b.c[i]; return r;   }
+    SPPARK_DEVFN friend bb31_4_dev operator-(const bb31_4_dev& a, const bb31_4_dev& b)
+    {   bb31_4_dev r; for (int i = 0; i < 4; i++) r.c[i] = a.c[i] - b.c[i]; return r;   }
+    // schoolbook: the degree-4..6 terms fold back with x^4 = beta
+    SPPARK_DEVFN friend bb31_4_dev operator*(const bb31_4_dev& a, const bb31_4_dev& b)
+    {
+        const bb31_dev beta = bb31_dev::from_raw(BETA);
+        bb31_dev lo[4], hi[3];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo[k] = a.c[0] * b.c[k];
+            #pragma unroll
+            for (int i = 1; i <= k; i++) lo[k] = lo[k] + a.c[i] * b.c[k - i];
+        }
+        #pragma unroll
+        for (int k = 4; k < 7; k++) {
+            hi[k - 4] = a.c[k - 3] * b.c[3];
+            #pragma unroll
+            for (int i = k - 2; i < 4; i++) hi[k - 4] = hi[k - 4] + a.c[i] * b.c[k - i];
+        }
+        bb31_4_dev r;
+        r.c[0] = lo[0] + beta * hi[0]; r.c[1] = lo[1] + beta * hi[1]; r.c[2] = lo[2] + beta * hi[2]; r.c[3] = lo[3];
+        return r;
+    }
+};
+
 template<class F> SPPARK_DEVFN F field_pow(F b, u64 e)
 {
     F r = F::one();

@@ -21,6 +21,10 @@ typedef fr256_dev<bls12_377_fr_p> ntt_fr_t;
 typedef fr256_dev<pasta_q_p> ntt_fr_t;
 #elif defined(FEATURE_VESTA)           // ntt_api.cu:11-12; "Fr for Vesta curve is Pallas" (ntt/parameters.cuh:56-57)
 typedef fr256_dev<pasta_p_p> ntt_fr_t;
+#elif defined(FEATURE_MERSENNE31)      // ff/mersenne31.hpp: a field type only (no NTT parameters): polynomial primitives
+typedef mrs31_dev ntt_fr_t;
+#elif defined(FEATURE_BABY_BEAR_X4)    // ff/baby_bear.hpp:70-446 bb31_4_t: likewise
+typedef bb31_4_dev ntt_fr_t;
 #else
 # error "no FEATURE"
 #endif

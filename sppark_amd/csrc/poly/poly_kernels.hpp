@@ -31,7 +31,7 @@
 namespace sppark_amd {
 
 static constexpr unsigned POLY_NT = 256;                                       // lanes per tile
-template<class F> struct poly_geom { static constexpr unsigned E = sizeof(F) <= 8 ? 8 : 4; };     // elements per lane
+template<class F> struct poly_geom { static constexpr unsigned E = sizeof(F) <= 8 ? 8 : 4; };      // (16-byte bb31_4: 4)     // elements per lane
 
 template<class F> SPPARK_DEVFN F poly_zero() { F r; memset(&r, 0, sizeof(r)); return r; }         // all three wire formats: zero bits
 

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 CURVES = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta")
+POLY_ONLY = ("m31", "bb31x4")                        # field types without NTT parameters: polynomial primitives only
 NO_G2 = ("pallas", "vesta")                          # no pairing: no mult_pippenger_fp2_inf / sppark_g2_*
 NTT_FIELDS = ("gl64", "bb31", "gl64_plonky2", "bb31_canonical")      # the last two: root-convention variants
 
@@ -130,6 +131,8 @@ def load(name):
         L.sppark_lde_powers.restype = _Error
         L.sppark_lde_expand.argtypes = [sz, vp, vp, u32, u32, vp]
         L.sppark_lde_expand.restype = _Error
+
+    if name in NTT_FIELDS or name in CURVES or name in POLY_ONLY:
         L.sppark_prefix_op.argtypes = [sz, vp, vp, sz, ci, vp]
         L.sppark_prefix_op.restype = _Error
         L.sppark_poly_evaluate.argtypes = [sz, vp, vp, sz, vp, sz, vp]

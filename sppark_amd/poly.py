@@ -6,7 +6,7 @@ format of the chosen library (gl64: canonical u64; bb31: Montgomery u32; bls12_3
 the curve's scalar field, 4 x u64 Montgomery)."""
 from . import ffi
 
-_ELEM_BYTES = {"gl64": 8, "bb31": 4, "bls12_381": 32, "bn254": 32, "bls12_377": 32, "pallas": 32, "vesta": 32, "gl64_plonky2": 8, "bb31_canonical": 4}
+_ELEM_BYTES = {"gl64": 8, "bb31": 4, "bls12_381": 32, "bn254": 32, "bls12_377": 32, "pallas": 32, "vesta": 32, "m31": 4, "bb31x4": 16, "gl64_plonky2": 8, "bb31_canonical": 4}
 ADD, MULTIPLY = 0, 1
 
 

@@ -364,6 +364,63 @@ def make_poly():
                 b[k] = (b[k] + z * b[k + 1]) % p
             cases.append({"field": field, "len": 300, "coeffs": hexs(enc(c)), "z": hexs(enc([z])), "div": hexs(enc(b)),
                           "div_rotate": hexs(enc(b[1:] + b[:1]))})
+    # Mersenne31 (canonical u32) and the BabyBear quartic extension F_p[x]/(x^4 + 11) (4 Montgomery u32):
+    # field types without NTT parameters in the reference; element arithmetic from the definitions
+    M31 = (1 << 31) - 1
+    BB = O.BB31_P
+
+    class Ext4:                                             # tuples of 4 canonical ints, x^4 = -11
+        zero = (0, 0, 0, 0); one = (1, 0, 0, 0)
+        @staticmethod
+        def add(a, b): return tuple((x + y) % BB for x, y in zip(a, b))
+        @staticmethod
+        def mul(a, b):
+            t = [0] * 7
+            for i in range(4):
+                for j in range(4):
+                    t[i + j] += a[i] * b[j]
+            return tuple((t[k] + (-11) * (t[k + 4] if k < 3 else 0)) % BB for k in range(4))
+        @staticmethod
+        def rand(): return tuple(int.from_bytes(rng.bytes(8), "little") % BB for _ in range(4))
+        @staticmethod
+        def enc(vals): return np.array([[c * R32 % BB for c in v] for v in vals], dtype=np.uint32).reshape(-1)
+
+    class Prime31:
+        zero = 0; one = 1
+        @staticmethod
+        def add(a, b): return (a + b) % M31
+        @staticmethod
+        def mul(a, b): return a * b % M31
+        @staticmethod
+        def rand(): return int.from_bytes(rng.bytes(8), "little") % M31
+        @staticmethod
+        def enc(vals): return np.array(vals, dtype=np.uint32)
+
+    for field, K in (("m31", Prime31), ("bb31x4", Ext4)):
+        for ln in ((1, 7, 257, 2049) if field == "m31" else (1, 7, 257, 1030)):     # one element past a GPU tile
+            c = [K.rand() for _ in range(ln)]
+            if ln >= 7:
+                c[3] = K.zero; c[ln - 1] = K.one
+            z = K.rand()
+            xs = [K.zero, K.one, z, K.mul(z, z)]
+            add, mul, ra, rm = [], [], K.zero, K.one
+            for v in c:
+                ra = K.add(ra, v); rm = K.mul(rm, v)
+                add.append(ra); mul.append(rm)
+
+            def horner(x):
+                acc = K.zero
+                for v in reversed(c):
+                    acc = K.add(v, K.mul(x, acc))
+                return acc
+            ev = [horner(x) for x in xs]
+            b = c[:]
+            for k in range(ln - 2, -1, -1):
+                b[k] = K.add(b[k], K.mul(z, b[k + 1]))
+            assert b[0] == horner(z)
+            cases.append({"field": field, "len": ln, "coeffs": hexs(K.enc(c)), "z": hexs(K.enc([z])), "xs": hexs(K.enc(xs)),
+                          "prefix_add": hexs(K.enc(add)), "prefix_mul": hexs(K.enc(mul)), "evaluate": hexs(K.enc(ev)),
+                          "div": hexs(K.enc(b)), "div_rotate": hexs(K.enc(b[1:] + b[:1]))})
     json.dump(cases, open(os.path.join(HERE, "poly_golden.json"), "w"), indent=0)
     print("poly cases:", len(cases))
 

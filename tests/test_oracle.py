@@ -263,8 +263,8 @@ def test_poly_golden(oracle):
     O = oracle
     for c in json.load(open(os.path.join(HERE, "golden", "poly_golden.json"))):
         f = c["field"]
-        dt = np.uint32 if f == "bb31" else np.uint64
-        w = 4 if f in O.CURVE_ID else 1
+        dt = np.uint32 if f in ("bb31", "m31", "bb31x4") else np.uint64
+        w = 4 if (f in O.CURVE_ID or f == "bb31x4") else 1
         arr = lambda key: np.frombuffer(bytes.fromhex(c[key]), dtype=dt).reshape(-1, w).squeeze(-1) if w == 1 else \
             np.frombuffer(bytes.fromhex(c[key]), dtype=dt).reshape(-1, w)
         coeffs, z = arr("coeffs"), arr("z")

@@ -17,9 +17,9 @@ FIELDS = ["gl64", "bb31"] + list(WIDE)
 
 def _arr(c, key):
     f = c["field"]
-    dt = np.uint32 if f == "bb31" else np.uint64
+    dt = np.uint32 if f in ("bb31", "m31", "bb31x4") else np.uint64
     a = np.frombuffer(bytes.fromhex(c[key]), dtype=dt).copy()
-    return a.reshape(-1, 4) if f in WIDE else a
+    return a.reshape(-1, 4) if (f in WIDE or f == "bb31x4") else a
 
 
 def test_poly_golden_vectors(libs):
@@ -46,22 +46,32 @@ def test_poly_golden_vectors(libs):
             assert (ret == _arr(c, "evaluate")).all(), (f, c["len"])
 
 
-@pytest.mark.parametrize("field", FIELDS)
+def _pool(field, lg):
+    """2^lg random field elements in the wire format of |field|"""
+    if field == "m31":
+        return (np.random.default_rng(3).integers(0, (1 << 31) - 1, size=1 << lg, dtype=np.uint64)).astype(np.uint32)
+    if field == "bb31x4":
+        return recipe.ntt_input("bb31", lg + 2, 98).reshape(-1, 4)
+    if field in WIDE:                                           # vectorised: values < 2^252 < r
+        rng = np.random.default_rng(5)
+        pool = rng.integers(0, 1 << 63, size=(1 << lg, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(1 << lg, 4), dtype=np.uint64)
+        pool[:, 3] &= np.uint64(0x0fffffffffffffff)
+        return pool
+    return recipe.ntt_input(field, lg, 99)
+
+
+@pytest.mark.parametrize("field", FIELDS + ["m31", "bb31x4"])
 def test_poly_vs_oracle(oracle, libs, field):
     """lengths around lane / tile / spine edges and a large one, host and device buffers"""
     import torch
     from sppark_amd import poly
     O = oracle
-    wide = field in WIDE
+    wide = field in WIDE or field == "bb31x4"
     tile = 1024 if wide else 2048
     lens = [1, 3, 255, 256, 257, tile - 1, tile, tile + 1, 3 * tile + 5, 256 * tile, 256 * tile + 1, 257 * tile + 77]
     lens.append((1 << 20) + 3 if wide else (1 << 22) + 3)
     lg = max(lens).bit_length()
-    pool = recipe.ntt_input(field, lg, 99) if not wide else None
-    if wide:                                                    # vectorised: values < 2^252 < r
-        rng = np.random.default_rng(5)
-        pool = rng.integers(0, 1 << 63, size=(1 << lg, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(1 << lg, 4), dtype=np.uint64)
-        pool[:, 3] &= np.uint64(0x0fffffffffffffff)
+    pool = _pool(field, lg)
     z = pool[7:8].copy()
     xs = pool[100:106].copy()
     for n in lens:
@@ -80,7 +90,7 @@ def test_poly_vs_oracle(oracle, libs, field):
     # device-resident buffers on torch's stream
     n = lens[-1]
     c = pool[:n].copy()
-    view = np.int32 if field == "bb31" else np.int64
+    view = np.int32 if field in ("bb31", "m31", "bb31x4") else np.int64
     d = torch.from_numpy(c.view(view)).cuda()
     s = torch.cuda.current_stream().cuda_stream
     poly.prefix_op(d, d, poly.ADD, field=field, stream=s)

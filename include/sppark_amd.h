@@ -10,8 +10,13 @@
  *   libsppark_bn254.so      mult_pippenger_inf, mult_pippenger          (alt_bn128 G1)
  *                           mult_pippenger_fp2_inf                      (alt_bn128 G2)
  *                           compute_ntt                                 (alt_bn128 Fr, 2-adicity 28)
+ *   libsppark_bls12_377.so  the same four entry points over BLS12-377   (G1, G2 with u^2 = -5, Fr: 2-adicity 47)
+ *   libsppark_pallas.so     mult_pippenger_inf, mult_pippenger, compute_ntt over the scalar field (Pasta; no G2)
+ *   libsppark_vesta.so      likewise
  *   libsppark_gl64.so       compute_ntt                                 (Goldilocks)
  *   libsppark_bb31.so       compute_ntt                                 (BabyBear)
+ *   libsppark_gl64_plonky2.so / libsppark_bb31_canonical.so   the -DGOLDILOCKS_PLONKY2 / -DBABY_BEAR_CANONICAL root conventions
+ *   libsppark_m31.so / libsppark_bb31x4.so   section 3 only (Mersenne31, BabyBear quartic extension)
  *
  * plus, in every library, the four symbols of util/all_gpus.cpp:65-86.
  * Section 1 below declares exactly what the reference's Rust/Go callers bind;

@@ -30,7 +30,7 @@ typedef mont_dev<curve_p::fr> fr_d;
 // class (ff/montx_dev.hpp): its mixed addition runs 1.30x faster than the 32-bit-limb one on
 // MI355X (profiles/r01_montx_vs_mont32.log).  alt_bn128's 254 bits fill eight 32-bit limbs
 // exactly, where the reduced radix gains nothing, so it keeps mont_dev.
-#if (defined(FEATURE_BLS12_381) || defined(FEATURE_BLS12_377)) && !defined(SPPARK_FP32LIMB)    // 377 bits: 14 limbs of 28 as well
+#if !defined(SPPARK_FP32LIMB)    // 381 / 377 bits: 14 limbs of 28; 254 / 255 bits: 10 limbs
 typedef montx_dev<curve_p::fp, 28> msm_fp_d;
 #else
 typedef fp_d msm_fp_d;

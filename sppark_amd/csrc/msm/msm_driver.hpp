@@ -436,7 +436,7 @@ private:
         hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
                            digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
         HIP_OK(hipGetLastError());
-        size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + 4096;
+        size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + SORT_NT * 4 + (size_t)SORTB_STAGE * 4;
         if (ldsA > 65536) {
             HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
             HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
@@ -452,8 +452,15 @@ private:
         HIP_OK(hipGetLastError());
         hipLaunchKernelGGL(k_scan_parts, dim3(wn), dim3(1024), 0, ss, offA, tot, p.NA);
         HIP_OK(hipGetLastError());
-        hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
-                           partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+        static const bool direct_scatter = getenv("SPPARK_EXP_DIRECT_SCATTER") != nullptr;
+        if (p.NA <= SCATA_MAX_NA && p.LB < 16 && !direct_scatter) {
+            const size_t ldsS = scatterA_staged_lds(p.NA);
+            HIP_OK(hipFuncSetAttribute((const void*)k_scatterA_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
+            hipLaunchKernelGGL(k_scatterA_staged, dim3(p.nslabs, wn), dim3(SORT_NT), ldsS, ss,
+                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+        } else
+            hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
         HIP_OK(hipGetLastError());
         const unsigned big = tune.big ? tune.big : (1u << 18);
         u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
@@ -485,6 +492,8 @@ private:
         bucket_t* buckets = (bucket_t*)(blob + l.buckets);
         u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
         u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
+        // (the bucket fill and the point conversion do not depend on the sort, but running them beside
+        // it on the second stream gains nothing: 157.0 -> 157.8 ms at 2^26, tools/gpu_r2_job11.sh)
         HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
 
         for (unsigned g = 0; g < p.G; g++, gseq++) {

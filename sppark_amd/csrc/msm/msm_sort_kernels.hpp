@@ -26,7 +26,34 @@ namespace sppark_amd {
 // 3.6 ms per 2^26 MSM: k_sortB 6.7 -> 9.3 ms, k_scatterA 8.6 -> 9.6 ms, profiles/r02_msm_groups.log.)
 static constexpr unsigned SORT_NT = 1024;
 #define SORT_VGPRS 32
-static constexpr int SORTB_UNROLL = 4;       // loads in flight per lane in k_sortB
+static constexpr int SORTB_UNROLL = 4;       // loads in flight per lane in k_sortB (partitions beyond the register path)
+// k_sortB keeps a partition of up to SORTB_PER * SORT_NT entries in REGISTERS between its counting
+// and its placement step (one read of the partition instead of two) and places the entries in an LDS
+// image of the partition's output range, which is then written out in whole lines.  Measured
+// before (rocprofv3 WRITE_SIZE, 2^26 points): 14.7 GB written for 3.2 GB of sorted entries -- the
+// 4-byte scatter into a 64 KB range reached HBM as partial lines -- and 13 GB read for 6.4 GB.
+// 18 x 1024 covers the uniform case at 2^26 (16384 +- 128 entries per partition).
+static constexpr int SORTB_PER = 18;
+static constexpr unsigned SORTB_STAGE = SORTB_PER * SORT_NT;
+
+// Exclusive prefix of |s| over the SORT_NT lanes of a work-group: wave scan with cross-lane moves,
+// 16 wave totals through LDS (two barriers; the ten-step ladder through LDS it replaces cost twenty).
+// *total = sum over all lanes.  |wsum|: 16 LDS words.
+SPPARK_DEVFN u32 block_scan_excl(u32 s, u32* wsum, u32* total)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = s;
+    #pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) { u32 v = __shfl_up(incl, dlt); if (lane >= (unsigned)dlt) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 wv = lane < 16 ? wsum[lane] : 0, before = lane < wave ? wv : 0, tot = wv;
+    #pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { before += __shfl_xor(before, m); tot += __shfl_xor(tot, m); }
+    before = __shfl(before, 0); *total = __shfl(tot, 0);
+    __syncthreads();                        // wsum may be rewritten by the next call
+    return before + incl - s;
+}
 
 // H[(w*nslabs + slab)*NA + k_hi] = count of the slab's window-w digits in partition k_hi
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
@@ -126,18 +153,113 @@ void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
     }
 }
 
+// level-A scatter through LDS (NA <= SCATA_MAX_NA partitions).  k_scatterA hands every entry to the
+// memory system as an isolated 8-byte write (rocprofv3 WRITE_SIZE at 2^26 points: 23.6 GB for 6.4 GB
+// of entries -- one 32-byte sector per entry).  Here a work-group takes its slab in tiles of
+// SCATA_PER * SORT_NT entries: tile histogram (LDS atomics), block scan, placement of the entries in
+// an LDS image of the tile GROUPED BY PARTITION, then a linear read-out in which adjacent lanes hold
+// adjacent entries of the same partition (3-4 per partition and tile at 2^12 partitions) and their
+// writes leave the wave as one request.  The running global cursor of a partition lives in a
+// register of the lane that owns its counter; per tile it publishes G[p] = cursor - tile offset, so
+// the read-out address is G[p] + position in the tile.  The digits of the next tile are loaded
+// before the current one is processed.
+static constexpr int SCATA_PER = 14;
+static constexpr unsigned SCATA_TILE = SCATA_PER * SORT_NT;
+static constexpr unsigned SCATA_MAX_NA = 4 * SORT_NT;
+static inline size_t scatterA_staged_lds(unsigned NA) { return (size_t)NA * 8 + 64 + (size_t)SCATA_TILE * 8; }
+
+__global__ __launch_bounds__(SORT_NT)
+void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits,
+                       const u32* __restrict__ H, const u32* __restrict__ offA,
+                       unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
+{
+    extern __shared__ u32 lds_sa[];
+    constexpr unsigned NT = SORT_NT;
+    u32* cnt = lds_sa;                      // tile histogram -> placement cursors
+    u32* G = cnt + NA;                      // global position of a partition's first tile entry, minus its tile offset
+    u32* wsum = G + NA;                     // per-wave totals of the block scan
+    uint2* stage = reinterpret_cast<uint2*>(wsum + 16);
+    const unsigned slab = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32* h = H + ((size_t)w * nslabs + slab) * NA;
+    const u32* o = offA + (size_t)w * (NA + 1);
+    u32 cur[4];                             // this lane owns counters 4*tid .. 4*tid+3
+    #pragma unroll
+    for (int i = 0; i < 4; i++) { unsigned b = 4 * tid + i; cur[i] = b < NA ? h[b] + o[b] : 0; if (b < NA) cnt[b] = 0; }
+
+    const unsigned lo = slab * slab_sz, hi = min(n, lo + slab_sz);
+    const u32* dig = digits + (size_t)w * n;
+    uint2* dst = partA + (size_t)w * n;
+    const u32 lomask = (1u << LB) - 1;
+    u32 d[SCATA_PER], dn[SCATA_PER];
+    #pragma unroll
+    for (int u = 0; u < SCATA_PER; u++) { unsigned j = lo + u * NT + tid; dn[u] = j < hi ? dig[j] : 0; }
+    __syncthreads();
+
+    for (unsigned t0 = lo; t0 < hi; t0 += SCATA_TILE) {
+        #pragma unroll
+        for (int u = 0; u < SCATA_PER; u++) d[u] = dn[u];
+        #pragma unroll
+        for (int u = 0; u < SCATA_PER; u++) { unsigned j = t0 + SCATA_TILE + u * NT + tid; dn[u] = j < hi ? dig[j] : 0; }
+        // A: tile histogram
+        #pragma unroll
+        for (int u = 0; u < SCATA_PER; u++) if (d[u]) atomicAdd(&cnt[((d[u] & 0x7fffffffu) - 1) >> LB], 1u);
+        __syncthreads();
+        // B: block scan over the counters, four per lane
+        u32 c[4], s = 0;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { unsigned b = 4 * tid + i; c[i] = b < NA ? cnt[b] : 0; s += c[i]; }
+        u32 incl = s;
+        #pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) { u32 v = __shfl_up(incl, dlt); if (lane >= (unsigned)dlt) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 wv = lane < 16 ? wsum[lane] : 0, before = lane < wave ? wv : 0, total = wv;
+        #pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { before += __shfl_xor(before, m); total += __shfl_xor(total, m); }
+        before = __shfl(before, 0); total = __shfl(total, 0);
+        u32 run = before + incl - s;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned b = 4 * tid + i;
+            if (b < NA) { cnt[b] = run; G[b] = cur[i] - run; }
+            cur[i] += c[i]; run += c[i];
+        }
+        __syncthreads();
+        // C: placement, grouped by partition
+        #pragma unroll
+        for (int u = 0; u < SCATA_PER; u++) {
+            if (d[u]) {
+                u32 k = (d[u] & 0x7fffffffu) - 1, p = k >> LB;
+                u32 pos = atomicAdd(&cnt[p], 1u);
+                stage[pos] = make_uint2((t0 + u * NT + tid) | (d[u] & 0x80000000u), (p << 16) | (k & lomask));
+            }
+        }
+        __syncthreads();
+        // D: read-out in tile order; counters cleared for the next tile
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { unsigned b = 4 * tid + i; if (b < NA) cnt[b] = 0; }
+        #pragma unroll
+        for (int u = 0; u < SCATA_PER; u++) {
+            unsigned e = u * NT + tid;
+            if (e < total) { uint2 v = stage[e]; dst[G[v.y >> 16] + e] = make_uint2(v.x, v.y & 0xffffu); }
+        }
+        __syncthreads();
+    }
+}
+
 // level B: block (k_hi, w) groups its partition by k_lo.
 //   off[w*(NB+1) + k_hi*2^LB + j] = first position of bucket (k_hi, j) in window w's list
 //   sorted[w*n + pos] = point index | sign<<31
-__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
+__global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(64)))
 void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __restrict__ partA,
              const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LB, unsigned big)
 {
-    extern __shared__ u32 lds[];            // 2^LB counters, then SORT_NT scan words
+    extern __shared__ u32 lds[];            // 2^LB counters, SORT_NT scan words, SORTB_STAGE staged entries
     constexpr unsigned NT = SORT_NT;
     const unsigned NL = 1u << LB;
     u32* cnt = lds;
     u32* part = lds + NL;
+    u32* stage = part + NT;
     const unsigned khi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const u32* oA = offA + (size_t)w * (NA + 1);
     const unsigned begin = oA[khi], end = oA[khi + 1];
@@ -147,14 +269,27 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
         return;
     }
 
+    const bool in_regs = end - begin <= SORTB_STAGE;        // uniform over the work-group
+    u32 rx[SORTB_PER], rk[SORTB_PER];
     for (unsigned b = tid; b < NL; b += NT) cnt[b] = 0;
     __syncthreads();
-    for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
-        u32 k[SORTB_UNROLL];
+    if (in_regs) {
         #pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; k[u] = j < end ? src[j].y : 0xffffffffu; }
+        for (int u = 0; u < SORTB_PER; u++) {
+            unsigned j = begin + tid + u * NT;
+            uint2 v = j < end ? src[j] : make_uint2(0, 0xffffffffu);
+            rx[u] = v.x; rk[u] = v.y;
+        }
         #pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
+        for (int u = 0; u < SORTB_PER; u++) if (rk[u] != 0xffffffffu) atomicAdd(&cnt[rk[u]], 1u);
+    } else {
+        for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
+            u32 k[SORTB_UNROLL];
+            #pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; k[u] = j < end ? src[j].y : 0xffffffffu; }
+            #pragma unroll
+            for (int u = 0; u < SORTB_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
+        }
     }
     __syncthreads();
 
@@ -164,15 +299,8 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     u32 sum = 0;
     #pragma unroll 1                        // (a handful of counters per lane: unrolling only costs registers)
     for (unsigned b = lo; b < hi; b++) sum += cnt[b];
-    part[tid] = sum;
-    __syncthreads();
-    for (unsigned d = 1; d < NT; d <<= 1) {
-        u32 v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    u32 run = begin + part[tid] - sum;
+    u32 all;
+    u32 run = begin + block_scan_excl(sum, part, &all);
     const size_t NB = (size_t)NA << LB;
     u32* o = off + (size_t)w * (NB + 1) + ((size_t)khi << LB);
     #pragma unroll 1
@@ -181,6 +309,14 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     __syncthreads();
 
     u32* dst = sorted + (size_t)w * n;
+    if (in_regs) {
+        #pragma unroll
+        for (int u = 0; u < SORTB_PER; u++)
+            if (rk[u] != 0xffffffffu) stage[atomicAdd(&cnt[rk[u]], 1u) - begin] = rx[u];
+        __syncthreads();
+        for (unsigned i = tid; i < end - begin; i += NT) dst[begin + i] = stage[i];
+        return;
+    }
     for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
         uint2 r[SORTB_UNROLL];
         #pragma unroll

@@ -158,12 +158,22 @@ public:
         if (!inverse && type == NTT_COSET)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
 
-        unsigned smax = S_MAX;
-        if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= S_MAX) smax = v; }   // tuning knob
-        unsigned lgc = LG_LINE, lgt = LG_TILE;
-        if (const char* e = getenv("SPPARK_NTT_LGC")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) lgc = v; }
-        if (const char* e = getenv("SPPARK_NTT_LGTILE")) { unsigned v = (unsigned)atoi(e); if (v >= 8 && v <= 14) lgt = v; }
-        if (lgt < smax + 1) lgt = smax + 1;
+        // tuning knobs (tools/gpu_ntt_sweep.py), read once per process; the LDS tile is clamped to what
+        // the element size allows (160 KB per work-group: 2^14 eight-byte elements, 2^12 32-byte ones)
+        struct knobs_t { unsigned smax, lgc, lgt; };
+        static const knobs_t knobs = [] {
+            knobs_t k{S_MAX, LG_LINE, LG_TILE};
+            if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= S_MAX) k.smax = v; }
+            if (const char* e = getenv("SPPARK_NTT_LGC")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) k.lgc = v; }
+            if (const char* e = getenv("SPPARK_NTT_LGTILE")) {
+                unsigned v = (unsigned)atoi(e), cap = 17;
+                while (((size_t)sizeof(F) << cap) > 160 * 1024) cap--;
+                if (v >= 8 && v <= cap) k.lgt = v;
+            }
+            if (k.lgt < k.smax + 1) k.lgt = k.smax + 1;
+            return k;
+        }();
+        const unsigned smax = knobs.smax, lgc = knobs.lgc, lgt = knobs.lgt;
         ntt_plan pl = make_ntt_plan(lg, lgc, lgt, smax);
         for (unsigned i = 0; i < pl.npass; i++) {
             ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];

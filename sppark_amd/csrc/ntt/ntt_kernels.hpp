@@ -276,6 +276,9 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
 }
 
 template<class F, bool DIF, bool INV, unsigned R1, unsigned R2>
+// (99 VGPRs for Goldilocks <4,4>: four waves per SIMD.  Forcing five -- 94 VGPRs, no spills, five
+// 32 KB tiles per CU -- changes nothing: 0.264 vs 0.263 ms at 2^24, tools/gpu_r2_job14.sh; the pass is
+// bound by its instruction count.)
 __global__ __launch_bounds__(512)
 void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
 {

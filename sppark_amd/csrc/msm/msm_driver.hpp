@@ -432,6 +432,8 @@ private:
         u32* off = (u32*)(blob + l.off[b]);
         uint2* partA = (uint2*)(blob + l.partA[b]);
         u32* offA = (u32*)(blob + l.offA[b]);
+        // local index of the first short window of this group (window_len: the first nbits % nwins are long)
+        const unsigned nlong = p.nbits % p.nwins, sf = nlong == 0 ? wn : (nlong > w0 ? std::min(wn, nlong - w0) : 0u);
         unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
                            digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
@@ -444,7 +446,7 @@ private:
         if (ldsB > 65536)
             HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
         hipLaunchKernelGGL(k_histA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
-                           H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+                           H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         HIP_OK(hipGetLastError());
         size_t na_total = (size_t)wn * p.NA;
         hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)((na_total + 255) / 256)), dim3(256), 0, ss,
@@ -452,29 +454,28 @@ private:
         HIP_OK(hipGetLastError());
         hipLaunchKernelGGL(k_scan_parts, dim3(wn), dim3(1024), 0, ss, offA, tot, p.NA);
         HIP_OK(hipGetLastError());
-        static const bool direct_scatter = getenv("SPPARK_EXP_DIRECT_SCATTER") != nullptr;
-        if (p.NA <= SCATA_MAX_NA && p.LB < 16 && !direct_scatter) {
+        if (p.NA <= SCATA_MAX_NA && p.LB < 16) {      // (always, with the automatic split: HB <= 12)
             const size_t ldsS = scatterA_staged_lds(p.NA);
             HIP_OK(hipFuncSetAttribute((const void*)k_scatterA_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
             hipLaunchKernelGGL(k_scatterA_staged, dim3(p.nslabs, wn), dim3(SORT_NT), ldsS, ss,
-                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         } else
             hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
-                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB);
+                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         HIP_OK(hipGetLastError());
         const unsigned big = tune.big ? tune.big : (1u << 18);
         u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
         HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
         hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
-                           sorted, off, partA, offA, p.n, p.NA, p.LB, big);
+                           sorted, off, partA, offA, p.n, p.NA, p.LB, sf, big);
         HIP_OK(hipGetLastError());
         // oversized partitions (skewed scalars); empty list and immediate return otherwise
         hipLaunchKernelGGL(k_big_find, dim3((p.NA * wn + 255) / 256), dim3(256), 0, ss,
-                           nbig, blist, off, offA, p.NA, p.LB, wn, big);
+                           nbig, blist, off, offA, p.NA, p.LB, sf, wn, big);
         size_t ldsBig = ((size_t)1 << p.LB) * 4;
-        hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB);
-        hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB);
-        hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB);
+        hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf);
+        hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB, sf);
+        hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf);
         HIP_OK(hipGetLastError());
     }
 

@@ -36,6 +36,14 @@ static constexpr int SORTB_UNROLL = 4;       // loads in flight per lane in k_so
 static constexpr int SORTB_PER = 18;
 static constexpr unsigned SORTB_STAGE = SORTB_PER * SORT_NT;
 
+// The windows of an MSM are split evenly (msm_kernels.hpp window_len): the first nbits % nwins of them
+// are one bit longer than the others.  |LB| is the k_lo width of the long windows; a short window
+// (local index >= short_from) keeps all 2^HB partitions busy with a k_lo of LB - 1 bits -- with the
+// long windows' split its digits would fill only the lower half of the partitions, at twice the size.
+// The bucket-offset rows keep the common stride (NA << LB) + 1.
+__host__ __device__ inline unsigned window_lb(unsigned LB, unsigned w, unsigned short_from)
+{   return (w >= short_from && LB) ? LB - 1 : LB;   }
+
 // Exclusive prefix of |s| over the SORT_NT lanes of a work-group: wave scan with cross-lane moves,
 // 16 wave totals through LDS (two barriers; the ten-step ladder through LDS it replaces cost twenty).
 // *total = sum over all lanes.  |wsum|: 16 LDS words.
@@ -58,10 +66,10 @@ SPPARK_DEVFN u32 block_scan_excl(u32 s, u32* wsum, u32* total)
 // H[(w*nslabs + slab)*NA + k_hi] = count of the slab's window-w digits in partition k_hi
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
 void k_histA(u32* __restrict__ H, const u32* __restrict__ digits, unsigned n,
-             unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
+             unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from)
 {
     extern __shared__ u32 lds_cnt[];
-    const unsigned slab = blockIdx.x, w = blockIdx.y;
+    const unsigned slab = blockIdx.x, w = blockIdx.y, LB = window_lb(LBL, w, short_from);
     for (unsigned b = threadIdx.x; b < NA; b += blockDim.x) lds_cnt[b] = 0;
     __syncthreads();
 
@@ -125,10 +133,10 @@ void k_scan_parts(u32* __restrict__ offA, const u32* __restrict__ tot, unsigned 
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
 void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
                 const u32* __restrict__ H, const u32* __restrict__ offA,
-                unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
+                unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from)
 {
     extern __shared__ u32 lds_cur[];
-    const unsigned slab = blockIdx.x, w = blockIdx.y;
+    const unsigned slab = blockIdx.x, w = blockIdx.y, LB = window_lb(LBL, w, short_from);
     const u32* h = H + ((size_t)w * nslabs + slab) * NA;
     const u32* o = offA + (size_t)w * (NA + 1);
     for (unsigned b = threadIdx.x; b < NA; b += blockDim.x) lds_cur[b] = h[b] + o[b];
@@ -168,10 +176,21 @@ static constexpr unsigned SCATA_TILE = SCATA_PER * SORT_NT;
 static constexpr unsigned SCATA_MAX_NA = 4 * SORT_NT;
 static inline size_t scatterA_staged_lds(unsigned NA) { return (size_t)NA * 8 + 64 + (size_t)SCATA_TILE * 8; }
 
+// Work-group barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (its fence covers global memory), which would wait for the digit prefetch of the next tile
+// and for the write-out of the previous one at every one of the five barriers of a tile.  The waves of
+// this kernel communicate through LDS alone; what they write to global memory is read by later kernels.
+SPPARK_DEVFN void lds_barrier()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 __global__ __launch_bounds__(SORT_NT)
 void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits,
                        const u32* __restrict__ H, const u32* __restrict__ offA,
-                       unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LB)
+                       unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from)
 {
     extern __shared__ u32 lds_sa[];
     constexpr unsigned NT = SORT_NT;
@@ -180,6 +199,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
     u32* wsum = G + NA;                     // per-wave totals of the block scan
     uint2* stage = reinterpret_cast<uint2*>(wsum + 16);
     const unsigned slab = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned LB = window_lb(LBL, w, short_from);
     const u32* h = H + ((size_t)w * nslabs + slab) * NA;
     const u32* o = offA + (size_t)w * (NA + 1);
     u32 cur[4];                             // this lane owns counters 4*tid .. 4*tid+3
@@ -203,7 +223,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
         // A: tile histogram
         #pragma unroll
         for (int u = 0; u < SCATA_PER; u++) if (d[u]) atomicAdd(&cnt[((d[u] & 0x7fffffffu) - 1) >> LB], 1u);
-        __syncthreads();
+        lds_barrier();
         // B: block scan over the counters, four per lane
         u32 c[4], s = 0;
         #pragma unroll
@@ -212,7 +232,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
         #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) { u32 v = __shfl_up(incl, dlt); if (lane >= (unsigned)dlt) incl += v; }
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+        lds_barrier();
         u32 wv = lane < 16 ? wsum[lane] : 0, before = lane < wave ? wv : 0, total = wv;
         #pragma unroll
         for (int m = 1; m < 16; m <<= 1) { before += __shfl_xor(before, m); total += __shfl_xor(total, m); }
@@ -224,7 +244,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
             if (b < NA) { cnt[b] = run; G[b] = cur[i] - run; }
             cur[i] += c[i]; run += c[i];
         }
-        __syncthreads();
+        lds_barrier();
         // C: placement, grouped by partition
         #pragma unroll
         for (int u = 0; u < SCATA_PER; u++) {
@@ -234,7 +254,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
                 stage[pos] = make_uint2((t0 + u * NT + tid) | (d[u] & 0x80000000u), (p << 16) | (k & lomask));
             }
         }
-        __syncthreads();
+        lds_barrier();
         // D: read-out in tile order; counters cleared for the next tile
         #pragma unroll
         for (int i = 0; i < 4; i++) { unsigned b = 4 * tid + i; if (b < NA) cnt[b] = 0; }
@@ -243,7 +263,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
             unsigned e = u * NT + tid;
             if (e < total) { uint2 v = stage[e]; dst[G[v.y >> 16] + e] = make_uint2(v.x, v.y & 0xffffu); }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -252,10 +272,12 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
 //   sorted[w*n + pos] = point index | sign<<31
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(64)))
 void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __restrict__ partA,
-             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LB, unsigned big)
+             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LBL, unsigned short_from, unsigned big)
 {
     extern __shared__ u32 lds[];            // 2^LB counters, SORT_NT scan words, SORTB_STAGE staged entries
     constexpr unsigned NT = SORT_NT;
+    const unsigned LB = window_lb(LBL, blockIdx.y, short_from);
+    const size_t NB = (size_t)NA << LBL;    // buckets per window (stride of off[]); this window uses NA << LB of them
     const unsigned NL = 1u << LB;
     u32* cnt = lds;
     u32* part = lds + NL;
@@ -265,9 +287,12 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     const unsigned begin = oA[khi], end = oA[khi + 1];
     const uint2* src = partA + (size_t)w * n;
     if (end - begin > big) {                // oversized partition: the cooperative kernels below sort it
-        if (khi == NA - 1 && tid == 0) off[(size_t)w * (((size_t)NA << LB) + 1) + ((size_t)NA << LB)] = end;
+        if (khi == NA - 1 && tid == 0) off[(size_t)w * (NB + 1) + NB] = end;
+        if (LB != LBL) for (unsigned b = tid; b < NL; b += NT) off[(size_t)w * (NB + 1) + ((size_t)(NA + khi) << LB) + b] = oA[NA];
         return;
     }
+    // a short window leaves the upper half of its bucket-offset row unused: "empty, at the end of the list"
+    if (LB != LBL) for (unsigned b = tid; b < NL; b += NT) off[(size_t)w * (NB + 1) + ((size_t)(NA + khi) << LB) + b] = oA[NA];
 
     const bool in_regs = end - begin <= SORTB_STAGE;        // uniform over the work-group
     u32 rx[SORTB_PER], rk[SORTB_PER];
@@ -301,7 +326,6 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     for (unsigned b = lo; b < hi; b++) sum += cnt[b];
     u32 all;
     u32 run = begin + block_scan_excl(sum, part, &all);
-    const size_t NB = (size_t)NA << LB;
     u32* o = off + (size_t)w * (NB + 1) + ((size_t)khi << LB);
     #pragma unroll 1
     for (unsigned b = lo; b < hi; b++) { u32 c = cnt[b]; cnt[b] = run; o[b] = run; run += c; }
@@ -345,15 +369,15 @@ static constexpr unsigned SORTB_SPLIT = 64;
 
 __global__ __launch_bounds__(256)
 void k_big_find(u32* __restrict__ nbig, u32* __restrict__ list, u32* __restrict__ off,
-                const u32* __restrict__ offA, unsigned NA, unsigned LB, unsigned nwins, unsigned big)
+                const u32* __restrict__ offA, unsigned NA, unsigned LBL, unsigned short_from, unsigned nwins, unsigned big)
 {
     const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= NA * nwins) return;
-    const unsigned w = id / NA, khi = id % NA;
+    const unsigned w = id / NA, khi = id % NA, LB = window_lb(LBL, w, short_from);
     const u32* oA = offA + (size_t)w * (NA + 1);
     if (oA[khi + 1] - oA[khi] <= big) return;
     list[atomicAdd(nbig, 1u)] = id;
-    u32* o = off + (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+    u32* o = off + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
     for (unsigned j = 0; j < (1u << LB); j++) o[j] = 0;                 // counters of the histogram step
 }
 
@@ -373,19 +397,20 @@ __device__ inline bool big_slice(const u32* nbig, const u32* list, const u32* of
 
 __global__ __launch_bounds__(1024)
 void k_big_hist(u32* __restrict__ off, const uint2* __restrict__ partA, const u32* __restrict__ offA,
-                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned n, unsigned NA, unsigned LB)
+                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned n, unsigned NA, unsigned LBL, unsigned short_from)
 {
     extern __shared__ u32 lds[];
-    const unsigned NL = 1u << LB, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
     for (unsigned item = blockIdx.x; ; item += gridDim.x) {
         unsigned w, khi, lo, hi;
         if (!big_slice(nbig, list, offA, NA, item, w, khi, lo, hi)) return;
+        const unsigned LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
         __syncthreads();
         const uint2* src = partA + (size_t)w * n;
         for (unsigned i = lo + tid; i < hi; i += 1024) atomicAdd(&lds[src[i].y], 1u);
         __syncthreads();
-        u32* o = off + (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+        u32* o = off + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
         for (unsigned j = tid; j < NL; j += 1024) if (lds[j]) atomicAdd(&o[j], lds[j]);
         __syncthreads();
     }
@@ -393,14 +418,14 @@ void k_big_hist(u32* __restrict__ off, const uint2* __restrict__ partA, const u3
 
 __global__ __launch_bounds__(1024)
 void k_big_scan(u32* __restrict__ off, u32* __restrict__ cur, const u32* __restrict__ offA,
-                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned NA, unsigned LB)
+                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned NA, unsigned LBL, unsigned short_from)
 {
     __shared__ u32 part[1024];
-    const unsigned NL = 1u << LB, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
     for (unsigned b = blockIdx.x; b < *nbig; b += gridDim.x) {
-        const unsigned w = list[b] / NA, khi = list[b] % NA;
+        const unsigned w = list[b] / NA, khi = list[b] % NA, LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         const u32 begin = offA[(size_t)w * (NA + 1) + khi];
-        const size_t base = (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+        const size_t base = (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
         const unsigned per = (NL + 1023) / 1024, lo = min(NL, tid * per), hi = min(NL, lo + per);
         u32 sum = 0;
         for (unsigned j = lo; j < hi; j++) sum += off[base + j];
@@ -421,19 +446,20 @@ void k_big_scan(u32* __restrict__ off, u32* __restrict__ cur, const u32* __restr
 __global__ __launch_bounds__(1024)
 void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2* __restrict__ partA,
                    const u32* __restrict__ offA, const u32* __restrict__ nbig, const u32* __restrict__ list,
-                   unsigned n, unsigned NA, unsigned LB)
+                   unsigned n, unsigned NA, unsigned LBL, unsigned short_from)
 {
     extern __shared__ u32 lds[];
-    const unsigned NL = 1u << LB, tid = threadIdx.x;
+    const unsigned tid = threadIdx.x;
     for (unsigned item = blockIdx.x; ; item += gridDim.x) {
         unsigned w, khi, lo, hi;
         if (!big_slice(nbig, list, offA, NA, item, w, khi, lo, hi)) return;
+        const unsigned LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
         __syncthreads();
         const uint2* src = partA + (size_t)w * n;
         for (unsigned i = lo + tid; i < hi; i += 1024) atomicAdd(&lds[src[i].y], 1u);
         __syncthreads();
-        u32* c = cur + (size_t)w * (((size_t)NA << LB) + 1) + ((size_t)khi << LB);
+        u32* c = cur + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
         for (unsigned j = tid; j < NL; j += 1024) if (lds[j]) lds[j] = atomicAdd(&c[j], lds[j]);   // reserve a range
         __syncthreads();
         u32* dst = sorted + (size_t)w * n;

@@ -45,8 +45,14 @@ NTT_BYTES_PER_ELEM = 16             # read + write one u64 per transform
 PERIOD = 2048                       # distinct points (util.rs:15 uses 2^11 too)
 # measured issue peak of the one wide integer multiplier, v_mad_u64_u32: 0.181 wave-instr/clk/SIMD
 # (profiles/r01_ubench2_instruction_rates.log) x 1024 SIMDs x 64 lanes x 2.4 GHz
-MAD_PEAK_PER_S = 0.181 * 1024 * 64 * 2.4e9
-MADS_PER_MIXED_ADD = 8 * 392 + 2 * 301      # ff/montx_dev.hpp: 14x14 + 14x14 per product, 105 + 196 per square
+# v_mad_u64_u32 issue rate, wave-instructions / clk / SIMD at the nominal 2.4 GHz, measured with
+# tools/exp/ubench_carry.hip (profiles/r02_ubench_instruction_rates.log): 0.226 with 8 waves per SIMD,
+# 0.178 with the 2 waves per SIMD that the 230 registers of k_accumulate allow
+MAD_RATE_PEAK, MAD_RATE_2WAVES = 0.226, 0.178
+MAD_PEAK_PER_S = MAD_RATE_PEAK * 1024 * 64 * 2.4e9
+# ff/montx_dev.hpp, ec/xyzzx_dev.hpp madd: 8 products (14x14) + 2 squares (105) + 9 Montgomery reductions
+# (14x14 each; Y3 is one reduced sum of two products)
+MADS_PER_MIXED_ADD = 8 * 196 + 2 * 105 + 9 * 196
 
 
 def cpu_model():
@@ -393,10 +399,13 @@ def main():
                                  "integer-multiplier bound, not HBM bound (SURVEY F11): see roofline_alu" % (acc_launches, acc_launches, acc_launches) + traffic_note},
             "roofline_alu": {"bound": "v_mad_u64_u32 issue", "achieved": mads / (a_ms * 1e-3) / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
                              "unit": "T mad/s (32x32+64 multiply-adds, lane level)", "frac": mads / (a_ms * 1e-3) / MAD_PEAK_PER_S,
-                             "note": "%d windows x points mixed additions x %d multiply-adds each (8 products + 2 squares on 14 limbs "
-                                     "of 28 bits) against the measured issue peak 0.181 wave-instr/clk/SIMD "
-                                     "(profiles/r01_ubench2_instruction_rates.log) x 1024 SIMDs x 64 lanes x 2.4 GHz"
-                                     % (nwins, MADS_PER_MIXED_ADD)},
+                             "frac_of_peak_at_kernel_occupancy": mads / (a_ms * 1e-3) / (MAD_RATE_2WAVES * 1024 * 64 * 2.4e9),
+                             "note": "%d windows x points mixed additions x %d multiply-adds each (8 products + 2 squares + 9 "
+                                     "reductions on 14 limbs of 28 bits) against the measured issue peak of the instruction, "
+                                     "%.3f wave-instr/clk/SIMD at 8 waves per SIMD x 1024 SIMDs x 64 lanes x 2.4 GHz "
+                                     "(profiles/r02_ubench_instruction_rates.log); the kernel's 230 registers allow 2 waves per "
+                                     "SIMD, where the same micro-benchmark reaches %.3f, and one in five of its instructions is "
+                                     "not a multiply-add" % (nwins, MADS_PER_MIXED_ADD, MAD_RATE_PEAK, MAD_RATE_2WAVES)},
             "phases_ms": {"before_first_accumulate": float(np.mean(sort_ms)), "accumulate": a_ms, "device_total": float(np.mean(dev_ms))},
             "cpu_baseline": cpu, "ntt": ntt, "extras": extras,
         }

@@ -28,8 +28,10 @@ typedef fp_class<curve_p::fp> fp_d;          // wire-format field: generators, t
 typedef mont_dev<curve_p::fr> fr_d;
 // coordinate field of the G1 bucket pipeline.  BLS12-381: the loosely-reduced 28-bit-limb
 // class (ff/montx_dev.hpp): its mixed addition runs 1.30x faster than the 32-bit-limb one on
-// MI355X (profiles/r01_montx_vs_mont32.log).  alt_bn128's 254 bits fill eight 32-bit limbs
-// exactly, where the reduced radix gains nothing, so it keeps mont_dev.
+// MI355X (profiles/r01_montx_vs_mont32.log).  The 254/255-bit fields (alt_bn128, Pasta) take ten
+// 28-bit limbs against eight 32-bit ones and still win: alt_bn128's accumulation 71.8 -> 66.7 ms
+// for 2^26 points (tools/gpu_r2_job11.sh), because what the 32-bit form spends on carries exceeds
+// the 56 % more multiply-adds.
 #if !defined(SPPARK_FP32LIMB)    // 381 / 377 bits: 14 limbs of 28; 254 / 255 bits: 10 limbs
 typedef montx_dev<curve_p::fp, 28> msm_fp_d;
 #else

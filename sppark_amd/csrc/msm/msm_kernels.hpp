@@ -190,6 +190,8 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     else           { acc.store(&rec_pt[rec0 + 1]); rec_key[rec0] = slot0_key; rec_key[rec0 + 1] = key; }
 }
 
+// (Fp2: 256 VGPRs + 106 AGPRs, one wave per SIMD; forcing two spills 121 registers and gains nothing:
+// 25.2 vs 25.6 ms for 2^22 G2 points)
 template<class FP, bool FLAGGED>
 __global__ __launch_bounds__(256)
 void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
@@ -334,8 +336,10 @@ SPPARK_DEVFN void bucket_level1_item(xyzz_mem<FP::N>* A, xyzz_mem<FP::N>* Wt, co
     acc.store(&A[id]); ret.store(&Wt[id]);
 }
 
+// (two waves per SIMD: the 28-bit-limb instantiation needs 263 registers unconstrained, seven more
+// than two waves leave each -- one wave per SIMD ran the bucket sums at half speed)
 template<class FP>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void k_bucket_level1(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __restrict__ Wt,
                      const xyzz_mem<FP::N>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins)
 {   bucket_level1_item<FP>(A, Wt, buckets, NB, K, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
@@ -366,7 +370,7 @@ SPPARK_DEVFN void bucket_levelN_item(xyzz_mem<FP::N>* A2, xyzz_mem<FP::N>* Wt2,
 }
 
 template<class FP>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void k_bucket_levelN(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restrict__ Wt2,
                      const xyzz_mem<FP::N>* __restrict__ A1, const xyzz_mem<FP::N>* __restrict__ Wt1,
                      unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)

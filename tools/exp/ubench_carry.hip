@@ -113,12 +113,28 @@ KERNEL64(k_mad_u64_u32_carry,     // multiply-add whose carry-out feeds an add-w
     "v_mad_u64_u32 %4, vcc, %9, %10, %4\n v_addc_co_u32 %11, vcc, 0, %11, vcc\n v_mad_u64_u32 %5, vcc, %11, %12, %5\n v_addc_co_u32 %13, vcc, 0, %13, vcc\n"
     "v_mad_u64_u32 %6, vcc, %13, %14, %6\n v_addc_co_u32 %15, vcc, 0, %15, vcc\n v_mad_u64_u32 %7, vcc, %15, %8, %7\n v_addc_co_u32 %9, vcc, 0, %9, vcc\n")
 
+KERNEL64(k_mad_two_chains,        // two dependent chains, alternating (montx_dev::mul2 / macx2)
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %10, %11, %1\n v_mad_u64_u32 %0, vcc, %12, %13, %0\n v_mad_u64_u32 %1, vcc, %14, %15, %1\n"
+    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %1, vcc, %11, %12, %1\n v_mad_u64_u32 %0, vcc, %13, %14, %0\n v_mad_u64_u32 %1, vcc, %15, %8, %1\n"
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %10, %11, %1\n v_mad_u64_u32 %0, vcc, %12, %13, %0\n v_mad_u64_u32 %1, vcc, %14, %15, %1\n"
+    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %1, vcc, %11, %12, %1\n v_mad_u64_u32 %0, vcc, %13, %14, %0\n v_mad_u64_u32 %1, vcc, %15, %8, %1\n")
+KERNEL64(k_mad_one_chain,         // one dependent chain (montx_dev::operator*)
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %0, vcc, %10, %11, %0\n v_mad_u64_u32 %0, vcc, %12, %13, %0\n v_mad_u64_u32 %0, vcc, %14, %15, %0\n"
+    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %0, vcc, %11, %12, %0\n v_mad_u64_u32 %0, vcc, %13, %14, %0\n v_mad_u64_u32 %0, vcc, %15, %8, %0\n"
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %0, vcc, %10, %11, %0\n v_mad_u64_u32 %0, vcc, %12, %13, %0\n v_mad_u64_u32 %0, vcc, %14, %15, %0\n"
+    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %0, vcc, %11, %12, %0\n v_mad_u64_u32 %0, vcc, %13, %14, %0\n v_mad_u64_u32 %0, vcc, %15, %8, %0\n")
+KERNEL64(k_mad_four_chains,
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %10, %11, %1\n v_mad_u64_u32 %2, vcc, %12, %13, %2\n v_mad_u64_u32 %3, vcc, %14, %15, %3\n"
+    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %1, vcc, %11, %12, %1\n v_mad_u64_u32 %2, vcc, %13, %14, %2\n v_mad_u64_u32 %3, vcc, %15, %8, %3\n"
+    "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %10, %11, %1\n v_mad_u64_u32 %2, vcc, %12, %13, %2\n v_mad_u64_u32 %3, vcc, %14, %15, %3\n"
+    "v_mad_u64_u32 %0, vcc, %9, %10, %0\n v_mad_u64_u32 %1, vcc, %11, %12, %1\n v_mad_u64_u32 %2, vcc, %13, %14, %2\n v_mad_u64_u32 %3, vcc, %15, %8, %3\n")
+
 typedef void (*kern_t)(u32*, u32, int);
 struct entry { const char* name; kern_t k; };
 static entry table[] = {
     {"v_add_u32", k_add_u32}, {"v_add_co + v_addc_co (vcc)", k_addco_vcc_pairs}, {"v_add_co + v_addc_co (sgpr pairs)", k_addco_sgpr_pairs},
     {"v_add_co_u32 (vcc, carry unused)", k_addco_only_vcc}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_add3_u32", k_add3_u32},
-    {"v_cmp_lt_u32 + v_cndmask_b32", k_cmp_cndmask}, {"v_mad_u64_u32", k_mad_u64_u32}, {"v_mad_u64_u32 + v_addc_co (vcc)", k_mad_u64_u32_carry}, {"v_mul_lo_u32", k_mul_lo_u32},
+    {"v_cmp_lt_u32 + v_cndmask_b32", k_cmp_cndmask}, {"v_mad_u64_u32 (8 chains)", k_mad_u64_u32}, {"v_mad_u64_u32, 1 dependent chain", k_mad_one_chain}, {"v_mad_u64_u32, 2 dependent chains", k_mad_two_chains}, {"v_mad_u64_u32, 4 dependent chains", k_mad_four_chains}, {"v_mad_u64_u32 + v_addc_co (vcc)", k_mad_u64_u32_carry}, {"v_mul_lo_u32", k_mul_lo_u32},
     {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},
     {"alignbit/lshrrev/and mix", k_alignbit_and}, {"v_pk_add_u16", k_pk_add_u16},
 };
@@ -126,25 +142,30 @@ static entry table[] = {
 int main()
 {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
-    const int cus = prop.multiProcessorCount, iters = 20000;
+    const int cus = prop.multiProcessorCount, iters = 100000;
     u32* out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%d CUs, clock %d kHz (nominal 2.4 GHz used below)\n", cus, prop.clockRate);
     printf("%-36s", "16-instruction block, 8 chains");
-    for (int w : {1, 2, 4, 8}) printf(" | %d waves/SIMD", w);
+    for (int w : {1, 2, 3, 4, 6, 8}) printf(" | %d w/SIMD", w);
     printf("   (wave-instr / clk / SIMD)\n");
+    hipLaunchKernelGGL(k_add_u32, dim3(cus * 8), dim3(256), 0, 0, out, 1u, 4000000);      // ~1 s: clocks up
+    hipDeviceSynchronize();
     for (auto& t : table) {
         printf("%-36s", t.name);
-        for (int w : {1, 2, 4, 8}) {
+        for (int w : {1, 2, 3, 4, 6, 8}) {
             dim3 grid(cus * w), block(256);              // one 4-wave block per CU and per wave of occupancy
             hipLaunchKernelGGL(t.k, grid, block, 0, 0, out, 1u, 100);
             hipDeviceSynchronize();
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(t.k, grid, block, 0, 0, out, 1u, iters);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
+            float ms = 1e9;
+            for (int r = 0; r < 3; r++) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(t.k, grid, block, 0, 0, out, 1u, iters);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float m; hipEventElapsedTime(&m, e0, e1); if (m < ms) ms = m;
+            }
             double instr_per_simd = (double)w * iters * 16;
-            printf(" | %11.3f", instr_per_simd / (ms * 1e-3 * 2.4e9));
+            printf(" | %8.3f", instr_per_simd / (ms * 1e-3 * 2.4e9));
         }
         printf("\n");
     }

@@ -153,6 +153,9 @@ SppError sppark_msm_tune_sort(sppark_msm_ctx *ctx, unsigned low_bits);
 /* sort partitions with more entries than this are split over several work-groups (skewed scalars;
  * 0 = automatic, 2^18) */
 SppError sppark_msm_tune_split(sppark_msm_ctx *ctx, unsigned big_partition);
+/* bucket sums: windows with at most top_items partial sums are finished by the subset-sum kernels
+ * (k_bucket_top_bits / k_bucket_top_sum); 0 = automatic (4096), 1 = never */
+SppError sppark_msm_tune_sums(sppark_msm_ctx *ctx, unsigned top_items);
 /* Pipeline shape.  groups: the windows are sorted and accumulated in this many groups, the digits +
  * sort of group g+1 on a second stream beside the bucket accumulation of group g (0 / 1 = one group,
  * the default: on MI355X the overlap gains nothing; more groups shrink the sort

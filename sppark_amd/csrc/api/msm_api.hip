@@ -20,6 +20,8 @@ extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_top_bits<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_top_sum<msm_fp_d>(bucket_m*, const bucket_m*, unsigned);
 // ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)
 #ifndef SPPARK_NO_G2
 extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
@@ -31,6 +33,8 @@ extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m
 extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
                                                        unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_top_bits<fp2_d>(bucket2_m*, const bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_top_sum<fp2_d>(bucket2_m*, const bucket2_m*, unsigned);
 #endif
 }
 
@@ -300,6 +304,9 @@ SPPARK_FFI RustError sppark_msm_tune_sort(sppark_msm_ctx* ctx, unsigned low_bits
 // level-A partitions with more entries than this are sorted by several work-groups (0 = 2^18)
 SPPARK_FFI RustError sppark_msm_tune_split(sppark_msm_ctx* ctx, unsigned big_partition)
 {   return guarded([&] { ctx->impl.tune.big = big_partition; });   }
+// bucket sums: windows with at most this many partial sums go to the subset-sum top (0 = automatic, 1 = never)
+SPPARK_FFI RustError sppark_msm_tune_sums(sppark_msm_ctx* ctx, unsigned top_items)
+{   return guarded([&] { ctx->impl.tune.top = top_items; });   }
 // pipeline shape: window groups (0 = automatic, 1 = single stream), points per chunk of the
 // chunked path (0 = automatic), upper bound of the scratch memory in bytes (0 = what the device has)
 SPPARK_FFI RustError sppark_msm_tune_pipeline(sppark_msm_ctx* ctx, unsigned groups, size_t chunk_points, size_t max_scratch_bytes)

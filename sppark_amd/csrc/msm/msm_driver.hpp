@@ -52,6 +52,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0, LB = 0;
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
     unsigned groups = 0;                // window groups (1 = everything on one stream)
+    unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
 };
@@ -562,6 +563,21 @@ private:
             unsigned lgG = lg2_floor(p.K);
             bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
             while (nitems > 1) {
+                // the top of the sums by bit-weighted subset sums (msm_kernels.hpp k_bucket_top_bits): depth, not work
+                if (nitems <= (tune.top ? tune.top : BUCKET_TOP_MAX) && nitems >= 32 && (nitems & (nitems - 1)) == 0
+                    && (size_t)p.NB / p.K >= 32) {
+                    const unsigned m = lg2_floor(nitems);
+                    const size_t img = (size_t)BUCKET_TOP_NT * sizeof(bucket_t);
+                    if (img > 65536)
+                        HIP_OK(hipFuncSetAttribute((const void*)k_bucket_top_bits<fp_d>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img));
+                    hipLaunchKernelGGL(k_bucket_top_bits<fp_d>, dim3(m + 1, p.nwins), dim3(BUCKET_TOP_NT), img, stream,
+                                       oa, ia, iw, nitems, m, lgG);
+                    HIP_OK(hipGetLastError());
+                    hipLaunchKernelGGL(k_bucket_top_sum<fp_d>, dim3(p.nwins), dim3(32), 32 * sizeof(bucket_t), stream, ow, oa, m);
+                    HIP_OK(hipGetLastError());
+                    std::swap(iw, ow);
+                    break;
+                }
                 unsigned K = std::min(p.K, nitems);
                 nthr = (size_t)p.nwins * (nitems / K);
                 hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,

@@ -377,6 +377,74 @@ void k_bucket_levelN(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restri
 {   bucket_levelN_item<FP>(A2, Wt2, A1, Wt1, nitems, K, lgG, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // ---------------------------------------------------------------------------
+// Top of the bucket sums.  Once a window is down to M = 2^m <= BUCKET_TOP_MAX items (A_j, Wt_j) of
+// 2^lgG buckets each, the chunked levels above are chains of dependent additions run by a handful of
+// waves (0.6 ms per level whatever its size: one wave gets an issue slot every ~12 cycles).  The
+// weighted sum is re-associated so that its DEPTH, not its work, is small:
+//     sum_j Wt_j + 2^lgG * sum_j j*A_j  =  sum_j Wt_j + sum_{b<m} 2^(lgG+b) * S_b,   S_b = sum_{j: bit b of j} A_j
+// k_bucket_top_bits: work-group (b, w) reduces S_b (b < m) or sum_j Wt_j (b == m) -- M/512 additions per
+// lane, an 8-step tree through LDS, then b + lgG doublings by one lane; k_bucket_top_sum adds the m + 1
+// parts of a window with a 4..5-step tree.  m*M/2 + M additions instead of ~3M, at a depth of
+// ~M/512 + 8 + (m + lgG) doublings + 5 instead of (m/3) * (23 additions + doublings).
+// ---------------------------------------------------------------------------
+static constexpr unsigned BUCKET_TOP_MAX = 4096, BUCKET_TOP_NT = 256;
+
+template<class FP>
+SPPARK_DEVFN void lds_tree_sum(xyzz_dev<FP>& acc, xyzz_mem<FP::N>* img, unsigned tid, unsigned nt)
+{
+    for (unsigned s = nt >> 1; s >= 1; s >>= 1) {
+        if (tid >= s && tid < 2 * s) acc.store(&img[tid]);
+        __syncthreads();
+        if (tid < s) bucket_add<FP>(acc, xyzz_dev<FP>::load(&img[tid + s]));
+        __syncthreads();
+    }
+}
+
+template<class FP>
+__global__ __launch_bounds__(BUCKET_TOP_NT, 2)
+void k_bucket_top_bits(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ A,
+                       const xyzz_mem<FP::N>* __restrict__ Wt, unsigned nitems, unsigned m, unsigned lgG)
+{
+    extern __shared__ unsigned char top_lds[];
+    xyzz_mem<FP::N>* img = reinterpret_cast<xyzz_mem<FP::N>*>(top_lds);
+    const unsigned b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const xyzz_mem<FP::N>* src = (b == m ? Wt : A) + (size_t)w * nitems;
+    // items of a lane: j = lo | i << p | hi << (p + lgI), bit b inside the i field, so that every lane
+    // owns as many selected items as any other
+    unsigned lgI = 0;
+    while ((BUCKET_TOP_NT << lgI) < nitems) lgI++;
+    const unsigned p = b >= m ? 0 : (b < m - lgI ? b : m - lgI);
+    const unsigned lo = tid & ((1u << p) - 1), hi = tid >> p;
+    xyzz_dev<FP> acc; acc.set_inf();
+    #pragma unroll 1
+    for (unsigned i = 0; i < (1u << lgI); i++) {
+        const unsigned j = lo | (i << p) | (hi << (p + lgI));
+        if (j < nitems && (b == m || ((j >> b) & 1))) bucket_add<FP>(acc, xyzz_dev<FP>::load(&src[j]));
+    }
+    lds_tree_sum<FP>(acc, img, tid, BUCKET_TOP_NT);
+    if (tid == 0) {
+        if (b < m) {
+            #pragma unroll 1
+            for (unsigned k = 0; k < b + lgG; k++) bucket_dbl<FP>(acc);
+        }
+        acc.store(&parts[(size_t)w * (m + 1) + b]);
+    }
+}
+
+template<class FP>
+__global__ __launch_bounds__(32)
+void k_bucket_top_sum(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned m)
+{
+    extern __shared__ unsigned char top_lds[];
+    xyzz_mem<FP::N>* img = reinterpret_cast<xyzz_mem<FP::N>*>(top_lds);
+    const unsigned w = blockIdx.x, tid = threadIdx.x;
+    xyzz_dev<FP> acc; acc.set_inf();
+    if (tid <= m) acc = xyzz_dev<FP>::load(&parts[(size_t)w * (m + 1) + tid]);
+    lds_tree_sum<FP>(acc, img, tid, 32);
+    if (tid == 0) acc.store(&out[w]);
+}
+
+// ---------------------------------------------------------------------------
 // Coordinate fields with an internal representation (ff/montx_dev.hpp): the points are
 // converted ONCE per MSM (or once per preload) into the field's own records, and the W
 // window sums are converted back to the reference's wire image at the end.

@@ -83,6 +83,8 @@ def load(name):
         L.sppark_msm_release_cached.restype = None
         L.sppark_msm_tune_split.argtypes = [vp, cu]
         L.sppark_msm_tune_split.restype = _Error
+        L.sppark_msm_tune_sums.argtypes = [vp, cu]
+        L.sppark_msm_tune_sums.restype = _Error
         L.sppark_msm_tune_sort.argtypes = [vp, cu]
         L.sppark_msm_tune_sort.restype = _Error
         L.sppark_msm_tune_pipeline.argtypes = [vp, cu, sz, sz]

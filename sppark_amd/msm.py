@@ -92,6 +92,10 @@ class MsmContext:
     def tune_split(self, big_partition=0):
         ffi.check(self.L, self.L.sppark_msm_tune_split(self.h, big_partition))
 
+    def tune_sums(self, top_items=0):
+        """bucket sums: windows with at most this many partial sums use the subset-sum top (0 = automatic, 1 = never)"""
+        ffi.check(self.L, self.L.sppark_msm_tune_sums(self.h, top_items))
+
     def tune_pipeline(self, groups=0, chunk_points=0, max_scratch_bytes=0):
         """window groups (sort of group g+1 under the accumulation of group g), points per chunk
         of the chunked path, upper bound of the scratch memory; 0 = automatic"""

@@ -10,6 +10,7 @@ pts = base[torch.arange(n, device="cuda") % 2048].contiguous()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g); sc[:, 31] &= 0x3f
 ctx = sppark_amd.MsmContext("bls12_381"); ctx.enable_timing(True)
+if os.environ.get("SPPARK_TOP"): ctx.tune_sums(int(os.environ["SPPARK_TOP"]))
 for spec in wbs:
     wb, lb = (int(x) for x in (spec.split(":") + ["0"])[:2])
     ctx.tune(wbits=wb); ctx.tune_sort(lb)

@@ -1,14 +1,14 @@
 // Loosely-reduced, reduced-radix Montgomery field for the MSM bucket kernels (gfx950).
 //
-// Every VALU instruction of a wave64 costs one quad-cycle on CDNA4 (64-bit shifts/adds two),
-// so the currency is the instruction COUNT.  With full 32-bit limbs (mont_dev.hpp) a 12-limb
+// Every integer VALU instruction of a wave64 issues at the same rate on CDNA4 (multiply-adds included:
+// profiles/r02_ubench_instruction_rates.log), so the currency is the instruction COUNT.  With full 32-bit limbs (mont_dev.hpp) a 12-limb
 // product is 288 mads + 288 carry adds + bookkeeping = ~680 instructions and a modular
 // add/sub ~50.  Here (LB = 28 for a 381-bit modulus: NL = 14 limbs):
 //
 //   * a partial product of normalised limbs is < 2^56 and a whole column of a*b AND m*p
 //     products (28 of them) fits ONE 64-bit accumulator: a column is a pure chain of
 //     v_mad_u64_u32, no carry instructions; between columns the accumulator moves down by
-//     LB bits with two 32-bit instructions;
+//     LB bits with one 64-bit shift;
 //   * the Montgomery radix is 2^(LB*NL) = 2^392, a factor ~2500 above the modulus: values
 //     are only loosely reduced.  A product of inputs < ka*p and < kb*p is
 //     < (ka*kb*p/R + 1)*p; a + b adds the bounds; a - b is a + K*p - b where K*p is written
@@ -226,15 +226,15 @@ template<class P, int LB> struct montx_dev {
         return r;
     }
 
-    // accumulator >> LB with two 32-bit instructions (a 64-bit shift costs two quad-cycles and
-    // hipcc re-fuses the C spelling into one)
+    // accumulator >> LB: ONE 64-bit shift.  (Round 1 split it into v_alignbit_b32 + v_lshrrev_b32 on the
+    // belief that a 64-bit shift costs two issue slots; measured A/B on one box, 2^26 points:
+    // 114.0 ms with the pair, 112.3 ms with the single instruction -- with two waves per SIMD the
+    // kernel is bound by the NUMBER of instructions a wave gets to issue, tools/gpu_r2_job19.sh.)
     SPPARK_DEVFN static u64 shift_down(u64 A)
     {
 #if defined(__HIP_DEVICE_COMPILE__)
-        u32 lo = (u32)A, hi = (u32)(A >> 32), nlo, nhi;
-        asm("v_alignbit_b32 %0, %2, %3, %4\n\tv_lshrrev_b32 %1, %4, %2"
-            : "=&v"(nlo), "=v"(nhi) : "v"(hi), "v"(lo), "n"(LB));
-        return ((u64)nhi << 32) | nlo;
+        asm("v_lshrrev_b64 %0, %1, %0" : "+v"(A) : "n"(LB));
+        return A;
 #else
         return A >> LB;
 #endif

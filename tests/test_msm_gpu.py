@@ -639,6 +639,32 @@ def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     ctx.close()
 
 
+# ------------------------------------------------- bucket sums: chunked levels vs the subset-sum top
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_msm_bucket_sum_top(oracle, libs, curve, name):
+    """k_bucket_top_bits / k_bucket_top_sum against the chunked levels they replace (the G2 entry points
+    run them with the automatic hand-over; test_msm_g2_*): every
+    hand-over point (never, 32 .. 32768 partial sums per window), window sizes that give short and long
+    windows, bucket chunk 4 and 8, and a skewed case where most partial sums are the point at infinity."""
+    import sppark_amd
+    O = oracle
+    n = 30000
+    pts, sc = recipe.msm_inputs(curve, n, 4242, ndistinct=700, flagged=True)
+    sc_skew = sc.copy(); sc_skew[: n - 50, 2:] = 0              # 16-bit scalars: the upper windows are empty
+    cases = [(name, curve, pts, sc), (name, curve, pts, sc_skew)]
+    for ctx_name, oid, PT, SC in cases:
+        exp = O.msm_affine(oid, PT, SC, algo=0, param=8)
+        ctx = sppark_amd.MsmContext(ctx_name)
+        for wb in (0, 11, 16, 18):
+            for K in (0, 4, 8):
+                ctx.tune(wbits=wb, K=K)
+                for top in (1, 32, 512, 0, 32768):
+                    ctx.tune_sums(top)
+                    out = ctx.invoke(PT, SC, ffi_affine_sz=PT.shape[1])
+                    assert (sppark_amd.to_affine(out, ctx_name) == exp).all(), (ctx_name, wb, K, top)
+        ctx.close()
+
+
 # ------------------------------------------------- pipeline shape: window groups, chunks, devices
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_msm_window_groups_and_chunks(oracle, libs, curve, name):

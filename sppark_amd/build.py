@@ -20,6 +20,7 @@ OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wno-duplicate-decl-specifier"]
+FLAGS += os.environ.get("SPPARK_EXTRA_FLAGS", "").split()      # experiments: extra -D switches for every translation unit
 
 MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
            "msm/k_bucket1.hip", "msm/k_bucketN.hip",

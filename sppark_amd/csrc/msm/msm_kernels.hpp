@@ -161,6 +161,10 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     // hides behind ~20k cycles of arithmetic.  It costs a second point in registers: worth it for
     // the reduced-radix field (2 waves/SIMD either way, +2 %), not for alt_bn128 (would drop from
     // 4 to 3 waves/SIMD: 53 -> 71 ms) or Fp2.
+    // (Three waves per SIMD instead of two -- __launch_bounds__(256, 3), 168 registers -- were measured
+    // with the compiler's allocation: 42 spilled registers without this prefetch, 93 with it, 29 with
+    // single-chain products on top; 174 / 200 ms against 112 ms.  The prefetch itself is worth 1 %:
+    // 113.4 vs 112.4 ms.  profiles/r02_msm_accumulate_waves_ab.log)
     constexpr bool PREFETCH = field_is_internal<FP>::value;
     u32 e_next = 0, e_next2 = 0;                    // the index list runs two entries ahead, so that the
     affine_dev<FP> pt_next = pt;                    // gather's address never waits for its own load

@@ -1,7 +1,8 @@
 // Loosely-reduced, reduced-radix Montgomery field for the MSM bucket kernels (gfx950).
 //
-// Every integer VALU instruction of a wave64 issues at the same rate on CDNA4 (multiply-adds included:
-// profiles/r02_ubench_instruction_rates.log), so the currency is the instruction COUNT.  With full 32-bit limbs (mont_dev.hpp) a 12-limb
+// Multiply-adds, multiplies, carry instructions and 64-bit adds/shifts of a wave64 all issue at the same
+// rate on CDNA4 (only plain 32-bit adds / logic ops are ~1.5x cheaper: profiles/r02_ubench_instruction_rates.log),
+// so the currency is the instruction COUNT.  With full 32-bit limbs (mont_dev.hpp) a 12-limb
 // product is 288 mads + 288 carry adds + bookkeeping = ~680 instructions and a modular
 // add/sub ~50.  Here (LB = 28 for a 381-bit modulus: NL = 14 limbs):
 //

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void name(u32* out, u32 seed, int iters)      
         asm volatile(ASMBLOCK                                                           \
             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), \
               "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7) \
-            : : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");         \
+            : : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");         \
     }                                                                                   \
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7; \
 }
@@ -84,6 +84,22 @@ KERNEL(k_pk_add_u16,
     "v_pk_add_u16 %12, %12, %4\n v_pk_add_u16 %13, %13, %5\n v_pk_add_u16 %14, %14, %6\n v_pk_add_u16 %15, %15, %7\n")
 
 
+KERNEL(k_add_nop0,               // every VALU instruction followed by s_nop 0 (the padding of the hand-written carry chains)
+    "v_add_u32 %0, %0, %8\n s_nop 0\n v_add_u32 %1, %1, %9\n s_nop 0\n v_add_u32 %2, %2, %10\n s_nop 0\n v_add_u32 %3, %3, %11\n s_nop 0\n"
+    "v_add_u32 %4, %4, %12\n s_nop 0\n v_add_u32 %5, %5, %13\n s_nop 0\n v_add_u32 %6, %6, %14\n s_nop 0\n v_add_u32 %7, %7, %15\n s_nop 0\n"
+    "v_add_u32 %8, %8, %0\n s_nop 0\n v_add_u32 %9, %9, %1\n s_nop 0\n v_add_u32 %10, %10, %2\n s_nop 0\n v_add_u32 %11, %11, %3\n s_nop 0\n"
+    "v_add_u32 %12, %12, %4\n s_nop 0\n v_add_u32 %13, %13, %5\n s_nop 0\n v_add_u32 %14, %14, %6\n s_nop 0\n v_add_u32 %15, %15, %7\n s_nop 0\n")
+KERNEL(k_add_nop1,
+    "v_add_u32 %0, %0, %8\n s_nop 1\n v_add_u32 %1, %1, %9\n s_nop 1\n v_add_u32 %2, %2, %10\n s_nop 1\n v_add_u32 %3, %3, %11\n s_nop 1\n"
+    "v_add_u32 %4, %4, %12\n s_nop 1\n v_add_u32 %5, %5, %13\n s_nop 1\n v_add_u32 %6, %6, %14\n s_nop 1\n v_add_u32 %7, %7, %15\n s_nop 1\n"
+    "v_add_u32 %8, %8, %0\n s_nop 1\n v_add_u32 %9, %9, %1\n s_nop 1\n v_add_u32 %10, %10, %2\n s_nop 1\n v_add_u32 %11, %11, %3\n s_nop 1\n"
+    "v_add_u32 %12, %12, %4\n s_nop 1\n v_add_u32 %13, %13, %5\n s_nop 1\n v_add_u32 %14, %14, %6\n s_nop 1\n v_add_u32 %15, %15, %7\n s_nop 1\n")
+KERNEL(k_add_salu,               // every VALU instruction followed by a scalar ALU instruction
+    "v_add_u32 %0, %0, %8\n s_add_u32 s20, s20, 1\n v_add_u32 %1, %1, %9\n s_add_u32 s21, s21, 1\n v_add_u32 %2, %2, %10\n s_add_u32 s22, s22, 1\n v_add_u32 %3, %3, %11\n s_add_u32 s23, s23, 1\n"
+    "v_add_u32 %4, %4, %12\n s_add_u32 s20, s20, 1\n v_add_u32 %5, %5, %13\n s_add_u32 s21, s21, 1\n v_add_u32 %6, %6, %14\n s_add_u32 s22, s22, 1\n v_add_u32 %7, %7, %15\n s_add_u32 s23, s23, 1\n"
+    "v_add_u32 %8, %8, %0\n s_add_u32 s20, s20, 1\n v_add_u32 %9, %9, %1\n s_add_u32 s21, s21, 1\n v_add_u32 %10, %10, %2\n s_add_u32 s22, s22, 1\n v_add_u32 %11, %11, %3\n s_add_u32 s23, s23, 1\n"
+    "v_add_u32 %12, %12, %4\n s_add_u32 s20, s20, 1\n v_add_u32 %13, %13, %5\n s_add_u32 s21, s21, 1\n v_add_u32 %14, %14, %6\n s_add_u32 s22, s22, 1\n v_add_u32 %15, %15, %7\n s_add_u32 s23, s23, 1\n")
+
 #define KERNEL64(name, ASMBLOCK)                                                       \
 __global__ __launch_bounds__(256) void name(u32* out, u32 seed, int iters)              \
 {                                                                                       \
@@ -132,7 +148,7 @@ KERNEL64(k_mad_four_chains,
 typedef void (*kern_t)(u32*, u32, int);
 struct entry { const char* name; kern_t k; };
 static entry table[] = {
-    {"v_add_u32", k_add_u32}, {"v_add_co + v_addc_co (vcc)", k_addco_vcc_pairs}, {"v_add_co + v_addc_co (sgpr pairs)", k_addco_sgpr_pairs},
+    {"v_add_u32", k_add_u32}, {"v_add_u32 + s_nop 0 (VALU only counted)", k_add_nop0}, {"v_add_u32 + s_nop 1 (VALU only counted)", k_add_nop1}, {"v_add_u32 + s_add_u32 (VALU only counted)", k_add_salu}, {"v_add_co + v_addc_co (vcc)", k_addco_vcc_pairs}, {"v_add_co + v_addc_co (sgpr pairs)", k_addco_sgpr_pairs},
     {"v_add_co_u32 (vcc, carry unused)", k_addco_only_vcc}, {"v_lshl_add_u64", k_lshl_add_u64}, {"v_add3_u32", k_add3_u32},
     {"v_cmp_lt_u32 + v_cndmask_b32", k_cmp_cndmask}, {"v_mad_u64_u32 (8 chains)", k_mad_u64_u32}, {"v_mad_u64_u32, 1 dependent chain", k_mad_one_chain}, {"v_mad_u64_u32, 2 dependent chains", k_mad_two_chains}, {"v_mad_u64_u32, 4 dependent chains", k_mad_four_chains}, {"v_mad_u64_u32 + v_addc_co (vcc)", k_mad_u64_u32_carry}, {"v_mul_lo_u32", k_mul_lo_u32},
     {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},

@@ -196,8 +196,12 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
 
 // (Fp2: 256 VGPRs + 106 AGPRs, one wave per SIMD; forcing two spills 121 registers and gains nothing:
 // 25.2 vs 25.6 ms for 2^22 G2 points)
+// The 10-limb fields (alt_bn128, Pasta) need 172 registers unconstrained, four more than three waves
+// per SIMD leave each: capped (4 spilled registers), alt_bn128 2^26: 68.4 -> 65.1 ms (A/B on one box,
+// tools/gpu_r2_job23.sh).  The 14-limb fields stay at two waves: 230 registers, and every attempt at
+// 168 spilled enough to lose (profiles/r02_msm_accumulate_waves_ab.log).
 template<class FP, bool FLAGGED>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, (field_is_internal<FP>::value && FP::N <= 10) ? 3 : 1)
 void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
                   u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict__ rec_pt,
                   const unsigned char* __restrict__ points, unsigned stride,

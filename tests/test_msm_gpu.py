@@ -603,6 +603,28 @@ def test_msm_oversized_sort_partitions(oracle, libs):
     ctx.close()
 
 
+def test_msm_sort_partition_paths(oracle, libs):
+    """k_sortB's three ways through a level-A partition in one MSM: up to 18432 entries it is held in
+    registers and placed through an LDS image, above that it takes the two-pass path, above the split
+    threshold the cooperative kernels -- forced with scalars that are equal for most points (every window
+    then has one partition with ~n entries) plus a uniform remainder, for long and short windows."""
+    import sppark_amd
+    O = oracle
+    n = 60000
+    pts, sc = recipe.msm_inputs(O.BLS12_381, n, 6060, ndistinct=400, flagged=False)
+    s_mix = sc.copy(); s_mix[: n - 9000] = sc[0]                # 51000 equal scalars + 9000 uniform ones
+    s_eq = sc.copy(); s_eq[:] = sc[1]
+    ctx = sppark_amd.MsmContext("bls12_381")
+    for big in (0, 30000):                                      # 0: automatic threshold (2^18): two-pass path
+        ctx.tune_split(big)
+        for wb, lb in ((0, 0), (17, 6), (21, 9), (22, 9), (13, 0)):
+            ctx.tune(wbits=wb); ctx.tune_sort(lb)
+            for s_ in (s_mix, s_eq):
+                out = ctx.invoke(pts, s_, ffi_affine_sz=96)
+                assert (sppark_amd.to_affine(out) == O.msm_affine(O.BLS12_381, pts, s_, algo=0, param=8)).all(), (big, wb, lb)
+    ctx.close()
+
+
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     """BASELINE size (2^26 points; configs[2] BLS12-381 G1 and configs[4] alt_bn128 G1) against the

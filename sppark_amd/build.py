@@ -29,7 +29,8 @@ MSM_TUS = ["api/msm_api.hip", "msm/k_accumulate.hip", "msm/k_reduce.hip",
            "api/ntt_api.hip:SPPARK_NTT_WITH_MSM",          # compute_ntt over the curve's scalar field
            "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0"]
 MSM_G1_TUS = [t for t in MSM_TUS if "SPPARK_G2" not in t]      # curves without a G2 (Pasta)
-NTT_TUS = ["api/ntt_api.hip", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0"]
+NTT_TUS = ["api/ntt_api.hip", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0",
+           "ntt/k_ntt_r64.hip:SPPARK_NTT_DIF=1", "ntt/k_ntt_r64.hip:SPPARK_NTT_DIF=0"]       # single-word fields: radix-64 plan
 
 TARGETS = {
     "bls12_381": ("FEATURE_BLS12_381", MSM_TUS),

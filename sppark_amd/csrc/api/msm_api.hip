@@ -16,7 +16,8 @@ extern template __global__ void k_accumulate<msm_fp_d, true>(bucket_m*, u32*, bu
 extern template __global__ void k_bitmap_accumulate<msm_fp_d, false>(u32*, bucket_m*, const unsigned char*, unsigned, unsigned, const u32*, const u32*, unsigned);
 extern template __global__ void k_bitmap_accumulate<msm_fp_d, true>(u32*, bucket_m*, const unsigned char*, unsigned, unsigned, const u32*, const u32*, unsigned);
 extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
-                                                    unsigned, unsigned, unsigned, int);
+                                                    unsigned, unsigned, unsigned, int, const u32*);
+extern template __global__ void k_join_runs<msm_fp_d>(bucket_m*, u32*, const u32*, const bucket_m*, unsigned, u32*);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
@@ -29,7 +30,8 @@ extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, buc
 extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
-                                                     unsigned, unsigned, unsigned, int);
+                                                     unsigned, unsigned, unsigned, int, const u32*);
+extern template __global__ void k_join_runs<fp2_d>(bucket2_m*, u32*, const u32*, const bucket2_m*, unsigned, u32*);
 extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
                                                        unsigned, unsigned, unsigned, unsigned);

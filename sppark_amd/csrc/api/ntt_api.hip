@@ -10,6 +10,15 @@ SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTE
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, false)
 #endif
 }
+#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // the radix-64 plan: ntt/k_ntt_r64.hip
+#include "../ntt/ntt_r64_kernels.hpp"
+namespace sppark_amd {
+#define SPPARK_R64_EXTERN(K, DIF, INV) \
+    extern template __global__ void K<ntt_fr_t, DIF, INV>(ntt_fr_t*, ntt_r64_args<ntt_fr_t>);
+SPPARK_R64_EXTERN(k_ntt6, true, false) SPPARK_R64_EXTERN(k_ntt6, true, true) SPPARK_R64_EXTERN(k_ntt6, false, false) SPPARK_R64_EXTERN(k_ntt6, false, true)
+SPPARK_R64_EXTERN(k_ntt12, true, false) SPPARK_R64_EXTERN(k_ntt12, true, true) SPPARK_R64_EXTERN(k_ntt12, false, false) SPPARK_R64_EXTERN(k_ntt12, false, true)
+}
+#endif
 #include "../ntt/ntt_driver.hpp"
 #ifdef SPPARK_NTT_WITH_MSM            // same .so as msm_api.hip, which already defines the common symbols
 # define SPPARK_FFI extern "C" __attribute__((visibility("default")))

@@ -317,6 +317,35 @@ struct gl64_dev {
         const unsigned e = root_exp<INV>(R, k) % 96;
         return e ? mul_pow2(x, e) : x;
     }
+    // p - a (0 for a == 0): 0 - a, and - (2^32 - 1) on borrow, i.e. the tail of operator-
+    SPPARK_DEVFN static gl64_dev neg(gl64_dev a)
+    {
+#if defined(SPPARK_GL64_ASM)
+        u32 a0 = (u32)a.v, a1 = (u32)(a.v >> 32), lo, hi, t;
+        asm("v_sub_co_u32 %0, vcc, 0, %3\n\t"
+            "s_nop 1\n\t"
+            "v_subb_co_u32 %1, vcc, 0, %4, vcc\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+            "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+            "s_nop 1\n\t"
+            "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+            : "=&v"(lo), "=&v"(hi), "=&v"(t) : "v"(a0), "v"(a1) : "vcc");
+        return from_raw(((u64)hi << 32) | lo);
+#else
+        return from_raw(a.v ? MOD - a.v : 0);
+#endif
+    }
+    // x * w_{2^R}^k with the sign included (a twiddle that no butterfly follows directly:
+    // the diagonal between the two radix-8 rounds of a radix-64 block, ntt/ntt_r64_kernels.hpp)
+    template<bool INV>
+    SPPARK_DEVFN static gl64_dev mul_root_full(gl64_dev x, unsigned R, unsigned k, const gl64_dev*)
+    {
+        const unsigned e = root_exp<INV>(R, k);
+        if (e == 0) return x;
+        if (e < 96) return mul_pow2(x, e);
+        return neg(e == 96 ? x : mul_pow2(x, e - 96));
+    }
     static constexpr bool SHIFT_ROOTS = true;
 };
 
@@ -358,6 +387,9 @@ struct bb31_dev {
     {   return k ? x * inner[(1u << R) + k] : x;   }
     template<bool INV>
     SPPARK_DEVFN static constexpr bool root_neg(unsigned, unsigned) { return false; }
+    template<bool INV>
+    SPPARK_DEVFN static bb31_dev mul_root_full(bb31_dev x, unsigned R, unsigned k, const bb31_dev* inner)
+    {   return k ? x * inner[(1u << R) + k] : x;   }
     SPPARK_DEVFN static void bfly(bb31_dev a, bb31_dev b, bb31_dev& s, bb31_dev& d) { s = a + b; d = a - b; }
     static constexpr bool SHIFT_ROOTS = false;
 };

@@ -2,5 +2,6 @@
 #include "msm_kernels.hpp"
 namespace sppark_amd {
 template __global__ void k_reduce_runs<inst_fp>(inst_m*, u32*, inst_m*, const u32*, const inst_m*,
-                                             unsigned, unsigned, unsigned, int);
+                                             unsigned, unsigned, unsigned, int, const u32*);
+template __global__ void k_join_runs<inst_fp>(inst_m*, u32*, const u32*, const inst_m*, unsigned, u32*);
 }

@@ -53,6 +53,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
     unsigned groups = 0;                // window groups (1 = everything on one stream)
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
+    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
 };
@@ -150,7 +151,7 @@ private:
 
     struct layout {
         size_t digits[2], sorted[2], partA[2], H[2], tot[2], offA[2], off[2], curB[2], bigl[2];
-        size_t buckets, keyA, ptA, keyB, ptB, A1, W1, A2, W2, conv, sums, total;
+        size_t buckets, keyA, ptA, keyB, ptB, keyC, flag, A1, W1, A2, W2, conv, sums, total;
     };
 
     static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -186,6 +187,7 @@ private:
         size_t nrecB = 2 * ((nrecA + p.F - 1) / p.F);
         l.keyA = take(nrecA * 4); l.ptA = take(nrecA * sizeof(bucket_t));
         l.keyB = take(nrecB * 4); l.ptB = take(nrecB * sizeof(bucket_t));
+        l.keyC = take(nrecA * 4); l.flag = take(4);                 // k_join_runs: filtered keys, "a long segment exists"
         size_t n1 = (size_t)p.nwins * (p.NB / p.K);
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n1 * sizeof(bucket_t)); l.W2 = take(n1 * sizeof(bucket_t));
@@ -539,11 +541,23 @@ private:
         {
             size_t nrec = (size_t)2 * p.nwins * p.chunks_per_win;
             u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
+            // segments of <= JOIN_WALK records (with uniform scalars: all of them) in one launch; the tree
+            // below then only sees the records of longer segments and returns at once when there are none
+            const u32* skip = nullptr;
+            if (tune.join != 1) {
+                u32* keyC = (u32*)(blob + l.keyC); u32* flag = (u32*)(blob + l.flag);
+                HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
+                const size_t nthr = nrec / 2 + 1;
+                hipLaunchKernelGGL(k_join_runs<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                   buckets, keyC, keyA, ptA, (unsigned)nrec, flag);
+                HIP_OK(hipGetLastError());
+                ik = keyC; skip = flag;
+            }
             for (;;) {
                 unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
                 int last = nthreads == 1;
                 hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
-                                   buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last);
+                                   buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last, skip);
                 HIP_OK(hipGetLastError());
                 if (last) break;
                 nrec = (size_t)2 * nthreads;
@@ -664,7 +678,7 @@ public:
             unsigned nthreads = (unsigned)((n + F - 1) / F);
             int last = nthreads == 1;
             hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
-                               bucket, ok, op, ik, ip, (unsigned)n, (unsigned)F, nthreads, last);
+                               bucket, ok, op, ik, ip, (unsigned)n, (unsigned)F, nthreads, last, (const u32*)nullptr);
             HIP_OK(hipGetLastError());
             if (last) break;
             n = (size_t)2 * nthreads;

@@ -256,6 +256,71 @@ void k_bitmap_accumulate(u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// join_runs: the SHORT segments of the record list, in one launch.
+// The records k_accumulate leaves are the partial sums of the buckets that touch a chunk
+// boundary: [first run | last run or NONE] per chunk.  Consecutive records with one key form a
+// segment (the pieces of one bucket); with ~2^4..2^5 entries per bucket and 64..128 per chunk
+// almost every segment is two records long -- the end of chunk t and the start of chunk t+1 --
+// but the fan-in tree below resolves a segment only at the level where both pieces meet in one
+// work item: ~12 dependent launches of a handful of latency-bound waves (1.2 ms of a 2^23-point
+// MSM).  Here work item t looks at records 2t-1 and 2t: a record that STARTS a segment which ends
+// within WALK records adds the segment up and stores the bucket; every record of such a segment
+// gets key NONE in |out_key|; records of longer segments (skewed scalars) keep their key and go
+// through the tree, which for uniform scalars then finds nothing to add.  Every record decides
+// "short or long" for itself from the keys alone (at most 2*WALK reads of 4 bytes), so there is
+// no ordering between work items.
+//   two NONE records in a row only occur at the tail of a window (an empty chunk), and the next
+//   window's keys are different: they end a segment like a different key does.
+// ---------------------------------------------------------------------------
+static constexpr unsigned JOIN_WALK = 8;
+template<class FP> SPPARK_DEVFN void bucket_add(xyzz_dev<FP>& a, const xyzz_dev<FP>& b);
+
+template<class FP>
+SPPARK_DEVFN void join_runs_item(xyzz_mem<FP::N>* buckets, u32* out_key, const u32* in_key,
+                                 const xyzz_mem<FP::N>* in_pt, unsigned nrec, u32* any_long, size_t t)
+{
+    for (unsigned s = 0; s < 2; s++) {
+        if (t == 0 && s == 0) continue;
+        const size_t q = 2 * t - 1 + s;
+        if (q >= nrec) return;
+        const u32 k = in_key[q];
+        if (k == KEY_NONE) { out_key[q] = KEY_NONE; continue; }
+        // the start of the segment: scan back
+        size_t h = q; bool is_long = false;
+        for (size_t i = q, none = 0; i-- > 0;) {
+            const u32 ki = in_key[i];
+            if (ki == KEY_NONE) { if (++none == 2) break; continue; }
+            none = 0;
+            if (ki != k) break;
+            h = i;
+            if (q - h > JOIN_WALK) { is_long = true; break; }
+        }
+        // its end: a different key (or two NONEs, or the end of the list) within WALK records of the start
+        size_t e = h;
+        if (!is_long) {
+            bool ended = false;
+            size_t i = h + 1;
+            for (unsigned none = 0; i < nrec && i <= h + JOIN_WALK; i++) {
+                const u32 ki = in_key[i];
+                if (ki == KEY_NONE) { if (++none == 2) { ended = true; break; } continue; }
+                none = 0;
+                if (ki != k) { ended = true; break; }
+                e = i;
+            }
+            if (i >= nrec) ended = true;
+            is_long = !ended;
+        }
+        if (is_long) { out_key[q] = k; *any_long = 1; continue; }
+        out_key[q] = KEY_NONE;
+        if (q != h) continue;
+        xyzz_dev<FP> acc = xyzz_dev<FP>::load(&in_pt[h]);
+        for (size_t i = h + 1; i <= e; i++)
+            if (in_key[i] == k) bucket_add<FP>(acc, xyzz_dev<FP>::load(&in_pt[i]));
+        acc.store(&buckets[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // reduce_runs (levels >= 1): same walk over F consecutive records.
 // |last| = this is the final level (single work item): every run is complete.
 // ---------------------------------------------------------------------------
@@ -296,15 +361,25 @@ SPPARK_DEVFN void reduce_runs_chunk(xyzz_mem<FP::N>* buckets, u32* out_key, xyzz
     else                      { acc.store(&out_pt[rec0 + 1]); out_key[rec0] = slot0_key; out_key[rec0 + 1] = cur; }
 }
 
+// |skip|: when non-null and *skip == 0 (k_join_runs found no long segment) the level has nothing to do
 template<class FP>
 __global__ __launch_bounds__(256)
 void k_reduce_runs(xyzz_mem<FP::N>* __restrict__ buckets,
                    u32* __restrict__ out_key, xyzz_mem<FP::N>* __restrict__ out_pt,
                    const u32* __restrict__ in_key, const xyzz_mem<FP::N>* __restrict__ in_pt,
-                   unsigned nrec, unsigned F, unsigned nthreads, int last)
+                   unsigned nrec, unsigned F, unsigned nthreads, int last, const u32* __restrict__ skip)
 {
+    if (skip != nullptr && *skip == 0) return;
     reduce_runs_chunk<FP>(buckets, out_key, out_pt, in_key, in_pt, nrec, F, nthreads, last,
                           blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+template<class FP>
+__global__ __launch_bounds__(256, 2)
+void k_join_runs(xyzz_mem<FP::N>* __restrict__ buckets, u32* __restrict__ out_key, const u32* __restrict__ in_key,
+                 const xyzz_mem<FP::N>* __restrict__ in_pt, unsigned nrec, u32* __restrict__ any_long)
+{
+    join_runs_item<FP>(buckets, out_key, in_key, in_pt, nrec, any_long, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 // device and kept for the life of the process, kernel sequence on one stream.
 #pragma once
 #include "ntt_kernels.hpp"
+#include "ntt_r64_kernels.hpp"
 #include "../ff/fr256_dev.hpp"
 #include "../ff/mont_host.hpp"
 #include "../util/runtime.hpp"
@@ -71,7 +72,11 @@ class ntt_engine {
     struct table_set {
         F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale;
         std::map<std::pair<unsigned, unsigned>, F*> pass_tw;    // (lg_cur, S) -> inter-pass twiddle table of that pass
+        std::map<std::tuple<unsigned, unsigned, int>, F*> r64_tw;   // (kind, lg_cur, scaled) -> table of the radix-64 plan
     };
+    // the radix-64 plan (ntt_r64_kernels.hpp): single-word fields, transforms of >= 2^12 elements
+    static constexpr bool R64 = sizeof(F) <= 8;
+    static constexpr unsigned R64_DIRECT_MAX_LG = 20;          // one inter-pass table up to 2^20 entries, two small ones above
     static constexpr unsigned PASS_TABLE_MAX_LG = 16;          // tables of <= 2^16 elements (512 KB for Goldilocks): L2-resident
     std::map<std::tuple<int, unsigned, int>, table_set> cache;     // (hip device, lg, inverse)
     std::mutex mtx;
@@ -103,6 +108,26 @@ class ntt_engine {
         if (e == hipSuccess) e = hipStreamSynchronize(stream);      // visible to every later call on any stream
         if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
         ts.pass_tw.emplace(key, tw);
+        return tw;
+    }
+
+    // a table of the radix-64 plan (r64_table_item), built once per (device, size, direction, kind, pass, scaled)
+    const F* r64_table(int hip_dev, unsigned lg, int inverse, unsigned kind, unsigned lg_cur, int scaled,
+                       const ntt_tables<F>& T, hipStream_t stream)
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        table_set& ts = cache.find(std::make_tuple(hip_dev, lg, inverse))->second;
+        auto key = std::make_tuple(kind, lg_cur, scaled);
+        auto it = ts.r64_tw.find(key);
+        if (it != ts.r64_tw.end()) return it->second;
+        const size_t count = kind == 0 ? (size_t)1 << lg_cur : kind == 1 ? (size_t)1 << (lg_cur - 6) : 4096;
+        F* tw = nullptr;
+        HIP_OK(hipMalloc((void**)&tw, count * sizeof(F)));
+        hipLaunchKernelGGL(k_r64_table<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tw, T, kind, lg_cur, scaled);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
+        ts.r64_tw.emplace(key, tw);
         return tw;
     }
 
@@ -160,9 +185,11 @@ public:
 
         // tuning knobs (tools/gpu_ntt_sweep.py), read once per process; the LDS tile is clamped to what
         // the element size allows (160 KB per work-group: 2^14 eight-byte elements, 2^12 32-byte ones)
-        struct knobs_t { unsigned smax, lgc, lgt; };
+        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct; };
         static const knobs_t knobs = [] {
-            knobs_t k{S_MAX, LG_LINE, LG_TILE};
+            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG};
+            if (const char* e = getenv("SPPARK_NTT_R64_MIN")) k.r64_min = (unsigned)atoi(e);          // 99: the 8-stage plan only
+            if (const char* e = getenv("SPPARK_NTT_R64_DIRECT")) k.r64_direct = (unsigned)atoi(e);    // largest single inter-pass table (log2)
             if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= S_MAX) k.smax = v; }
             if (const char* e = getenv("SPPARK_NTT_LGC")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= 8) k.lgc = v; }
             if (const char* e = getenv("SPPARK_NTT_LGTILE")) {
@@ -174,10 +201,48 @@ public:
             return k;
         }();
         const unsigned smax = knobs.smax, lgc = knobs.lgc, lgt = knobs.lgt;
-        ntt_plan pl = make_ntt_plan(lg, lgc, lgt, smax);
+        ntt_plan pl;
+        r64_plan rp; rp.nsteps = 0;
+        if (R64 && lg >= 12 && lg >= knobs.r64_min) {
+            rp = make_r64_plan(lg);
+            pl.npass = rp.nsteps;
+        } else {
+            pl = make_ntt_plan(lg, lgc, lgt, smax);
+        }
         for (unsigned i = 0; i < pl.npass; i++) {
-            ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
-            P.apply_scale = inverse && i == pl.npass - 1;
+            const bool last = i == pl.npass - 1;
+            ntt_pass P;
+            if (rp.nsteps) {
+                const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
+                if constexpr (R64) {
+                    if (st.kind != 0) {
+                        const int scaled = inverse && last;
+                        ntt_r64_args<F> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur};
+                        if (st.kind == 2 || st.lg_cur <= knobs.r64_direct)
+                            A.tw = r64_table(gpu.hip_id, lg, inverse, 0, st.lg_cur, scaled, T, stream);
+                        else {
+                            A.t1 = r64_table(gpu.hip_id, lg, inverse, 1, st.lg_cur, scaled, T, stream);
+                            A.t2 = r64_table(gpu.hip_id, lg, inverse, 2, st.lg_cur, 0, T, stream);
+                        }
+                        const unsigned tiles = (unsigned)(n >> 12);
+                        const size_t lds = sizeof(F) << 12;
+#define SPPARK_R64_LAUNCH(K)                                                                                   \
+                        do {                                                                                   \
+                            if (gs) { if (inverse) hipLaunchKernelGGL((K<F, true, true>), dim3(tiles), dim3(512), lds, stream, d, A);    \
+                                      else         hipLaunchKernelGGL((K<F, true, false>), dim3(tiles), dim3(512), lds, stream, d, A); } \
+                            else    { if (inverse) hipLaunchKernelGGL((K<F, false, true>), dim3(tiles), dim3(512), lds, stream, d, A);   \
+                                      else         hipLaunchKernelGGL((K<F, false, false>), dim3(tiles), dim3(512), lds, stream, d, A); } \
+                        } while (0)
+                        if (st.kind == 1) SPPARK_R64_LAUNCH(k_ntt6); else SPPARK_R64_LAUNCH(k_ntt12);
+#undef SPPARK_R64_LAUNCH
+                        continue;
+                    }
+                }
+                P.lg_cur = st.lg_cur; P.S = st.S; P.lgC = lgc; P.lgG = 0;       // a strided pass above >= 12 further stages
+            } else {
+                P = pl.pass[gs ? i : pl.npass - 1 - i];
+            }
+            P.apply_scale = inverse && last;
             T.pass_tw = pass_table(gpu.hip_id, lg, inverse, P.lg_cur, P.S, T, stream);
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);

@@ -4,6 +4,7 @@
 #define SPPARK_HOST_EMULATION 1
 #include "../../sppark_amd/csrc/ff/params.hpp"
 #include "../../sppark_amd/csrc/ntt/ntt_kernels.hpp"
+#include "../../sppark_amd/csrc/ntt/ntt_r64_kernels.hpp"
 #include "../../sppark_amd/csrc/ff/fr256_dev.hpp"
 #include <vector>
 #include <cstring>
@@ -56,6 +57,71 @@ static void emu_bitrev(F* d, unsigned lg)
     }
 }
 
+// the radix-64 plan of ntt_engine::run (single-word fields, lg >= 12): k_ntt6 / k_ntt12 round by round,
+// generic passes for the other steps; tables from r64_table_item, as ntt_engine::r64_table builds them
+template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int inverse, ntt_tables<FF>& T, unsigned nt, unsigned direct_max)
+{
+    if constexpr (sizeof(FF) <= 8) {
+        const size_t n = (size_t)1 << lg;
+        r64_plan rp = make_r64_plan(lg);
+        for (unsigned i = 0; i < rp.nsteps; i++) {
+            const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
+            const bool last = i == rp.nsteps - 1;
+            if (st.kind == 0) {
+                ntt_pass P; P.lg_cur = st.lg_cur; P.S = st.S; P.lgC = LG_LINE; P.lgG = 0; P.apply_scale = inverse && last;
+                std::vector<FF> tile(ntt_lds_elems(P) + 1);
+                T.pass_tw = nullptr;
+                const size_t tile_elems = (size_t)1 << (P.S + P.lgC);
+                for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {
+#define EMU_ROUNDS(R1, R2)                                                                                         \
+                    do {                                                                                               \
+                        if (gs) {                                                                                      \
+                            for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_high<FF, true, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_high<FF, true, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                            if (R2) for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_low<FF, true, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_low<FF, true, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                        } else {                                                                                       \
+                            if (R2) for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_low<FF, false, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_low<FF, false, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                            for (unsigned tid = 0; tid < nt; tid++) { if (inverse) ntt_round_high<FF, false, true, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); else ntt_round_high<FF, false, false, R1, R2>(d, tile.data(), T, P, tile_id, tid, nt); } \
+                        }                                                                                              \
+                    } while (0)
+                    SPPARK_NTT_DISPATCH_S(P.S, EMU_ROUNDS);
+#undef EMU_ROUNDS
+                }
+                continue;
+            }
+            const int scaled = inverse && last;
+            std::vector<FF> tw, t1, t2, tile(4096);
+            ntt_r64_args<FF> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur};
+            auto fill = [&](std::vector<FF>& v, unsigned kind, int sc) {
+                v.resize(kind == 0 ? (size_t)1 << st.lg_cur : kind == 1 ? (size_t)1 << (st.lg_cur - 6) : 4096);
+                for (size_t k = 0; k < v.size(); k++) r64_table_item(v.data(), T, kind, st.lg_cur, sc, k);
+            };
+            if (st.kind == 2 || st.lg_cur <= direct_max) { fill(tw, 0, scaled); A.tw = tw.data(); }
+            else { fill(t1, 1, scaled); fill(t2, 2, 0); A.t1 = t1.data(); A.t2 = t2.data(); }
+            for (size_t tile_id = 0; tile_id < (n >> 12); tile_id++) {
+#define EMU_ALL(CALL) for (unsigned tid = 0; tid < 512; tid++) { CALL; }
+                if (st.kind == 1) {
+                    if (gs) { if (inverse) { EMU_ALL((ntt6_high<FF, true, true>(d, tile.data(), A, tile_id, tid))) EMU_ALL((ntt6_low<FF, true, true>(d, tile.data(), A, tile_id, tid))) }
+                              else         { EMU_ALL((ntt6_high<FF, true, false>(d, tile.data(), A, tile_id, tid))) EMU_ALL((ntt6_low<FF, true, false>(d, tile.data(), A, tile_id, tid))) } }
+                    else    { if (inverse) { EMU_ALL((ntt6_low<FF, false, true>(d, tile.data(), A, tile_id, tid))) EMU_ALL((ntt6_high<FF, false, true>(d, tile.data(), A, tile_id, tid))) }
+                              else         { EMU_ALL((ntt6_low<FF, false, false>(d, tile.data(), A, tile_id, tid))) EMU_ALL((ntt6_high<FF, false, false>(d, tile.data(), A, tile_id, tid))) } }
+                } else {
+                    FF* sub = d + (tile_id << 12);
+#define EMU_R12(DIF, INV, D) EMU_ALL((ntt12_round<FF, DIF, INV, D>(sub, tile.data(), A, tid)))
+                    if (gs) { if (inverse) { EMU_R12(true, true, R12_A1) EMU_R12(true, true, R12_B1) EMU_R12(true, true, R12_A2) EMU_R12(true, true, R12_B2) }
+                              else         { EMU_R12(true, false, R12_A1) EMU_R12(true, false, R12_B1) EMU_R12(true, false, R12_A2) EMU_R12(true, false, R12_B2) } }
+                    else    { if (inverse) { EMU_R12(false, true, R12_B2) EMU_R12(false, true, R12_A2) EMU_R12(false, true, R12_B1) EMU_R12(false, true, R12_A1) }
+                              else         { EMU_R12(false, false, R12_B2) EMU_R12(false, false, R12_A2) EMU_R12(false, false, R12_B1) EMU_R12(false, false, R12_A1) } }
+#undef EMU_R12
+                }
+#undef EMU_ALL
+            }
+        }
+    }
+}
+
+static unsigned g_r64_min = 12, g_r64_direct = 20;          // as ntt_engine's knobs (SPPARK_NTT_R64_MIN / _DIRECT)
+extern "C" void emu_ntt_plan(unsigned r64_min, unsigned r64_direct) { g_r64_min = r64_min; g_r64_direct = r64_direct; }
+
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
     if (lg == 0) return 0;
@@ -88,6 +154,10 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
 #define EMU_SMAX (sizeof(F) > 8 ? 4 : 8)        // as ntt_engine<F>::S_MAX
 #endif
     ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
+    if (sizeof(F) <= 8 && lg >= 12 && lg >= g_r64_min) {
+        emu_r64_passes<F>(d, lg, gs, inverse, T, nt, g_r64_direct);
+        pl.npass = 0;
+    }
     for (unsigned i = 0; i < pl.npass; i++) {
         ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
         P.apply_scale = inverse && i == pl.npass - 1;

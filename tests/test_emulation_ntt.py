@@ -25,6 +25,8 @@ def _emu(feature):
     L = ctypes.CDLL(so)
     L.emu_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
     L.emu_lde.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
+    L.emu_ntt_plan.argtypes = [ctypes.c_uint, ctypes.c_uint]
+    L.emu_ntt_plan.restype = None
     return L
 
 
@@ -66,3 +68,36 @@ def test_lde_kernels_on_host(oracle, field, feature):
         L.emu_lde(buf.ctypes.data, lg, lgb, aux.ctypes.data)
         assert (buf.reshape(exp.shape) == exp).all(), (field, lg, lgb)
         assert (aux.reshape(aux_exp.shape) == aux_exp).all(), (field, lg, lgb)
+
+
+@pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR")])
+def test_ntt_radix64_plan_on_host(oracle, field, feature):
+    """The radix-64 plan (k_ntt6 / k_ntt12 round functions, r64_table_item tables, make_r64_plan) on the
+    host against the oracle AND against the 8-stage plan: 12-stage kernel alone (2^12), a generic pass
+    above it (2^13..2^17), k_ntt6 with ONE inter-pass table (2^18, direct) and with the two small
+    tables (2^18, factored), both directions and all four orders."""
+    O = oracle
+    L = _emu(feature)
+    f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+    try:
+        for lg, direct, modes in ((12, 20, "all"), (13, 20, "all"), (15, 20, "nr"), (17, 20, "nr"),
+                                  (18, 20, "all"), (18, 12, "nr"), (19, 12, "nr")):
+            x = recipe.ntt_input(field, lg, 500 + lg)
+            for order in range(4):
+                for direction in range(2):
+                    for typ in range(2):
+                        if modes == "nr" and (typ == 1 or order in (0, 3)):
+                            continue
+                        if lg >= 18 and modes == "all" and typ == 1 and order != 1:
+                            continue
+                        L.emu_ntt_plan(12, direct)
+                        y = x.copy()
+                        L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 256)
+                        assert (y == f(x, order, direction, typ)).all(), (field, lg, direct, order, direction, typ)
+            # the 8-stage plan gives the same bytes
+            L.emu_ntt_plan(99, 20)
+            z = x.copy()
+            L.emu_ntt(z.ctypes.data, lg, 1, 0, 0, 256)
+            assert (z == f(x, 1, 0, 0)).all()
+    finally:
+        L.emu_ntt_plan(12, 20)

@@ -6,8 +6,13 @@ import sppark_amd
 from sppark_amd import NTTInputOutputOrder as Ord
 
 stream = torch.cuda.current_stream().cuda_stream
+FIELDS = os.environ.get("NTT_FIELDS", "gl64,bb31,bls12_381,bn254").split(",")      # e.g. NTT_FIELDS=gl64 NTT_LGS=12,16,24
+LGS = [int(v) for v in os.environ["NTT_LGS"].split(",")] if os.environ.get("NTT_LGS") else None
+print("plan knobs:", {k: v for k, v in os.environ.items() if k.startswith("SPPARK_NTT")}, flush=True)
 for field, dt, eb in (("gl64", torch.int64, 8), ("bb31", torch.int32, 4), ("bls12_381", torch.int64, 32), ("bn254", torch.int64, 32)):
-    for lg in (16, 20, 22, 24) + ((26,) if eb < 32 else ()):
+    if field not in FIELDS:
+        continue
+    for lg in LGS or ((16, 20, 22, 24) + ((26,) if eb < 32 else ())):
         n = 1 << lg
         x = torch.randint(0, 2**30, (n * (eb // 8 if eb >= 8 else 1),), dtype=dt, device="cuda")
         res = []

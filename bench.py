@@ -10,6 +10,8 @@ HBM, on N GPUs of one node.  A step = one full MSM.
                         combine on every rank -- "MSM points/sec (2^26) at 1/2/4/8 GPUs"
   --total-lg 28         strong scaling at 2^28 total (configs[3]: 2^25 per rank on 8 GPUs)
   --scaling weak        2^lg points PER RANK (a 2^lg * N-point MSM)
+  --backend gloo        dry run of the world > 1 control flow on a 1-GPU box: the ranks share the GPU and
+                        exchange through host memory (tests/test_bench_multirank_gpu.py); not a measurement
 
 Inputs follow poc/msm-cuda/src/util.rs:11-38: 2^11 distinct points replicated cyclically
 (point 3 = infinity), independent uniform scalars on [0, r) (rejection sampled).
@@ -78,20 +80,29 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--groups", type=int, default=0, help="window groups of the MSM pipeline (0 = automatic)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="exchange backend: nccl = RCCL over xGMI, one GPU per rank (what the driver runs); gloo = the ranks "
+                         "share the visible GPU(s) round-robin and exchange through host memory -- a dry run of the whole "
+                         "world > 1 control flow on a 1-GPU box, never a performance number")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())         # dry run: ranks share the visible devices
     torch.cuda.set_device(local_rank)
     dist = None
-    # SPPARK_FORCE_DIST=1 exercises the RCCL exchange with a single rank (1-GPU boxes)
+    # SPPARK_FORCE_DIST=1 exercises the exchange with a single rank (1-GPU boxes)
     use_dist = world > 1 or os.environ.get("SPPARK_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     assert args.gpus == world, "--gpus must equal WORLD_SIZE"
 
     scaling = args.scaling
@@ -101,9 +112,12 @@ def main():
         total = 1 << args.lg
     else:
         total = world << args.lg
-    lo, hi = multi_gpu.shard_bounds(total, world, rank)
-    assert lo % PERIOD == 0 and (hi - lo) % PERIOD == 0, "shards must be multiples of the point period"
+    # contiguous shards in whole periods of the point list (any rank count: 3, 5, 6, 7 GPUs give shards that
+    # differ by one period), so that every shard folds onto the same 2048 distinct points for the checker
+    assert total % PERIOD == 0, "the MSM must be a whole number of point periods"
+    lo, hi = (PERIOD * v for v in multi_gpu.shard_bounds(total // PERIOD, world, rank))
     n = hi - lo                                                  # this rank's points
+    assert n > 0, "more ranks than point periods"
 
     pts, base = synth.replicated_points(n, "bls12_381", PERIOD, 0x5eed5eed0001)
     sc = synth.uniform_scalars(n, "bls12_381", 0x5eed5eed0001 + rank)
@@ -136,7 +150,7 @@ def main():
     elapsed = time.perf_counter() - t0
     acc_launches = int(ctx.kernel_ms(3))
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -317,6 +331,26 @@ def main():
             host["2^%d" % lgh] = {"points": m, "seconds": dt, "points_per_s": m / dt, "equals_oracle": ok}
             del hp, hs
         extras["mult_pippenger_inf_host_buffers"] = host
+        # the per-GPU shards of the headline MSM at N = 2 / 4 / 8 on THIS GPU (device-resident, same inputs): an upper
+        # bound for strong scaling read off a 1-GPU line (t_shard, before the all-gather); each result asserted
+        shard = {}
+        for lgs in (25, 24, 23, 20, 16):
+            if lgs >= args.lg:
+                continue
+            m = 1 << lgs
+            sp, ss = pts[:m], sc[:m]
+            sout = ctx.invoke(sp, ss)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            reps = 3 if lgs >= 23 else 20
+            for _ in range(reps):
+                sout = ctx.invoke(sp, ss)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / reps * 1e3
+            sexp = O.msm_affine(O.BLS12_381, base.cpu().numpy(), fold.fold_scalars(ss, PERIOD, r_mod), algo=0, param=8)
+            ok = bool((sppark_amd.to_affine(sout) == sexp).all())
+            assert ok, "shard-size MSM differs from the oracle"
+            shard["msm_ms_at_2^%d" % lgs] = {"ms": ms, "points_per_s": m / (ms * 1e-3), "windows": ctx.plan(m)["windows"], "equals_oracle": ok}
+        extras["shard_sizes"] = shard
         sppark_amd.ffi.load("bls12_381").sppark_msm_release_cached()
 
     cpu = None
@@ -374,6 +408,7 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
         mads = float(nwins) * n * MADS_PER_MIXED_ADD
+        xchg = "RCCL" if args.backend == "nccl" else "gloo (DRY RUN: ranks share a GPU, not a performance number)"
         line = {
             "metric": "MSM points/sec (BLS12-381 G1, 2^%d points%s)" % (total.bit_length() - 1, " in total over %d GPUs" % world if world > 1 else ""),
             "value": total * args.steps / elapsed, "unit": "points/s",
@@ -384,8 +419,9 @@ def main():
                                    % (total.bit_length() - 1, n,
                                       "BASELINE configs[2]" if world == 1 and total == 1 << 26 else
                                       "BASELINE configs[3]" if total == 1 << 28 else
-                                      "BASELINE metric: the 2^26 MSM sharded x%d, RCCL all-gather of partial sums" % world if total == 1 << 26 else
-                                      "sharded x%d, RCCL all-gather of partial sums" % world),
+                                      "BASELINE metric: the 2^26 MSM sharded x%d, %s all-gather of partial sums" % (world, xchg) if total == 1 << 26 else
+                                      "sharded x%d, %s all-gather of partial sums" % (world, xchg)),
+                       "backend": args.backend if use_dist else None,
                        "curve": "bls12_381", "points_total": total, "points_per_gpu": n,
                        "window_bits": plan["window_bits"], "windows": nwins, "window_groups": acc_launches,
                        "distinct_points": PERIOD, "scalars": "uniform on [0, r), rejection sampled"},

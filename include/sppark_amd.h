@@ -135,6 +135,14 @@ SppError sppark_msm_multi(void *out, const void *points, size_t npoints, const v
 SppError sppark_msm_multi_shards(void *out, const void *const *points, const size_t *npoints,
                                  const void *const *scalars, int mont, size_t ffi_affine_sz,
                                  unsigned nshards, const int *device_ids);
+/* The same two with per-device timings: out_ms[i] = wall-clock milliseconds shard i's device spent on its MSM
+ * (host-to-device copies included), ndev / nshards entries -- load imbalance between the devices is visible
+ * to the caller (with ndev == 0 provide sppark_ngpus() entries). */
+SppError sppark_msm_multi_ms(void *out, const void *points, size_t npoints, const void *scalars,
+                             int mont, size_t ffi_affine_sz, unsigned ndev, float *out_ms);
+SppError sppark_msm_multi_shards_ms(void *out, const void *const *points, const size_t *npoints,
+                                    const void *const *scalars, int mont, size_t ffi_affine_sz,
+                                    unsigned nshards, const int *device_ids, float *out_ms);
 
 typedef struct sppark_msm_ctx sppark_msm_ctx;
 
@@ -156,6 +164,11 @@ SppError sppark_msm_tune_split(sppark_msm_ctx *ctx, unsigned big_partition);
 /* bucket sums: windows with at most top_items partial sums are finished by the subset-sum kernels
  * (k_bucket_top_bits / k_bucket_top_sum); 0 = automatic (4096), 1 = never */
 SppError sppark_msm_tune_sums(sppark_msm_ctx *ctx, unsigned top_items);
+/* The tail of an MSM.  join: 0 = the record segments of at most eight records (with uniform scalars: all
+ * of them) are summed by one launch (k_join_runs) and the fan-in tree only sees the longer ones; 1 = every
+ * segment goes through the tree.  k1: buckets per work item of the first bucket-sum level (a power of
+ * two; 0 = the same as the other levels). */
+SppError sppark_msm_tune_tail(sppark_msm_ctx *ctx, unsigned join, unsigned k1);
 /* Pipeline shape.  groups: the windows are sorted and accumulated in this many groups, the digits +
  * sort of group g+1 on a second stream beside the bucket accumulation of group g (0 / 1 = one group,
  * the default: on MI355X the overlap gains nothing; more groups shrink the sort
@@ -224,14 +237,15 @@ SppError sppark_lde(size_t device_id, void *inout, uint32_t lg_domain_size, uint
 /* NTT::LDE_powers(stream, d_inout, lg) (ntt.cuh:352-356): d_inout[i] *= g^bitrev(i), device buffer */
 SppError sppark_lde_powers(size_t device_id, void *d_inout, uint32_t lg_domain_size, void *stream);
 /* NTT::LDE_expand (ntt.cuh:358-365): d_out[i << lg_blowup] = d_in[i], zeros elsewhere; device
- * buffers.  Unlike the reference (which accepts d_in aligned to the end of d_out and pays a
- * grid-wide sync for it) the two buffers must not overlap: invalid-value error otherwise. */
+ * buffers.  As in the reference the two buffers either do not overlap or d_in is aligned to the END
+ * of d_out (d_in == d_out + 2^(lg_domain_size+lg_blowup) - 2^lg_domain_size, lg_blowup >= 1): the
+ * expansion is then done in place.  Any other overlap is an invalid-value error. */
 SppError sppark_lde_expand(size_t device_id, void *d_out, const void *d_in, uint32_t lg_domain_size,
                            uint32_t lg_blowup, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* 3. Polynomial primitives over the library's NTT field (every library)      */
-/*    C++ templates only in the reference (polynomial/*.cuh); buffers host or */
+/*    C++ templates only in the reference (polynomial/<name>.cuh); buffers host or */
 /*    device, elements in the wire format of compute_ntt.                     */
 /* ------------------------------------------------------------------------ */
 

@@ -18,7 +18,7 @@ extern template __global__ void k_bitmap_accumulate<msm_fp_d, true>(u32*, bucket
 extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                     unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<msm_fp_d>(bucket_m*, u32*, const u32*, const bucket_m*, unsigned, u32*);
-extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_bits<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
@@ -32,7 +32,7 @@ extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, buck
 extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
                                                      unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<fp2_d>(bucket2_m*, u32*, const u32*, const bucket2_m*, unsigned, u32*);
-extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
                                                        unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_bits<fp2_d>(bucket2_m*, const bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned);
@@ -43,6 +43,7 @@ extern template __global__ void k_bucket_top_sum<fp2_d>(bucket2_m*, const bucket
 #include "../ff/fp2_host.hpp"
 #include "../msm/msm_driver.hpp"
 #include "common_api.hpp"
+#include <chrono>
 #include <map>
 #include <memory>
 
@@ -147,25 +148,39 @@ static RustError one_shot(void* out, const void* points, size_t npoints, const v
 // device_ids[i] on its own host thread with a context of its own; the partial results are added
 // on the host.  Sum_i s_i*P_i splits over any partition of the index set, so there is exactly
 // one exchange step, of 144-byte points.
+// |out_ms| (nullable): wall-clock milliseconds of every shard's MSM on its host thread (copies included), so that
+// a caller sees load imbalance between the devices.
 static void msm_shards(point_t& out, const void* const* points, const size_t* npoints, const void* const* scalars,
-                       bool mont, size_t ffi_sz, unsigned nshards, const int* device_ids)
+                       bool mont, size_t ffi_sz, unsigned nshards, const int* device_ids, float* out_ms = nullptr)
 {
     out.set_inf();
     if (nshards == 0) return;
     std::vector<point_t> part(nshards);
     std::vector<RustError> err(nshards, rust_ok());
     auto work = [&](unsigned i) {
+        if (out_ms) out_ms[i] = 0.f;
         err[i] = guarded([&] {
             part[i].set_inf();
             if (npoints[i] == 0) return;
-            borrowed<msm_impl> msm(device_ids ? device_ids[i] : (int)i);
+            const auto t0 = std::chrono::steady_clock::now();
+            borrowed<msm_impl> msm(device_ids ? device_ids[i] : (int)i);    // selects the shard's device
+            // device-resident shards may have been produced on ANY stream of that device (as in one_shot())
+            if (is_device_pointer(points[i]) || is_device_pointer(scalars[i])) HIP_OK(hipDeviceSynchronize());
             msm->invoke(part[i], points[i], npoints[i], scalars[i], mont, ffi_sz);
+            if (out_ms) out_ms[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
     };
     int cur = -1;
     (void)hipGetDevice(&cur);
     std::vector<std::thread> threads;
-    for (unsigned i = 1; i < nshards; i++) threads.emplace_back(work, i);
+    try {
+        for (unsigned i = 1; i < nshards; i++) threads.emplace_back(work, i);
+    } catch (...) {                             // thread creation failed: the ones already running must be joined
+        for (auto& t : threads) t.join();
+        for (auto& e : err) free(e.message);
+        if (cur >= 0) (void)hipSetDevice(cur);
+        throw;
+    }
     work(0);
     for (auto& t : threads) t.join();
     if (cur >= 0) (void)hipSetDevice(cur);      // shard 0 ran on this thread and selected its device
@@ -236,8 +251,8 @@ SPPARK_FFI size_t sppark_ngpus(void) { return gpus_t::all().size(); }
 // Multi-GPU G1 MSM in one process: the vector is cut into ndev contiguous shards (shard i =
 // [i*n/ndev, (i+1)*n/ndev)) that run concurrently on devices 0..ndev-1; ndev == 0 = all devices.
 // points / scalars: HOST pointers (each device copies its own shard, chunk by chunk).
-SPPARK_FFI RustError sppark_msm_multi(void* out, const void* points, size_t npoints, const void* scalars,
-                                      int mont, size_t ffi_affine_sz, unsigned ndev)
+static RustError msm_multi_impl(void* out, const void* points, size_t npoints, const void* scalars,
+                                int mont, size_t ffi_affine_sz, unsigned ndev, float* out_ms)
 {
     store_inf(out);
     return guarded([&] {
@@ -257,16 +272,24 @@ SPPARK_FFI RustError sppark_msm_multi(void* out, const void* points, size_t npoi
             ids[i] = (int)i;
         }
         point_t r;
-        msm_shards(r, p.data(), n.data(), s.data(), mont != 0, ffi_affine_sz, ndev, ids.data());
+        msm_shards(r, p.data(), n.data(), s.data(), mont != 0, ffi_affine_sz, ndev, ids.data(), out_ms);
         store_point(out, r);
     });
 }
+SPPARK_FFI RustError sppark_msm_multi(void* out, const void* points, size_t npoints, const void* scalars,
+                                      int mont, size_t ffi_affine_sz, unsigned ndev)
+{   return msm_multi_impl(out, points, npoints, scalars, mont, ffi_affine_sz, ndev, nullptr);   }
+// the same, and out_ms[i] = wall-clock milliseconds device i spent on its shard (ndev entries; with ndev == 0
+// the caller provides sppark_ngpus() entries)
+SPPARK_FFI RustError sppark_msm_multi_ms(void* out, const void* points, size_t npoints, const void* scalars,
+                                         int mont, size_t ffi_affine_sz, unsigned ndev, float* out_ms)
+{   return msm_multi_impl(out, points, npoints, scalars, mont, ffi_affine_sz, ndev, out_ms);   }
 // The general form: nshards independent (points, npoints, scalars) triples, shard i on device
 // device_ids[i] (index in the filtered list; NULL = device i).  Pointers may be host pointers or
 // pointers into the memory of the shard's own device.  A device may appear more than once.
-SPPARK_FFI RustError sppark_msm_multi_shards(void* out, const void* const* points, const size_t* npoints,
-                                             const void* const* scalars, int mont, size_t ffi_affine_sz,
-                                             unsigned nshards, const int* device_ids)
+static RustError msm_multi_shards_impl(void* out, const void* const* points, const size_t* npoints,
+                                       const void* const* scalars, int mont, size_t ffi_affine_sz,
+                                       unsigned nshards, const int* device_ids, float* out_ms)
 {
     store_inf(out);
     return guarded([&] {
@@ -278,10 +301,18 @@ SPPARK_FFI RustError sppark_msm_multi_shards(void* out, const void* const* point
             if (id < 0 || (size_t)id >= avail) HIP_OK(hipErrorInvalidDevice);
         }
         point_t r;
-        msm_shards(r, points, npoints, scalars, mont != 0, ffi_affine_sz, nshards, device_ids);
+        msm_shards(r, points, npoints, scalars, mont != 0, ffi_affine_sz, nshards, device_ids, out_ms);
         store_point(out, r);
     });
 }
+SPPARK_FFI RustError sppark_msm_multi_shards(void* out, const void* const* points, const size_t* npoints,
+                                             const void* const* scalars, int mont, size_t ffi_affine_sz,
+                                             unsigned nshards, const int* device_ids)
+{   return msm_multi_shards_impl(out, points, npoints, scalars, mont, ffi_affine_sz, nshards, device_ids, nullptr);   }
+SPPARK_FFI RustError sppark_msm_multi_shards_ms(void* out, const void* const* points, const size_t* npoints,
+                                                const void* const* scalars, int mont, size_t ffi_affine_sz,
+                                                unsigned nshards, const int* device_ids, float* out_ms)
+{   return msm_multi_shards_impl(out, points, npoints, scalars, mont, ffi_affine_sz, nshards, device_ids, out_ms);   }
 
 SPPARK_FFI RustError sppark_msm_create(sppark_msm_ctx** ctx, int device_id, void* stream)
 {
@@ -309,6 +340,15 @@ SPPARK_FFI RustError sppark_msm_tune_split(sppark_msm_ctx* ctx, unsigned big_par
 // bucket sums: windows with at most this many partial sums go to the subset-sum top (0 = automatic, 1 = never)
 SPPARK_FFI RustError sppark_msm_tune_sums(sppark_msm_ctx* ctx, unsigned top_items)
 {   return guarded([&] { ctx->impl.tune.top = top_items; });   }
+// the tail of an MSM: join = 1 switches k_join_runs off (every record segment through the fan-in tree);
+// k1 = buckets per work item of the first bucket-sum level (a power of two; 0 = as the other levels)
+SPPARK_FFI RustError sppark_msm_tune_tail(sppark_msm_ctx* ctx, unsigned join, unsigned k1)
+{
+    return guarded([&] {
+        if (k1 & (k1 - 1)) HIP_OK(hipErrorInvalidValue);
+        ctx->impl.tune.join = join; ctx->impl.tune.K1 = k1;
+    });
+}
 // pipeline shape: window groups (0 = automatic, 1 = single stream), points per chunk of the
 // chunked path (0 = automatic), upper bound of the scratch memory in bytes (0 = what the device has)
 SPPARK_FFI RustError sppark_msm_tune_pipeline(sppark_msm_ctx* ctx, unsigned groups, size_t chunk_points, size_t max_scratch_bytes)

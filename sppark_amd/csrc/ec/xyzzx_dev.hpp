@@ -84,7 +84,7 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         if (is_inf()) { set(p, negate); return; }
 
         F U2, S2;
-        F::mul2(U2, S2, p.X, ZZ, p.Y, ZZZ);                 // n, < 2p (pairs of products are interleaved)
+        F::template mul2<true, true>(U2, S2, p.X, ZZ, p.Y, ZZZ);   // all four operands n: < 2p, n (pairs of products are interleaved)
         if (negate) S2 = F::template neg<3>(S2);            // < 3p, limbs <= 2*2^LB
         F Pd = F::template sub<11, 6>(U2, X).norm();        // U2 - X      < 13p, n
         F Rd = F::template sub<6, 4>(S2, Y).norm();         // +-S2 - Y    < 9p, n
@@ -92,7 +92,7 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         if (!Pd.template is_zero_mod<13>()) {               // fast path
             F PP, RR, PPP, Q;
             F::sqr2(PP, RR, Pd, Rd);                        // n, < 2p
-            F::mul2(PPP, Q, Pd, PP, X, PP);                 // left operand of the second one fat: allowed
+            F::template mul2<true, false>(PPP, Q, Pd, PP, X, PP);  // Pd n; the left operand of the second one fat: allowed
             F T   = PPP + Q + Q;                            // < 6p, limbs <= 3*(2^LB - 1)
             F X3  = F::template sub<8, 3>(RR, T);           // < 10p, limbs <= 5*2^LB
             F D   = F::template sub<11, 6>(Q, X3);          // Q - X3      < 13p, limbs < 2^31
@@ -101,7 +101,7 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
             // the result's limbs are < 5*2^LB)
             F nY  = F::template neg<6, 4>(Y);               // < 6p
             Y   = F::mul_add(D, Rd, nY, PPP);               // < (13*9 + 6*2)p/rho + p < 2p, n
-            F::mul2(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);
+            F::template mul2<true, true>(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);       // n x n
             X = X3;
         } else if (Rd.template is_zero_mod<9>()) {          // same point: 2*p
             F y2 = negate ? F::template neg<3>(p.Y).norm() : p.Y;       // n, < 3p

@@ -268,14 +268,31 @@ template<class P, int LB> struct montx_dev {
         }
         return r;
     }
+    // The Montgomery quotient digit of column k.  m = A * (-1/p) mod 2^LB makes A + m*p divisible by 2^LB;
+    // so does any m' = m (mod 2^LB), and m' = the low 32 bits of A * (-1/p) saves the mask.  It costs
+    // head-room: m' < 2^32 makes the m*p terms of a column 16 times larger and adds (m' - m) * p / 2^LB
+    // <= 16 p / 2^LB to the value per later column -- negligible except for the LAST digit, which stays
+    // masked.  FAT_M is therefore allowed only when BOTH operands are normalised:
+    //   NL * (2^32 * 2^LB + 2^LB * 2^LB) + carry < 2^64   (static_assert below),
+    // and the result is < a*b/2^RBITS + (1 + 2^-20) p, normalised as before.
+    template<bool FAT_M> SPPARK_DEVFN static u32 quotient_digit(u64 A, int k)
+    {
+        constexpr u32 PINV = P::M0 & MASK;
+        static_assert(!FAT_M || (double)NL * (4294967296.0 * (double)(1ull << LB) + (double)(1ull << LB) * (double)(1ull << LB))
+                      + 68719476736.0 < 18446744073709551616.0, "unmasked quotient digits need the head-room of normalised operands");
+        if (FAT_M && k < NL - 1) return (u32)A * (u32)P::M0;
+        return ((u32)A * PINV) & MASK;
+    }
+
     // Two independent products with their multiply-add chains interleaved: a v_mad_u64_u32
     // that feeds the next one through its addend costs an extra wait state (and hipcc pads
     // it with an s_nop); alternating two accumulators hides it and halves the padding.
+    // NORM0 / NORM1: the left operand of that product is normalised too (unmasked quotient digits).
+    template<bool NORM0 = false, bool NORM1 = false>
     SPPARK_DEVFN static void mul2(montx_dev& r0, montx_dev& r1,
                                   const montx_dev& a0, const montx_dev& b0,
                                   const montx_dev& a1, const montx_dev& b1)
     {
-        constexpr u32 PINV = P::M0 & MASK;
         u32 m0[NL], m1[NL];
         u64 A0 = 0, A1 = 0;
         #pragma unroll
@@ -288,7 +305,7 @@ template<class P, int LB> struct montx_dev {
                 for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], mod_limb(k - i));
             }
             if (k < NL) {
-                m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
+                m0[k] = quotient_digit<NORM0>(A0, k); m1[k] = quotient_digit<NORM1>(A1, k);
                 macxs2(A0, m0[k], A1, m1[k], mod_limb(0));
             } else {
                 r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
@@ -343,10 +360,10 @@ template<class P, int LB> struct montx_dev {
         return r;
     }
 
-    // two squares, interleaved likewise (inputs normalised)
+    // two squares, interleaved likewise (inputs normalised: unmasked quotient digits -- a cross term uses
+    // the doubled limb, (NL/2) * 2^(2LB+1) per column, the same bound as NL * 2^(2LB))
     SPPARK_DEVFN static void sqr2(montx_dev& r0, montx_dev& r1, const montx_dev& a0, const montx_dev& a1)
     {
-        constexpr u32 PINV = P::M0 & MASK;
         u32 m0[NL], m1[NL], d0[NL], d1[NL];
         #pragma unroll
         for (int j = 0; j < NL; j++) { d0[j] = a0.l[j] << 1; d1[j] = a1.l[j] << 1; }
@@ -366,7 +383,7 @@ template<class P, int LB> struct montx_dev {
                 for (int i = lo; i <= hi; i++) if (i < k) macxs2(A0, m0[i], A1, m1[i], mod_limb(k - i));
             }
             if (k < NL) {
-                m0[k] = ((u32)A0 * PINV) & MASK; m1[k] = ((u32)A1 * PINV) & MASK;
+                m0[k] = quotient_digit<true>(A0, k); m1[k] = quotient_digit<true>(A1, k);
                 macxs2(A0, m0[k], A1, m1[k], mod_limb(0));
             } else {
                 r0.l[k - NL] = (u32)A0 & MASK; r1.l[k - NL] = (u32)A1 & MASK;
@@ -417,10 +434,10 @@ template<class P, int LB> struct montx_dev {
     // the low limb filters out almost everything before the exact comparison.
     template<int KMAX> SPPARK_DEVFN bool is_zero_mod() const
     {
-        bool maybe = false;
-        #pragma unroll
-        for (int k = 0; k < KMAX; k++) maybe |= (l[0] == multiples_tab<KMAX>::T.l[k][0]);
-        if (!maybe) return false;
+        // k*p has the low limb l[0] iff k = l[0] / p (mod 2^LB): one multiply by M0 = -1/p and one compare
+        // instead of KMAX compares of the low limb (13 + 13 scalar ORs per mixed addition)
+        const u32 k = (0u - l[0] * (u32)P::M0) & MASK;
+        if (k >= (u32)KMAX) return false;
         bool hit = false;
         #pragma unroll 1
         for (int k = 0; k < KMAX; k++) {                    // rare: keep it small, not unrolled over k

@@ -33,6 +33,8 @@
 #include "../ec/jacobian_host.hpp"
 #include "../util/runtime.hpp"
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace sppark_amd {
@@ -45,6 +47,7 @@ struct msm_plan {
     unsigned nslabs, slab_sz;           // hist/scatter point slabs
     unsigned F;                         // reduce_runs fan-in
     unsigned K;                         // bucket-reduction chunk
+    unsigned K1;                        // ... of the first level (buckets per work item)
     unsigned G, wpg;                    // window groups, windows per group (the last group may be shorter)
 };
 
@@ -54,6 +57,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned groups = 0;                // window groups (1 = everything on one stream)
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree)
+    unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
 };
@@ -96,6 +100,7 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.F = std::max(4u, t.F ? t.F : 8u);        // fan-in < 3 would never shrink the record list
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
+    p.K1 = std::min(t.K1 ? t.K1 : p.K, p.NB);
     // window groups: ONE by default.  Measured on MI355X (profiles/r02_msm_groups.log): whatever
     // the sort of the next group gains by running beside k_accumulate, the accumulation loses --
     // 2^26 points: 168.5 ms with one group, 169-190 ms with 2..12 groups, with the sort stream on
@@ -188,7 +193,7 @@ private:
         l.keyA = take(nrecA * 4); l.ptA = take(nrecA * sizeof(bucket_t));
         l.keyB = take(nrecB * 4); l.ptB = take(nrecB * sizeof(bucket_t));
         l.keyC = take(nrecA * 4); l.flag = take(4);                 // k_join_runs: filtered keys, "a long segment exists"
-        size_t n1 = (size_t)p.nwins * (p.NB / p.K);
+        size_t n1 = (size_t)p.nwins * (p.NB / p.K1);
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n1 * sizeof(bucket_t)); l.W2 = take(n1 * sizeof(bucket_t));
         l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
@@ -223,6 +228,18 @@ private:
         h_sums_cap = count;
     }
     void need_event(hipEvent_t& e) { if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+    // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised at most once per (device, kernel, size step)
+    // in the process: the call costs a few microseconds of host time on every launch path otherwise
+    void lds_attr(const void* fn, size_t bytes)
+    {
+        static std::mutex m;
+        static std::map<std::pair<int, const void*>, size_t> done;
+        std::lock_guard<std::mutex> lk(m);
+        size_t& have = done[std::make_pair(gpu->hip_id, fn)];
+        if (bytes <= have) return;
+        HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
     void need_aux()
     {
         if (aux) return;
@@ -327,8 +344,10 @@ public:
     {
         HIP_OK(hipSetDevice(gpu->hip_id));
         size_t chunk = choose_chunk(npoints, (host_points ? ffi_affine_sz : 0) + (host_scalars ? SCALAR_BYTES : 0));
-        msm_plan p = make_plan(chunk, FRp::NBITS, tune);
-        reserve(make_layout(p, true).total);
+        // as invoke(): one plan for the full chunks, one for the shorter last one, scratch for the larger
+        const size_t nchunks = (npoints + chunk - 1) / chunk;
+        msm_plan p = make_plan(chunk, FRp::NBITS, tune), p_last = make_plan(npoints - (nchunks - 1) * chunk, FRp::NBITS, tune);
+        reserve(std::max(make_layout(p, true).total, make_layout(p_last, true).total));
         if (host_points || host_scalars)
             reserve_stage(2 * (align_up(host_points ? chunk * ffi_affine_sz : 0) + align_up(host_scalars ? chunk * SCALAR_BYTES : 0)));
     }
@@ -413,7 +432,11 @@ private:
         };
         size_t limit = tune.max_scratch;
         if (!limit) {
-            if (need(chunk) <= blob_sz + stage_sz) return chunk;        // already reserved: no driver query
+            // already reserved (both allocations, each on its own: the scratch blob and the staging sets
+            // are separate hipMallocs): no driver query
+            const bool blob_ok = make_layout(make_plan(chunk, FRp::NBITS, tune), true).total <= blob_sz;
+            const bool stage_ok = stage_per_point == 0 || 2 * (chunk * stage_per_point + 512) <= stage_sz;  // two sets, each of two 256-byte aligned parts
+            if (blob_ok && stage_ok) return chunk;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return chunk; }
             limit = free_b - (free_b >> 5) + blob_sz + stage_sz;        // what this context may hold in total
@@ -442,12 +465,10 @@ private:
                            digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
         HIP_OK(hipGetLastError());
         size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + SORT_NT * 4 + (size_t)SORTB_STAGE * 4;
-        if (ldsA > 65536) {
-            HIP_OK(hipFuncSetAttribute((const void*)k_histA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
-            HIP_OK(hipFuncSetAttribute((const void*)k_scatterA, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA));
-        }
-        if (ldsB > 65536)
-            HIP_OK(hipFuncSetAttribute((const void*)k_sortB, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+        // (the attribute is per device and sticky: raised once to the largest size asked for so far,
+        // not on every MSM -- lds_attr())
+        if (ldsA > 65536) { lds_attr((const void*)k_histA, ldsA); lds_attr((const void*)k_scatterA, ldsA); }
+        if (ldsB > 65536) lds_attr((const void*)k_sortB, ldsB);
         hipLaunchKernelGGL(k_histA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
                            H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         HIP_OK(hipGetLastError());
@@ -459,7 +480,7 @@ private:
         HIP_OK(hipGetLastError());
         if (p.NA <= SCATA_MAX_NA && p.LB < 16) {      // (always, with the automatic split: HB <= 12)
             const size_t ldsS = scatterA_staged_lds(p.NA);
-            HIP_OK(hipFuncSetAttribute((const void*)k_scatterA_staged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsS));
+            lds_attr((const void*)k_scatterA_staged, ldsS);
             hipLaunchKernelGGL(k_scatterA_staged, dim3(p.nslabs, wn), dim3(SORT_NT), ldsS, ss,
                                partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         } else
@@ -498,7 +519,10 @@ private:
         u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
         // (the bucket fill and the point conversion do not depend on the sort, but running them beside
         // it on the second stream gains nothing: 157.0 -> 157.8 ms at 2^26, tools/gpu_r2_job11.sh)
-        HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
+        // With ONE window group the bucket offsets of every window are still there when the bucket sums run:
+        // empty buckets are recognised from them and never read (k_bucket_level1), so no memset.  With several
+        // groups the two offset sets are reused, and the buckets are cleared instead.
+        if (multi) HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
 
         for (unsigned g = 0; g < p.G; g++, gseq++) {
             // sort sets by the parity of a counter that keeps running across MSMs (chunks): the
@@ -569,21 +593,21 @@ private:
         bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
         bucket_t* result;
         {
-            unsigned nitems = p.NB / p.K;
+            unsigned nitems = p.NB / p.K1;
             size_t nthr = (size_t)p.nwins * nitems;
             hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                               A1, W1, buckets, p.NB, p.K, p.nwins);
+                               A1, W1, buckets, p.NB, p.K1, p.nwins, multi ? (const u32*)nullptr : (const u32*)(blob + l.off[0]));
             HIP_OK(hipGetLastError());
-            unsigned lgG = lg2_floor(p.K);
+            unsigned lgG = lg2_floor(p.K1);
             bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
             while (nitems > 1) {
                 // the top of the sums by bit-weighted subset sums (msm_kernels.hpp k_bucket_top_bits): depth, not work
                 if (nitems <= (tune.top ? tune.top : BUCKET_TOP_MAX) && nitems >= 32 && (nitems & (nitems - 1)) == 0
-                    && (size_t)p.NB / p.K >= 32) {
+                    && (size_t)p.NB / p.K1 >= 32) {
                     const unsigned m = lg2_floor(nitems);
                     const size_t img = (size_t)BUCKET_TOP_NT * sizeof(bucket_t);
                     if (img > 65536)
-                        HIP_OK(hipFuncSetAttribute((const void*)k_bucket_top_bits<fp_d>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img));
+                        lds_attr((const void*)k_bucket_top_bits<fp_d>, img);
                     hipLaunchKernelGGL(k_bucket_top_bits<fp_d>, dim3(m + 1, p.nwins), dim3(BUCKET_TOP_NT), img, stream,
                                        oa, ia, iw, nitems, m, lgG);
                     HIP_OK(hipGetLastError());

@@ -299,17 +299,29 @@ public:
     }
 
     // d_out[idx << lg_blowup] = d_in[idx] (* g^rev(idx) when |shift|), zeros elsewhere
-    // (NTT::LDE_expand / LDE_launch, ntt/ntt.cuh:247-281,358-365).  No overlap.
+    // (NTT::LDE_expand / LDE_launch, ntt/ntt.cuh:247-281,358-365).  The buffers either do not overlap or
+    // d_in is aligned to the END of d_out ("d_out is expected to encompass d_in and d_in is expected to be
+    // aligned to the end of d_out", ntt.cuh:358-360; any other overlap is an error, as the reference's
+    // assert, ntt/kernels.cu:176).  In place: output o needs input o >> lg_blowup, which sits at position
+    // P(o) = ext - dom + (o >> lg_blowup) >= o, so an output range [lo, hi) may be written in one launch
+    // as long as P(lo) >= hi: hi = ext - (ext - lo) / blowup.  The ranges shrink geometrically
+    // ([0, ext - dom), then dom (1 - 1/blowup) elements, ...): 2 + lg_domain / lg_blowup launches, kernel
+    // boundaries instead of the reference's cooperative grid sync (kernels.cu:199-200).
     void lde_spread(const gpu_info& gpu, F* d_out, const F* d_in, unsigned lg_domain, unsigned lg_blowup,
                     bool shift, hipStream_t stream)
     {
         if (lg_domain + lg_blowup > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
         const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
-        if ((d_in < d_out + ext) && (d_out < d_in + dom)) HIP_OK(hipErrorInvalidValue);
+        const bool overlap = (d_in < d_out + ext) && (d_out < d_in + dom);
+        if (overlap && (lg_blowup == 0 || d_in != d_out + (ext - dom))) HIP_OK(hipErrorInvalidValue);
         const table_set& ts = tables(gpu.hip_id, lg_domain, 0, stream);
         ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg_domain, ts.h, ts.scale, nullptr};
-        hipLaunchKernelGGL(k_lde_spread<F>, dim3((unsigned)((ext + 255) / 256)), dim3(256), 0, stream,
-                           d_out, d_in, G, lg_domain, lg_blowup, (int)shift);
+        for (size_t lo = 0; lo < ext;) {
+            const size_t hi = overlap ? ext - ((ext - lo) >> lg_blowup) : ext;
+            hipLaunchKernelGGL(k_lde_spread<F>, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, stream,
+                               d_out, d_in, G, lg_domain, lg_blowup, (int)shift, lo, hi);
+            lo = hi;
+        }
         HIP_OK(hipGetLastError());
     }
 

@@ -401,7 +401,10 @@ __global__ __launch_bounds__(256) void k_coset(F* data, ntt_tables<F> G, int bit
 // LDE spread (LDE_spread_distribute_powers, ntt/kernels.cu:155-237): the 2^lg_domain
 // inputs are in bit-reversed order; out[idx << lg_blowup] = in[idx] * g^(rev(idx))
 // (the coset shift, when |shift|), every other element of out is zero.  One work
-// item per OUTPUT element so the stores are coalesced; out and in must not overlap.
+// item per OUTPUT element so the stores are coalesced.  out and in either do not overlap or in is
+// aligned to the END of out (the reference's in-place form, ntt/ntt.cuh:358-360); the driver then
+// launches the kernel over output ranges that never contain an input still to be read
+// (ntt_driver.hpp lde_spread).
 template<class F>
 SPPARK_DEVFN void lde_spread_item(F* out, const F* in, const ntt_tables<F>& G, unsigned lg_domain,
                                   unsigned lg_blowup, int shift, size_t o)
@@ -418,12 +421,14 @@ SPPARK_DEVFN void lde_spread_item(F* out, const F* in, const ntt_tables<F>& G, u
     }
     out[o] = r;
 }
+// output elements [o_begin, o_end)
 template<class F>
 __global__ __launch_bounds__(256)
-void k_lde_spread(F* out, const F* in, ntt_tables<F> G, unsigned lg_domain, unsigned lg_blowup, int shift)
+void k_lde_spread(F* out, const F* in, ntt_tables<F> G, unsigned lg_domain, unsigned lg_blowup, int shift,
+                  size_t o_begin, size_t o_end)
 {
-    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < ((size_t)1 << (lg_domain + lg_blowup))) lde_spread_item(out, in, G, lg_domain, lg_blowup, shift, o);
+    size_t o = o_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < o_end) lde_spread_item(out, in, G, lg_domain, lg_blowup, shift, o);
 }
 // out[rev(i)] = in[i]  (out-of-place bit reversal: the aux output of LDE_aux, ntt/ntt.cuh:312-315)
 template<class F>

@@ -87,6 +87,8 @@ def load(name):
         L.sppark_msm_tune_sums.restype = _Error
         L.sppark_msm_tune_sort.argtypes = [vp, cu]
         L.sppark_msm_tune_sort.restype = _Error
+        L.sppark_msm_tune_tail.argtypes = [vp, cu, cu]
+        L.sppark_msm_tune_tail.restype = _Error
         L.sppark_msm_tune_pipeline.argtypes = [vp, cu, sz, sz]
         L.sppark_msm_tune_pipeline.restype = _Error
         L.sppark_msm_last_chunks.argtypes = [vp]
@@ -102,6 +104,11 @@ def load(name):
         L.sppark_msm_multi_shards.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ci, sz, cu,
                                               ctypes.POINTER(ci)]
         L.sppark_msm_multi_shards.restype = _Error
+        L.sppark_msm_multi_ms.argtypes = [vp, vp, sz, vp, ci, sz, cu, ctypes.POINTER(ctypes.c_float)]
+        L.sppark_msm_multi_ms.restype = _Error
+        L.sppark_msm_multi_shards_ms.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ci, sz, cu,
+                                                 ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float)]
+        L.sppark_msm_multi_shards_ms.restype = _Error
         L.sppark_msm_reserve.argtypes = [vp, sz, sz, ci, ci]
         L.sppark_msm_reserve.restype = _Error
         L.sppark_msm_invoke.argtypes = [vp, vp, vp, sz, vp, ci, sz]

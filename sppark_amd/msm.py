@@ -96,6 +96,11 @@ class MsmContext:
         """bucket sums: windows with at most this many partial sums use the subset-sum top (0 = automatic, 1 = never)"""
         ffi.check(self.L, self.L.sppark_msm_tune_sums(self.h, top_items))
 
+    def tune_tail(self, join=0, k1=0):
+        """join=1: no k_join_runs (every record segment through the fan-in tree); k1: buckets per work
+        item of the first bucket-sum level (0 = as the other levels)"""
+        ffi.check(self.L, self.L.sppark_msm_tune_tail(self.h, join, k1))
+
     def tune_pipeline(self, groups=0, chunk_points=0, max_scratch_bytes=0):
         """window groups (sort of group g+1 under the accumulation of group g), points per chunk
         of the chunked path, upper bound of the scratch memory; 0 = automatic"""
@@ -160,9 +165,10 @@ def ngpus(curve="bls12_381"):
     return int(ffi.load(curve).sppark_ngpus())
 
 
-def msm_multi(points, scalars, curve="bls12_381", ndev=0, mont=False, ffi_affine_sz=None):
+def msm_multi(points, scalars, curve="bls12_381", ndev=0, mont=False, ffi_affine_sz=None, timings=False):
     """sppark_msm_multi: one process, one host thread + context per device, contiguous shards of
-    HOST-resident inputs, partial sums added on the host.  Returns the Jacobian result."""
+    HOST-resident inputs, partial sums added on the host.  Returns the Jacobian result; with
+    timings=True (sppark_msm_multi_ms) also the wall-clock milliseconds of every device."""
     L = ffi.load(curve)
     fb = FP_BYTES[curve]
     stride = ffi_affine_sz or 2 * fb
@@ -172,11 +178,15 @@ def msm_multi(points, scalars, curve="bls12_381", ndev=0, mont=False, ffi_affine
     pp, _k1 = ffi.as_pointer(points)
     sp, _k2 = ffi.as_pointer(scalars)
     out = np.zeros(3 * fb, dtype=np.uint8)
+    if timings:
+        ms = (ctypes.c_float * (ndev or int(L.sppark_ngpus())))()
+        ffi.check(L, L.sppark_msm_multi_ms(out.ctypes.data, pp, n, sp, int(mont), stride, ndev, ms))
+        return out, [float(v) for v in ms]
     ffi.check(L, L.sppark_msm_multi(out.ctypes.data, pp, n, sp, int(mont), stride, ndev))
     return out
 
 
-def msm_multi_shards(shards, curve="bls12_381", device_ids=None, mont=False, ffi_affine_sz=None):
+def msm_multi_shards(shards, curve="bls12_381", device_ids=None, mont=False, ffi_affine_sz=None, timings=False):
     """sppark_msm_multi_shards: |shards| = [(points, scalars), ...], shard i on device
     device_ids[i] (default: device i); buffers may be host arrays or tensors on that device."""
     L = ffi.load(curve)
@@ -194,6 +204,10 @@ def msm_multi_shards(shards, curve="bls12_381", device_ids=None, mont=False, ffi
         P[i] = pp; S[i] = sp; N[i] = n
     ids = (ctypes.c_int * k)(*device_ids) if device_ids is not None else None
     out = np.zeros(3 * fb, dtype=np.uint8)
+    if timings:
+        ms = (ctypes.c_float * max(1, k))()
+        ffi.check(L, L.sppark_msm_multi_shards_ms(out.ctypes.data, P, N, S, int(mont), stride, k, ids, ms))
+        return out, [float(v) for v in ms][:k]
     ffi.check(L, L.sppark_msm_multi_shards(out.ctypes.data, P, N, S, int(mont), stride, k, ids))
     return out
 

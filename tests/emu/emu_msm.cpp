@@ -4,9 +4,22 @@
 // msm_kernels.hpp, ec/xyzz_dev.hpp, ff/mont_dev.hpp) for the host CPU with
 // -DSPPARK_HOST_EMULATION and runs the MSM pipeline by looping over the work
 // items the GPU grid would cover, in the order msm_driver.hpp launches them.
-// Purpose: exercise digit recoding, chunk walking / flush logic, record levels
-// and the bucket-sum levels in the GPU-less build container before spending
-// GPU minutes.  Results are compared with the oracle by tests/test_emulation.py.
+// Purpose: exercise digit recoding, chunk walking / flush logic, the short-segment
+// join, the record levels and the chunked bucket-sum levels in the GPU-less build
+// container before spending GPU minutes.  Results are compared with the oracle by
+// tests/test_emulation.py.
+//
+// WHAT IT COVERS: the product's own bodies of recode_digits / load_scalar_abs, accumulate_chunk,
+// join_runs_item, reduce_runs_chunk, bucket_level1_item / bucket_levelN_item, the point conversion
+// and finalisation, and the field / point classes' C paths.
+// WHAT IT DOES NOT: the sort.  The grouped index list is produced below by a PLAIN HOST COUNTING
+// SORT with the same output contract (indices grouped by bucket, offsets per bucket) -- it is not a
+// translation of msm_sort_kernels.hpp: the LDS-staged scatter (k_scatterA_staged), both k_sortB
+// paths, the k_big_* split for oversized partitions, the per-window k_lo width (window_lb), the
+// window-group indexing, the subset-sum top of the bucket sums (k_bucket_top_bits / _sum) and
+// k_bitmap_accumulate are work-group-level kernels (LDS, barriers, cross-lane scans) and are checked
+// by the GPU suite only (tests/test_msm_gpu.py: sort partition paths, oversized partitions,
+// bucket-sum top, window groups, bitmaps).
 #define SPPARK_HOST_EMULATION 1
 #include "../../sppark_amd/csrc/msm/curve_select.hpp"
 #include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
@@ -79,7 +92,7 @@ static void finalize_sum(M* out, const xyzz_mem<F::N>* in)
 
 extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                        const unsigned char* scalars, int mont,
-                       unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs)
+                       unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs, int join, unsigned* join_stats)
 {
 #ifdef SPPARK_G2                                 // the same pipeline over Fp2 (G2)
     typedef fp2_host<curve_p::fp> fp_h;
@@ -164,7 +177,9 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
 
     // ---- accumulate + record levels ----
     std::vector<inst_m> buckets((size_t)p.nwins * p.NB);
-    memset(buckets.data(), 0, buckets.size() * sizeof(inst_m));
+    // NOT cleared (as msm_driver.hpp with one window group): an empty bucket is recognised from the sort's
+    // offsets and never read -- garbage here would show up in the result if it were
+    memset(buckets.data(), 0xAB, buckets.size() * sizeof(inst_m));
     size_t nrecA = (size_t)2 * p.nwins * p.chunks_per_win, nrecB = 2 * ((nrecA + p.F - 1) / p.F);
     std::vector<u32> keyA(nrecA), keyB(nrecB);
     std::vector<inst_m> ptA(nrecA), ptB(nrecB);
@@ -185,6 +200,16 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     {
         size_t nrec = nrecA;
         u32 *ik = keyA.data(), *ok = keyB.data(); inst_m *ip = ptA.data(), *op = ptB.data();
+        // k_join_runs: segments of <= JOIN_WALK records are summed here; the tree sees the rest
+        std::vector<u32> keyC(nrecA);
+        u32 any_long = 0;
+        if (join) {
+            for (size_t t = 0; t < ((nrec / 2 + 1 + 255) / 256) * 256; t++)
+                join_runs_item<inst_fp>(buckets.data(), keyC.data(), keyA.data(), ptA.data(), (unsigned)nrec, &any_long, t);
+            ik = keyC.data();
+        }
+        if (join_stats) { join_stats[0] = any_long; join_stats[1] = 0; for (size_t i = 0; join && i < nrec; i++) join_stats[1] += keyC[i] != KEY_NONE; }
+        if (!join || any_long)
         for (;;) {
             unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
             int last = nthreads == 1;
@@ -200,7 +225,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     size_t n1 = (size_t)p.nwins * (p.NB / p.K);
     std::vector<inst_m> A1(n1), W1(n1), A2(n1), W2(n1);
     unsigned nitems = p.NB / p.K;
-    for (size_t id = 0; id < n1; id++) bucket_level1_item<inst_fp>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id);
+    for (size_t id = 0; id < n1; id++) bucket_level1_item<inst_fp>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id, off.data());
     unsigned lgG = lg2_floor(p.K);
     inst_m *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
     while (nitems > 1) {

@@ -33,7 +33,7 @@ def _emu(feature, g2=False):
     vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
     L.emu_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
     L.emu_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
-    L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu]
+    L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu, ci, vp]
     return L
 
 
@@ -74,7 +74,7 @@ def test_msm_pipeline_on_host(oracle, curve):
                                          (300, 2, 4, 4, 2, 1, False), (300, 16, 64, 32, 8, 1, False), (500, 19, 8, 8, 8, 2, True)):
         pts, sc = recipe.msm_inputs(curve, n, 1234 + n + wb, flagged=flagged)
         out = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns)
+        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
 
 
@@ -88,7 +88,7 @@ def test_msm_g2_pipeline_on_host(oracle, curve):
                                          (500, 7, 4, 4, 2, 3, False), (300, 11, 16, 8, 4, 2, True)):
         pts, sc = recipe.msm_inputs(curve, n, 4321 + n + wb, flagged=flagged)
         out = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns)
+        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
     # all points equal (doubling branch) and all scalars equal
     pts, sc = recipe.msm_inputs(curve, 400, 5, edge=False, flagged=True)
@@ -96,7 +96,7 @@ def test_msm_g2_pipeline_on_host(oracle, curve):
     s_eq = sc.copy(); s_eq[:] = sc[0]
     for p_, s_ in ((same, sc), (pts, s_eq)):
         out = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(out), P(p_), p_.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2)
+        L.emu_msm(P(out), P(p_), p_.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2, 1, None)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, p_, s_, algo=0, param=4)).all()
 
 
@@ -115,7 +115,7 @@ def test_msm_skewed_scalars_on_host(oracle):
     for s in cases:
         for p in (pts, same_pts):
             out = np.zeros(144, dtype=np.uint8)
-            L.emu_msm(P(out), P(p), 96, n, P(s), 0, 8, 8, 4, 4, 2)
+            L.emu_msm(P(out), P(p), 96, n, P(s), 0, 8, 8, 4, 4, 2, 1, None)
             assert (O.jac_to_affine(0, out) == O.msm_affine(0, p, s, algo=0, param=4)).all()
 
 
@@ -127,5 +127,29 @@ def test_msm_montgomery_scalars_on_host(oracle):
     for i in range(200):
         mont[i] = O.field_op(O.FIELD_BN_FR, 4, sc[i].view(np.uint64)).view(np.uint8)
     out = np.zeros(96, dtype=np.uint8)
-    L.emu_msm(P(out), P(pts), 64, 200, P(mont), 1, 0, 0, 0, 0, 0)
+    L.emu_msm(P(out), P(pts), 64, 200, P(mont), 1, 0, 0, 0, 0, 0, 1, None)
     assert (O.jac_to_affine(1, out) == O.msm_affine(1, pts, sc)).all()
+
+
+def test_msm_short_segment_join_on_host(oracle):
+    """k_join_runs (join_runs_item): with uniform scalars every bucket that straddles a chunk boundary is
+    a segment of a few records -- the join resolves all of them and the fan-in tree has nothing left;
+    with one bucket holding everything the segment is longer than the walk and goes through the tree.
+    Same group element with and without the join in both cases."""
+    O = oracle
+    L = _emu("BLS12_381")
+    n = 3000
+    pts, sc = recipe.msm_inputs(0, n, 99, edge=False)
+    s_eq = sc.copy(); s_eq[:] = sc[0]
+    s_two = sc.copy(); s_two[: n // 2] = sc[0]; s_two[n // 2:] = sc[1]
+    for s, wb, LL, expect_long in ((sc, 8, 16, False), (sc, 6, 8, None), (sc, 4, 4, None), (s_eq, 8, 8, True), (s_two, 8, 16, True)):
+        exp = O.msm_affine(0, pts, s, algo=0, param=4)
+        for join in (1, 0):
+            out = np.zeros(144, dtype=np.uint8)
+            stats = np.zeros(2, dtype=np.uint32)
+            L.emu_msm(P(out), P(pts), 96, n, P(s), 0, wb, LL, 4, 4, 2, join, P(stats))
+            assert (O.jac_to_affine(0, out) == exp).all(), (wb, LL, join)
+            if join and expect_long is not None:
+                assert bool(stats[0]) == expect_long, (wb, LL, stats)
+                if not expect_long:
+                    assert stats[1] == 0            # no record left for the tree

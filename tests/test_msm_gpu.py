@@ -787,6 +787,12 @@ def test_msm_multi_device_entry_points(oracle, libs):
         dev = [(torch.from_numpy(p).to("cuda:%d" % i), torch.from_numpy(s).to("cuda:%d" % i)) for (p, s), i in zip(shards, ids)]
         torch.cuda.synchronize()
         assert (sppark_amd.to_affine(sppark_amd.msm_multi_shards(dev, device_ids=ids)) == e_).all()
+        # the timed variants: same result, one wall-clock figure per shard (0 for the empty one)
+        out, ms = sppark_amd.msm_multi_shards(shards, device_ids=ids, timings=True)
+        assert (sppark_amd.to_affine(out) == e_).all() and len(ms) == len(shards)
+        assert ms[1] == 0.0 and all(v > 0 for i, v in enumerate(ms) if i != 1)
+    out, ms = sppark_amd.msm_multi(pts, sc, ndev=1, timings=True)
+    assert (sppark_amd.to_affine(out) == exp).all() and len(ms) == 1 and ms[0] > 0
 
 
 def test_one_shot_pool_is_not_tied_to_threads(oracle, libs):

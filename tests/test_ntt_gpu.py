@@ -265,9 +265,17 @@ def test_lde_vs_oracle(oracle, libs, field, lg, lgb):
     assert (d_out.cpu().numpy().view(dt).reshape(-1, w) == O.lde_expand(field, x, lgb).reshape(-1, w)).all()
     sppark_amd.LDE_powers(0, d_in, field)
     assert (d_in.cpu().numpy().view(dt).reshape(-1, w) == O.lde_powers(field, x).reshape(-1, w)).all()
+    # in place: d_in aligned to the END of d_out (ntt/ntt.cuh:358-360)
+    buf = torch.full((d_in.numel() << lgb,), 7, dtype=tdt, device="cuda")
+    tail = buf[buf.numel() - d_in.numel():]
+    tail.copy_(torch.from_numpy(np.ascontiguousarray(x).view(sdt).reshape(-1).copy()).cuda())
+    sppark_amd.LDE_expand(0, buf, tail, lg, lgb, field)
+    assert (buf.cpu().numpy().view(dt).reshape(-1, w) == O.lde_expand(field, x, lgb).reshape(-1, w)).all()
     from sppark_amd import ffi
-    with pytest.raises(ffi.SpparkError):                        # overlapping expand is refused
+    with pytest.raises(ffi.SpparkError):                        # any other overlap is refused
         sppark_amd.LDE_expand(0, d_out, d_out[:d_in.numel()], lg, lgb, field)
+    with pytest.raises(ffi.SpparkError):                        # inside d_out, but not at its end
+        sppark_amd.LDE_expand(0, d_out, d_out[d_in.numel() // 2:][:d_in.numel()], lg, lgb, field)
 
 
 def test_lde_large_properties(libs):

@@ -147,6 +147,56 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         }
     }
 
+    // The same addition with its products in interleaved PAIRS (two multiply-add chains in flight, quotient
+    // digits without masks where both operands are normalised): for the kernels at the top of the bucket sums,
+    // where a handful of waves -- one per SIMD at most -- run chains of dependent additions and the latency of
+    // one addition, not the register footprint, is what counts.
+    SPPARK_DEVFN void add_pairs(const xyzz_dev& q)
+    {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+        F U1, S1, U2, S2;
+        F::mul2(U1, S1, X, q.ZZ, Y, q.ZZZ);                 // fat left operands; n, < 2p
+        F::mul2(U2, S2, q.X, ZZ, q.Y, ZZZ);
+        F Pd = F::template sub<3>(U2, U1).norm();           // < 5p, n
+        F Rd = F::template sub<3>(S2, S1).norm();
+        if (!Pd.template is_zero_mod<5>()) {
+            F PP, RR, PPP, Q, t0, t1;
+            F::sqr2(PP, RR, Pd, Rd);
+            F::template mul2<true, true>(PPP, Q, Pd, PP, U1, PP);
+            F T   = PPP + Q + Q;
+            F X3  = F::template sub<8, 3>(RR, T);
+            F D   = F::template sub<11, 6>(Q, X3);
+            Y   = F::mul_add(D, Rd, F::template neg<3>(S1), PPP);
+            F::template mul2<true, true>(t0, t1, ZZ, PP, ZZZ, PPP);
+            F::template mul2<true, true>(ZZ, ZZZ, t0, q.ZZ, t1, q.ZZZ);
+            X = X3;
+        } else if (Rd.template is_zero_mod<5>()) {
+            xyzz_dev t = *this;
+            dbl_outlined(t);
+            *this = t;
+        } else {
+            set_inf();
+        }
+    }
+    // ... and the doubling: (V, M) and (W, S) as pairs
+    SPPARK_DEVFN void dbl_pairs()
+    {
+        if (is_inf()) return;
+        F Yn = Y.norm(), Xn = X.norm();                     // n, < 5p / < 10p
+        F U = (Yn + Yn).norm();                             // < 10p
+        F V, M, W, S, M3s;
+        F::sqr2(V, M, U, Xn);                               // < 2p
+        F::template mul2<true, true>(W, S, U, V, Xn, V);
+        F M3 = (M + M + M).norm();                          // < 6p
+        M3s = M3.sqr();
+        F X3 = F::template sub<5, 2>(M3s, S + S);           // < 7p, limbs <= 4*2^LB
+        F D  = F::template sub<8, 4>(S, X3);                // < 10p
+        Y = F::mul_add(D, M3, F::template neg<3>(W), Yn);
+        F::template mul2<true, true>(ZZ, ZZZ, ZZ, V, ZZZ, W);
+        X = X3;
+    }
+
 #if defined(SPPARK_HOST_EMULATION)
     static void dbl_outlined(xyzz_dev& t) { t.dbl(); }
 #else

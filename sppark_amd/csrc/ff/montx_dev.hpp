@@ -434,10 +434,14 @@ template<class P, int LB> struct montx_dev {
     // the low limb filters out almost everything before the exact comparison.
     template<int KMAX> SPPARK_DEVFN bool is_zero_mod() const
     {
-        // k*p has the low limb l[0] iff k = l[0] / p (mod 2^LB): one multiply by M0 = -1/p and one compare
-        // instead of KMAX compares of the low limb (13 + 13 scalar ORs per mixed addition)
-        const u32 k = (0u - l[0] * (u32)P::M0) & MASK;
-        if (k >= (u32)KMAX) return false;
+        // (A one-multiply filter -- k*p has the low limb l[0] iff k = l[0] / p mod 2^LB -- saves ~30 scalar and
+        // vector instructions per mixed addition, but hipcc then allocates 269 registers for k_accumulate
+        // instead of 238: ONE wave per SIMD, 151 ms instead of 114 at 2^26 points.  Measured and reverted,
+        // profiles/r03_msm_diet_ab.log; tests/test_build_resources.py now pins the register budget.)
+        bool maybe = false;
+        #pragma unroll
+        for (int kk = 0; kk < KMAX; kk++) maybe |= (l[0] == multiples_tab<KMAX>::T.l[kk][0]);
+        if (!maybe) return false;
         bool hit = false;
         #pragma unroll 1
         for (int k = 0; k < KMAX; k++) {                    // rare: keep it small, not unrolled over k

@@ -90,9 +90,10 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.HB = p.wbits - 1 - p.LB;
     p.NA = 1u << p.HB;
     size_t entries = (size_t)p.n * p.nwins;
-    // run length: 64 entries per lane, 128 from 2^24 points on (half the run records for the tree,
-    // still > 10^5 lanes per window; 2^26: 162.9 -> 161.3 ms, profiles/r02_msm_L_sweep.log)
-    unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(lg >= 24 ? 128 : 64, std::max<size_t>(4, entries / 262144));
+    // run length: 64 entries per lane, 128 from 2^22 points on, 256 from 2^25 (every chunk boundary costs one
+    // full addition in k_join_runs; the accumulation itself is flat in L as long as there are > 10^5 lanes per
+    // window.  2^23: tail 3.46 -> 2.67 ms with 128, 2^26: 11.5 -> 10.4 ms with 256, profiles/r03_msm_tail.log)
+    unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(lg >= 25 ? 256 : lg >= 22 ? 128 : 64, std::max<size_t>(4, entries / 262144));
     p.L = L;
     p.chunks_per_win = (p.n + L - 1) / L;
     p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
@@ -100,7 +101,8 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.F = std::max(4u, t.F ? t.F : 8u);        // fan-in < 3 would never shrink the record list
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
-    p.K1 = std::min(t.K1 ? t.K1 : p.K, p.NB);
+    // first level: 16 buckets per work item once a window has >= 2^21 of them (2^26 points: tail 11.35 -> 11.03 ms)
+    p.K1 = std::min(t.K1 ? t.K1 : (p.NB >= (1u << 21) ? 16u : p.K), p.NB);
     // window groups: ONE by default.  Measured on MI355X (profiles/r02_msm_groups.log): whatever
     // the sort of the next group gains by running beside k_accumulate, the accumulation loses --
     // 2^26 points: 168.5 ms with one group, 169-190 ms with 2..12 groups, with the sort stream on

@@ -409,6 +409,11 @@ template<class FP> SPPARK_DEVFN void bucket_add(xyzz_dev<FP>& a, const xyzz_dev<
 {   if constexpr (FP::N > 16) xyzz_add_outlined<FP>(a, b); else a.add(b);   }
 template<class FP> SPPARK_DEVFN void bucket_dbl(xyzz_dev<FP>& a)
 {   if constexpr (FP::N > 16) xyzz_dbl_outlined<FP>(a); else a.dbl();   }
+// the low-latency forms (products in interleaved pairs) where the field has them: the top of the bucket sums
+template<class FP> SPPARK_DEVFN void bucket_add_fast(xyzz_dev<FP>& a, const xyzz_dev<FP>& b)
+{   if constexpr (field_is_internal<FP>::value) a.add_pairs(b); else bucket_add<FP>(a, b);   }
+template<class FP> SPPARK_DEVFN void bucket_dbl_fast(xyzz_dev<FP>& a)
+{   if constexpr (field_is_internal<FP>::value) a.dbl_pairs(); else bucket_dbl<FP>(a);   }
 
 // ---------------------------------------------------------------------------
 // |off| (nullable): the bucket offsets of the sort, off[w * (NB + 1) + b].  A bucket is written by exactly
@@ -498,7 +503,7 @@ SPPARK_DEVFN void lds_tree_sum(xyzz_dev<FP>& acc, xyzz_mem<FP::N>* img, unsigned
     for (unsigned s = nt >> 1; s >= 1; s >>= 1) {
         if (tid >= s && tid < 2 * s) acc.store(&img[tid]);
         __syncthreads();
-        if (tid < s) bucket_add<FP>(acc, xyzz_dev<FP>::load(&img[tid + s]));
+        if (tid < s) bucket_add_fast<FP>(acc, xyzz_dev<FP>::load(&img[tid + s]));
         __syncthreads();
     }
 }
@@ -522,13 +527,13 @@ void k_bucket_top_bits(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N
     #pragma unroll 1
     for (unsigned i = 0; i < (1u << lgI); i++) {
         const unsigned j = lo | (i << p) | (hi << (p + lgI));
-        if (j < nitems && (b == m || ((j >> b) & 1))) bucket_add<FP>(acc, xyzz_dev<FP>::load(&src[j]));
+        if (j < nitems && (b == m || ((j >> b) & 1))) bucket_add_fast<FP>(acc, xyzz_dev<FP>::load(&src[j]));
     }
     lds_tree_sum<FP>(acc, img, tid, BUCKET_TOP_NT);
     if (tid == 0) {
         if (b < m) {
             #pragma unroll 1
-            for (unsigned k = 0; k < b + lgG; k++) bucket_dbl<FP>(acc);
+            for (unsigned k = 0; k < b + lgG; k++) bucket_dbl_fast<FP>(acc);
         }
         acc.store(&parts[(size_t)w * (m + 1) + b]);
     }

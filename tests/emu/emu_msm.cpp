@@ -68,6 +68,43 @@ extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size
     return 0;
 }
 
+// add_pairs / dbl_pairs (the low-latency forms used at the top of the bucket sums) against add / dbl on the
+// same operands, compared in the canonical wire form: |points| = n affine points in the wire format; returns
+// the number of mismatches (the fields without their own records have no such forms: 0).
+extern "C" int emu_pairs_check(const unsigned char* points, size_t stride, size_t n)
+{
+    int bad = 0;
+    if constexpr (field_is_internal<inst_fp>::value) {
+        typedef xyzz_dev<inst_fp> B;
+        std::vector<uint4> conv((size_t)n * affine_loader<inst_fp>::STRIDE / 16 + 1);
+        for (size_t i = 0; i < n; i++) affine_loader<inst_fp>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+        auto pt = [&](size_t i) { return load_affine<inst_fp, false>((const unsigned char*)conv.data(), i, 0); };
+        auto same = [&](const B& a, const B& b) {
+            xyzz_mem<sizeof(mont_host<curve_p::fp>) / 4> sa, sb;
+            a.store_std(&sa); b.store_std(&sb);
+            // XYZZ representatives differ between formulas only by the common factor; both run the SAME formulas here
+            return memcmp(&sa, &sb, sizeof(sa)) == 0;
+        };
+        B acc; acc.set_inf();
+        for (size_t i = 0; i + 2 < n; i++) {
+            B q; q.set(pt(i), i & 1); q.madd(pt(i + 1), false); q.madd(pt(i + 2), true);   // a bucket with non-trivial ZZ
+            B a = acc, b = acc;
+            a.add(q); b.add_pairs(q);
+            if (!same(a, b)) bad++;
+            B c = q, d = q;
+            c.dbl(); d.dbl_pairs();
+            if (!same(c, d)) bad++;
+            B e = q, f = q; e.add(q); f.add_pairs(q);                                      // equal operands: doubling branch
+            if (!same(e, f)) bad++;
+            B g = q, h = q; B nq = q; nq.Y = inst_fp::template neg<6, 4>(q.Y).norm();      // q + (-q) = infinity
+            g.add(nq); h.add_pairs(nq);
+            if (!same(g, h) || !g.is_inf()) bad++;
+            acc = a;
+        }
+    }
+    return bad;
+}
+
 // the two extra steps of fields with their own records (k_convert_points / k_finalize)
 template<class F>
 static const unsigned char* convert_points(std::vector<uint4>& conv, const unsigned char* pts, size_t npoints, size_t stride, bool flagged)

@@ -1,0 +1,48 @@
+"""CPU: register / scratch budgets of the hot kernels, read from the objects the build left under build/obj
+(tools/isa_stats.py: kernel-descriptor metadata of the gfx950 code object; no GPU needed).
+
+Why this is a test: in round 3 a harmless-looking change of a zero test inside the mixed addition made hipcc
+allocate 269 registers for k_accumulate instead of 238 -- ONE wave per SIMD instead of two, 151 ms instead of
+114 ms for the 2^26-point accumulation -- and nothing but a GPU timing showed it.  Occupancy steps on gfx950:
+<= 256 registers per lane (VGPR + AGPR) for two waves per SIMD, <= 168 for three, <= 128 for four, <= 64 for eight."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+OBJ = os.path.join(ROOT, "build", "obj")
+
+
+def _kernels(obj):
+    import isa_stats
+    path = os.path.join(OBJ, obj)
+    if not os.path.exists(path):
+        pytest.skip("%s not built here" % obj)
+    meta = isa_stats.metadata(isa_stats.code_object(path))
+    assert meta, obj
+    return meta
+
+
+def _regs(md):
+    return int(md.get("vgpr_count") or 0) + int(md.get("agpr_count") or 0)
+
+
+@pytest.mark.parametrize("obj,needle,max_regs", [
+    ("bls12_381__msm_k_accumulate.hip.o", "k_accumulate", 256),          # two waves per SIMD
+    ("bls12_377__msm_k_accumulate.hip.o", "k_accumulate", 256),
+    ("bn254__msm_k_accumulate.hip.o", "k_accumulate", 168),              # ten-limb fields: three waves
+    ("bls12_381__msm_k_bucket1.hip.o", "k_bucket_level1", 256),
+    ("bls12_381__msm_k_reduce.hip.o", "k_join_runs", 256),
+    ("gl64__ntt_k_ntt_r64.hip__SPPARK_NTT_DIF=1.o", "k_ntt", 64),        # eight waves per SIMD
+    ("gl64__ntt_k_ntt_r64.hip__SPPARK_NTT_DIF=0.o", "k_ntt", 64),
+])
+def test_register_budget(obj, needle, max_regs):
+    meta = _kernels(obj)
+    hit = {k: v for k, v in meta.items() if needle in k and "vgpr_count" in v}
+    assert hit, (obj, needle)
+    for name, md in hit.items():
+        assert _regs(md) <= max_regs, (name[:60], md)
+        if "k_accumulate" in needle and max_regs == 256:
+            assert int(md.get("private_segment_fixed_size") or 0) == 0, (name[:60], "scratch", md)

@@ -34,6 +34,7 @@ def _emu(feature, g2=False):
     L.emu_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
     L.emu_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
     L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu, ci, vp]
+    L.emu_pairs_check.argtypes = [vp, sz, sz]
     return L
 
 
@@ -153,3 +154,12 @@ def test_msm_short_segment_join_on_host(oracle):
                 assert bool(stats[0]) == expect_long, (wb, LL, stats)
                 if not expect_long:
                     assert stats[1] == 0            # no record left for the tree
+
+
+@pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])
+def test_low_latency_point_ops_on_host(oracle, curve, feature):
+    """add_pairs / dbl_pairs (products in interleaved pairs, unmasked quotient digits: the forms the top of the
+    bucket sums uses) give the same canonical XYZZ values as add / dbl, incl. the doubling and P + (-P) branches"""
+    L = _emu(feature)
+    pts, _ = recipe.msm_inputs(curve, 64, 2024, edge=False)
+    assert L.emu_pairs_check(P(pts), pts.shape[1], 64) == 0

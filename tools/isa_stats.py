@@ -71,22 +71,24 @@ def code_object(path):
 
 
 def metadata(co):
+    """{kernel symbol: {field: value}} from the amdhsa.kernels metadata note (one '- .agpr_count' list item per kernel)"""
     txt = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-    out, cur = {}, {}
+    out, cur = {}, None
+    keep = ("agpr_count", "vgpr_count", "sgpr_count", "group_segment_fixed_size", "private_segment_fixed_size",
+            "vgpr_spill_count", "sgpr_spill_count", "max_flat_workgroup_size", "symbol")
     for line in txt.splitlines():
-        m = re.match(r"\s+(?:- )?\.(\w+):\s+(.*)", line)
+        m = re.match(r"^(\s+)(- )?\.(\w+):\s+(.*)", line)
         if not m:
             continue
-        k, v = m.group(1), m.group(2).strip().strip("'")
-        if k in ("agpr_count", "vgpr_count", "sgpr_count", "group_segment_fixed_size", "private_segment_fixed_size",
-                 "vgpr_spill_count", "sgpr_spill_count", "max_flat_workgroup_size"):
-            cur[k] = v
-        elif k == "name" and "symbol" not in cur and v.startswith("_Z"):
-            cur["name"] = v
-        elif k == "symbol":
-            cur["symbol"] = v
-            out[v.replace(".kd", "")] = cur
+        indent, item, k, v = len(m.group(1)), m.group(2), m.group(3), m.group(4).strip().strip("'")
+        if item and indent == 2:                                # a new kernel record (top-level list item)
+            if cur and "symbol" in cur:
+                out[cur["symbol"].replace(".kd", "")] = cur
             cur = {}
+        if cur is not None and indent <= 4 and k in keep:
+            cur[k] = v
+    if cur and "symbol" in cur:
+        out[cur["symbol"].replace(".kd", "")] = cur
     return out
 
 

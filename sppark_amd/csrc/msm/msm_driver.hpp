@@ -93,16 +93,21 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // run length: 64 entries per lane, 128 from 2^22 points on, 256 from 2^25 (every chunk boundary costs one
     // full addition in k_join_runs; the accumulation itself is flat in L as long as there are > 10^5 lanes per
     // window.  2^23: tail 3.46 -> 2.67 ms with 128, 2^26: 11.5 -> 10.4 ms with 256, profiles/r03_msm_tail.log)
-    unsigned L = t.L ? t.L : (unsigned)std::min<size_t>(lg >= 25 ? 256 : lg >= 22 ? 128 : 64, std::max<size_t>(4, entries / 262144));
+    // Below 2^22 points: 8..64 entries, twice what round 2 used (2^14..2^18: -5..-9 %, profiles/r03_msm_small_grid.log)
+    unsigned L = t.L ? t.L : lg >= 22 ? (lg >= 25 ? 256u : 128u)
+                           : (unsigned)std::min<size_t>(64, std::max<size_t>(8, entries / 131072));
     p.L = L;
     p.chunks_per_win = (p.n + L - 1) / L;
     p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
-    p.F = std::max(4u, t.F ? t.F : 8u);        // fan-in < 3 would never shrink the record list
+    // fan-in of the record tree (< 3 would never shrink the list): 4 up to 2^20 points, where the buckets are longer
+    // than the join's walk and the tree does the work -- one addition per work item and level instead of three
+    p.F = std::max(4u, t.F ? t.F : (lg <= 20 ? 4u : 8u));
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
     // first level: 16 buckets per work item once a window has >= 2^21 of them (2^26 points: tail 11.35 -> 11.03 ms)
-    p.K1 = std::min(t.K1 ? t.K1 : (p.NB >= (1u << 21) ? 16u : p.K), p.NB);
+    // 8 where that hands 4096 partial sums per window straight to the subset-sum top (2^15 buckets: no chunked level at all)
+    p.K1 = std::min(t.K1 ? t.K1 : (p.NB >= (1u << 21) ? 16u : p.NB == (1u << 15) ? 8u : p.K), p.NB);
     // window groups: ONE by default.  Measured on MI355X (profiles/r02_msm_groups.log): whatever
     // the sort of the next group gains by running beside k_accumulate, the accumulation loses --
     // 2^26 points: 168.5 ms with one group, 169-190 ms with 2..12 groups, with the sort stream on

@@ -274,6 +274,7 @@ void k_bitmap_accumulate(u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict_
 // ---------------------------------------------------------------------------
 static constexpr unsigned JOIN_WALK = 8;
 template<class FP> SPPARK_DEVFN void bucket_add(xyzz_dev<FP>& a, const xyzz_dev<FP>& b);
+template<class FP> SPPARK_DEVFN void bucket_add_fast(xyzz_dev<FP>& a, const xyzz_dev<FP>& b);
 
 template<class FP>
 SPPARK_DEVFN void join_runs_item(xyzz_mem<FP::N>* buckets, u32* out_key, const u32* in_key,
@@ -349,7 +350,7 @@ SPPARK_DEVFN void reduce_runs_chunk(xyzz_mem<FP::N>* buckets, u32* out_key, xyzz
         const u32 k = in_key[r];
         if (k == KEY_NONE) continue;
         if (k == cur) {
-            acc.add(xyzz_dev<FP>::load(&in_pt[r]));
+            bucket_add_fast<FP>(acc, xyzz_dev<FP>::load(&in_pt[r]));    // a handful of waves per level: latency, not registers
         } else {
             if (cur != KEY_NONE) {
                 if (first_run && !last) { acc.store(&out_pt[rec0]); slot0_key = cur; }

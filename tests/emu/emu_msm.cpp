@@ -71,10 +71,11 @@ extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size
 // add_pairs / dbl_pairs (the low-latency forms used at the top of the bucket sums) against add / dbl on the
 // same operands, compared in the canonical wire form: |points| = n affine points in the wire format; returns
 // the number of mismatches (the fields without their own records have no such forms: 0).
-extern "C" int emu_pairs_check(const unsigned char* points, size_t stride, size_t n)
+template<class FPX> static int pairs_check(const unsigned char* points, size_t stride, size_t n)
 {
     int bad = 0;
-    if constexpr (field_is_internal<inst_fp>::value) {
+    if constexpr (field_is_internal<FPX>::value) {
+        typedef FPX inst_fp;                                // (a dependent name: the branch is discarded for the other fields)
         typedef xyzz_dev<inst_fp> B;
         std::vector<uint4> conv((size_t)n * affine_loader<inst_fp>::STRIDE / 16 + 1);
         for (size_t i = 0; i < n; i++) affine_loader<inst_fp>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
@@ -104,6 +105,8 @@ extern "C" int emu_pairs_check(const unsigned char* points, size_t stride, size_
     }
     return bad;
 }
+extern "C" int emu_pairs_check(const unsigned char* points, size_t stride, size_t n)
+{   return pairs_check<inst_fp>(points, stride, n);   }
 
 // the two extra steps of fields with their own records (k_convert_points / k_finalize)
 template<class F>

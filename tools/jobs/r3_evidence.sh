@@ -1,0 +1,27 @@
+# round 3 evidence run: full GPU suite, rocprofv3 kernel trace + stats of bench.py, the two PMC passes (FETCH_SIZE /
+# WRITE_SIZE, separate, counters only), SQ counters of k_accumulate, then bench.py itself.  Outputs: gpurun_out/r3e_*
+set -x
+R=$PWD; mkdir -p $R/gpurun_out
+timeout 1800 python -m pytest tests -m gpu -x -q > $R/gpurun_out/r3e_pytest_gpu.log 2>&1; tail -3 $R/gpurun_out/r3e_pytest_gpu.log
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_r3e $R/gpurun_out/prof_r3e_fetch $R/gpurun_out/prof_r3e_write
+(cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r3e -o bench -- python bench.py > $R/gpurun_out/r3e_bench_prof.log 2>&1); tail -c 300 $R/gpurun_out/r3e_bench_prof.log
+(cd $R && timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_r3e_fetch -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt --no-extras > $R/gpurun_out/r3e_prof_fetch.log 2>&1); tail -c 200 $R/gpurun_out/r3e_prof_fetch.log
+(cd $R && timeout 400 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_r3e_write -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ntt --no-extras > $R/gpurun_out/r3e_prof_write.log 2>&1); tail -c 200 $R/gpurun_out/r3e_prof_write.log
+cd $R
+python tools/rocprof_summary.py $(find gpurun_out/prof_r3e -name "*.db" | head -1) $(find gpurun_out/prof_r3e_fetch -name "*.db" | head -1) $(find gpurun_out/prof_r3e_write -name "*.db" | head -1) > gpurun_out/r3e_bench_rocprofv3_summary.txt 2>&1
+python tools/make_pmc_traffic.py $(find gpurun_out/prof_r3e_fetch -name "*.db" | head -1) $(find gpurun_out/prof_r3e_write -name "*.db" | head -1) 26 > gpurun_out/r3e_pmc_traffic.json 2>&1
+head -34 gpurun_out/r3e_bench_rocprofv3_summary.txt | cut -c1-140
+cat gpurun_out/r3e_pmc_traffic.json | head -20
+for lg in 26 23 20 16; do
+  rm -rf gpurun_out/prof_tl
+  (cd /tmp && cd $R && timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/prof_tl -o tl -- python tools/gpu_msm_one.py $lg 0 > $R/gpurun_out/r3e_tl.log 2>&1)
+  python tools/rocprof_timeline.py $(find gpurun_out/prof_tl -name "*.db" | head -1) 48 > gpurun_out/r3e_msm_timeline_2p$lg.txt 2>&1
+done
+rm -f gpurun_out/pmc_msm_acc3.txt
+bash tools/gpu_pmc_job.sh msm_acc3 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU|SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" -- python tools/gpu_msm_one.py 26 0 | grep -i "accumulate\|kernel "
+timeout 900 python bench.py > $R/gpurun_out/r3e_bench_final.json 2> $R/gpurun_out/r3e_bench_final.err; tail -c 600 $R/gpurun_out/r3e_bench_final.json
+timeout 300 env NTT_LGS=12,16,20,22,24,26 python tools/gpu_ntt_bench.py > $R/gpurun_out/r3e_ntt_bench.log 2>&1
+timeout 300 python tools/gpu_msm_tail.py ab 14 16 18 20 22 23 24 25 26 > $R/gpurun_out/r3e_msm_sizes.log 2>&1; grep -v amdgpu $R/gpurun_out/r3e_msm_sizes.log
+rm -rf gpurun_out/prof_r3e gpurun_out/prof_r3e_fetch gpurun_out/prof_r3e_write gpurun_out/prof_tl
+du -sh gpurun_out

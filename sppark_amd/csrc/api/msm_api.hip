@@ -18,6 +18,7 @@ extern template __global__ void k_bitmap_accumulate<msm_fp_d, true>(u32*, bucket
 extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                     unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<msm_fp_d>(bucket_m*, u32*, const u32*, const bucket_m*, unsigned, u32*);
+extern template __global__ void k_reduce_tail<msm_fp_d>(bucket_m*, u32*, bucket_m*, u32*, bucket_m*, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
@@ -32,6 +33,7 @@ extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, buck
 extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
                                                      unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<fp2_d>(bucket2_m*, u32*, const u32*, const bucket2_m*, unsigned, u32*);
+extern template __global__ void k_reduce_tail<fp2_d>(bucket2_m*, u32*, bucket2_m*, u32*, bucket2_m*, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
                                                        unsigned, unsigned, unsigned, unsigned);

@@ -4,4 +4,5 @@ namespace sppark_amd {
 template __global__ void k_reduce_runs<inst_fp>(inst_m*, u32*, inst_m*, const u32*, const inst_m*,
                                              unsigned, unsigned, unsigned, int, const u32*);
 template __global__ void k_join_runs<inst_fp>(inst_m*, u32*, const u32*, const inst_m*, unsigned, u32*);
+template __global__ void k_reduce_tail<inst_fp>(inst_m*, u32*, inst_m*, u32*, inst_m*, unsigned, unsigned, const u32*);
 }

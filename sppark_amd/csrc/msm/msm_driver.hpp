@@ -56,7 +56,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
     unsigned groups = 0;                // window groups (1 = everything on one stream)
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
-    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree)
+    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
@@ -102,7 +102,8 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
     // fan-in of the record tree (< 3 would never shrink the list): 4 up to 2^20 points, where the buckets are longer
     // than the join's walk and the tree does the work -- one addition per work item and level instead of three
-    p.F = std::max(4u, t.F ? t.F : (lg <= 20 ? 4u : 8u));
+    // (above 2^18 the join leaves the tree nothing to do and every level is an empty launch of ~6 us: fewer, wider ones)
+    p.F = std::max(4u, t.F ? t.F : (lg <= 18 ? 4u : 8u));
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
     // first level: 16 buckets per work item once a window has >= 2^21 of them (2^26 points: tail 11.35 -> 11.03 ms)
@@ -586,6 +587,13 @@ private:
             }
             for (;;) {
                 unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
+                if (nthreads <= REDUCE_TAIL_NT && tune.join != 2) {     // the narrow end: every remaining level in one launch
+                    // (the level kernels write into the OTHER buffer pair; here the pairs alternate from |ik| on)
+                    hipLaunchKernelGGL(k_reduce_tail<fp_d>, dim3(1), dim3(REDUCE_TAIL_NT), 0, stream,
+                                       buckets, ik, ip, ok, op, (unsigned)nrec, p.F, skip);
+                    HIP_OK(hipGetLastError());
+                    break;
+                }
                 int last = nthreads == 1;
                 hipLaunchKernelGGL(k_reduce_runs<fp_d>, dim3((nthreads + 255) / 256), dim3(256), 0, stream,
                                    buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, last, skip);

@@ -383,6 +383,30 @@ void k_reduce_runs(xyzz_mem<FP::N>* __restrict__ buckets,
                           blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// The narrow end of the tree in ONE launch: from the level with <= REDUCE_TAIL_NT work items on, one work-group runs
+// the remaining levels with a barrier between them (a launch boundary costs ~6 us, and below 2^18 points, where the
+// buckets are longer than the join's walk, ten of these levels are real work of one addition each).  Record buffers
+// ping-pong as in the launch-per-level loop; |buf0| holds the input of the first level run here.
+static constexpr unsigned REDUCE_TAIL_NT = 1024;
+template<class FP>
+__global__ __launch_bounds__(REDUCE_TAIL_NT)
+void k_reduce_tail(xyzz_mem<FP::N>* __restrict__ buckets, u32* key0, xyzz_mem<FP::N>* pt0, u32* key1, xyzz_mem<FP::N>* pt1,
+                   unsigned nrec, unsigned F, const u32* __restrict__ skip)
+{
+    if (skip != nullptr && *skip == 0) return;
+    u32 *ik = key0, *ok = key1; xyzz_mem<FP::N> *ip = pt0, *op = pt1;
+    for (;;) {
+        const unsigned nthreads = (nrec + F - 1) / F;
+        const int last = nthreads == 1;
+        reduce_runs_chunk<FP>(buckets, ok, op, ik, ip, nrec, F, nthreads, last, threadIdx.x);
+        if (last) break;
+        __syncthreads();                                    // this level's records are written (same CU: visible)
+        nrec = 2 * nthreads;
+        u32* tk = ik; ik = ok; ok = tk;
+        xyzz_mem<FP::N>* tp = ip; ip = op; op = tp;
+    }
+}
+
 template<class FP>
 __global__ __launch_bounds__(256, 2)
 void k_join_runs(xyzz_mem<FP::N>* __restrict__ buckets, u32* __restrict__ out_key, const u32* __restrict__ in_key,

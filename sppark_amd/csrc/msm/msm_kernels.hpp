@@ -385,9 +385,12 @@ void k_reduce_runs(xyzz_mem<FP::N>* __restrict__ buckets,
 
 // The narrow end of the tree in ONE launch: from the level with <= REDUCE_TAIL_NT work items on, one work-group runs
 // the remaining levels with a barrier between them (a launch boundary costs ~6 us, and below 2^18 points, where the
-// buckets are longer than the join's walk, ten of these levels are real work of one addition each).  Record buffers
+// buckets are longer than the join's walk, nine of these levels are real work of one addition each).  Record buffers
 // ping-pong as in the launch-per-level loop; |buf0| holds the input of the first level run here.
-static constexpr unsigned REDUCE_TAIL_NT = 1024;
+// (256 lanes = one wave per SIMD, like the other cold kernels: a 1024-lane work-group would cap the kernel at 128
+// registers -- 187 spilled for the 14-limb field, 3x slower per addition -- and, over Fp2, call the outlined addition,
+// which is compiled for up to 512, from a kernel that owns 128: that build hung the G2 tests)
+static constexpr unsigned REDUCE_TAIL_NT = 256;
 template<class FP>
 __global__ __launch_bounds__(REDUCE_TAIL_NT)
 void k_reduce_tail(xyzz_mem<FP::N>* __restrict__ buckets, u32* key0, xyzz_mem<FP::N>* pt0, u32* key1, xyzz_mem<FP::N>* pt1,

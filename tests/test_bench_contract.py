@@ -1,4 +1,4 @@
-"""CPU: the bench line recorded on the GPU box (profiles/r02_bench_line.json, the raw last line of
+"""CPU: the bench line recorded on the GPU box (profiles/r03_bench_line.json, the raw last line of
 `python bench.py`) has every field of the driver's contract, with consistent values."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_recorded_bench_line_schema():
-    line = open(os.path.join(ROOT, "profiles", "r02_bench_line.json")).read().strip()
+    line = open(os.path.join(ROOT, "profiles", "r03_bench_line.json")).read().strip()
     assert "\n" not in line                                     # ONE line
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -38,3 +38,9 @@ def test_recorded_bench_line_schema():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["parity_with_gpu_on_sample"] is True
     assert d["ntt"]["roofline"]["bound"] == "hbm" and 0 < d["ntt"]["roofline"]["frac"] < 1
     assert d["ntt"]["equals_oracle"] is True
+    # round 3: the per-GPU shard sizes of the headline MSM on this one GPU, each asserted against the oracle
+    sh = d["extras"]["shard_sizes"]
+    for lg in (25, 24, 23, 20, 16):
+        e = sh["msm_ms_at_2^%d" % lg]
+        assert e["equals_oracle"] is True and e["ms"] > 0
+    assert sh["msm_ms_at_2^25"]["ms"] < d["ms_per_step"] < 2.2 * sh["msm_ms_at_2^25"]["ms"]

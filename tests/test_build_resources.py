@@ -46,3 +46,17 @@ def test_register_budget(obj, needle, max_regs):
         assert _regs(md) <= max_regs, (name[:60], md)
         if "k_accumulate" in needle and max_regs == 256:
             assert int(md.get("private_segment_fixed_size") or 0) == 0, (name[:60], "scratch", md)
+
+
+@pytest.mark.parametrize("obj", ["bls12_381__msm_k_reduce.hip.o", "bls12_381__msm_k_reduce.hip__SPPARK_G2.o",
+                                 "bls12_381__msm_k_bucketN.hip.o", "bls12_381__msm_k_bucketN.hip__SPPARK_G2.o",
+                                 "bls12_381__msm_k_bucket1.hip.o", "bls12_381__msm_k_accumulate.hip.o"])
+def test_point_arithmetic_kernels_are_one_wave_per_simd_groups(obj):
+    """The kernels that do point arithmetic are built for work-groups of <= 256 lanes (one wave per SIMD, up to 512
+    registers).  A larger `__launch_bounds__` caps the kernel's registers (1024 lanes: 128) -- the 14-limb addition then
+    spills 187 of them, and over Fp2 the OUTLINED addition, compiled for up to 512 registers, is called from a kernel
+    that owns 128: round 3's first k_reduce_tail did exactly that and hung the G2 tests on the GPU box."""
+    meta = _kernels(obj)
+    for name, md in meta.items():
+        if "max_flat_workgroup_size" in md:
+            assert int(md["max_flat_workgroup_size"]) <= 256, (name[:70], md["max_flat_workgroup_size"])

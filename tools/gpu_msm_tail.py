@@ -1,14 +1,15 @@
 """The tail of an MSM at 2^LG points (record list + bucket sums): k_join_runs on / off, run length, fan-in,
 the first bucket-sum level's chunk, window size.
-    python tools/gpu_msm_tail.py [curve] MODE LG [LG ...]      MODE: ab | sweep | grid
+    python tools/gpu_msm_tail.py [curve] MODE LG [LG ...]      MODE: ab | sweep | grid | sort
 ab: automatic plan and join off only; sweep: one knob at a time around the automatic plan;
-grid: (window bits x run length x fan-in) for the small sizes."""
+grid: (window bits x run length x fan-in) for the small sizes; sort: split of the bucket index between the two
+sort levels (low bits) x point slabs -- watch "before-acc"."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sppark_amd
 from sppark_amd import synth
 args = sys.argv[1:]
-curve = args.pop(0) if args[0] not in ("ab", "sweep", "grid") else "bls12_381"
+curve = args.pop(0) if args[0] not in ("ab", "sweep", "grid", "sort") else "bls12_381"
 mode = args.pop(0)
 ctx = sppark_amd.MsmContext(curve); ctx.enable_timing(True)
 for lg in (int(a) for a in args):
@@ -16,8 +17,8 @@ for lg in (int(a) for a in args):
     pts, _ = synth.replicated_points(n, curve, 2048, 1)
     sc = synth.uniform_scalars(n, curve, 1)
     ref = [None]
-    def run(tag, join=0, k1=0, **kw):
-        ctx.tune(**kw); ctx.tune_tail(join, k1)
+    def run(tag, join=0, k1=0, lb=0, **kw):
+        ctx.tune(**kw); ctx.tune_tail(join, k1); ctx.tune_sort(lb)
         out = None
         for _ in range(3):
             out = ctx.invoke(pts, sc)
@@ -35,7 +36,16 @@ for lg in (int(a) for a in args):
             lg, tag, pl["windows"], pl["run_length"], b, a, d - a - b, d, wall), flush=True)
         return d
     run("auto")
-    run("join off", join=1)
+    if mode != "sort":
+        run("join off", join=1)
+    if mode == "sort":
+        pl = ctx.plan(n)
+        for lb in range(max(1, pl["low_bits"] - 1), min(13, pl["window_bits"] - 1) + 1):
+            if pl["window_bits"] - 1 - lb > 12: continue
+            run("low bits %d (2^%d partitions)" % (lb, pl["window_bits"] - 1 - lb), lb=lb)
+        ctx.tune_sort(0)
+        for ns in (4, 8, 16, 32, 64, 128):
+            run("slabs %d" % ns, nslabs=ns)
     if mode == "sweep":
         for L in (32, 64, 128, 256):
             run("L=%d" % L, L=L)

@@ -82,9 +82,18 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.nbits = scalar_bits;
     p.wbits = scalar_bits / p.nwins + (scalar_bits % p.nwins ? 1 : 0);     // even split (window_len)
     p.NB = 1u << (p.wbits - 1);
-    // many small level-A partitions (<= 2^12 per window) keep level B's two passes
-    // over a partition inside L2 (measured: profiles/r01_sort_split_sweep.log)
-    p.LB = t.LB ? std::min(t.LB, p.wbits - 1) : (p.wbits - 1 > 12 ? p.wbits - 1 - 12 : 0);
+    // Split of the bucket index between the two sort levels: 2^HB level-A partitions per window of ~2^14 entries each
+    // -- what k_sortB's register path takes in one piece (18 K) -- but at least ~2^10 (partition, window) work-groups.
+    // Until round 3 it was "as many partitions as possible" (HB = 12), right for 2^26 points only: at 2^20 that
+    // is 65 536 work-groups of 256 entries (digits + sort 0.79 ms -> 0.33 ms with 2^7 partitions; 2^22: 1.31 -> 0.79,
+    // 2^23: 2.04 -> 1.50, 2^24: 3.61 -> 3.07; profiles/r03_msm_sort_split.log)
+    unsigned hb = lg > 14 ? lg - 14 : 0;
+    {
+        const unsigned lgw = lg2_floor(p.nwins);
+        hb = std::max(hb, lgw < 10 ? 10 - lgw : 0u);
+        hb = std::min(hb, std::min(p.wbits - 1, 12u));
+    }
+    p.LB = t.LB ? std::min(t.LB, p.wbits - 1) : p.wbits - 1 - hb;
     if (p.LB > 13) p.LB = 13;                       // 2^LB LDS counters + scan words
     if (p.wbits - 1 - p.LB > 15) p.LB = p.wbits - 1 - 15;
     p.HB = p.wbits - 1 - p.LB;
@@ -98,7 +107,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
                            : (unsigned)std::min<size_t>(64, std::max<size_t>(8, entries / 131072));
     p.L = L;
     p.chunks_per_win = (p.n + L - 1) / L;
-    p.nslabs = t.nslabs ? t.nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
+    // point slabs of the level-A histogram / scatter: >= 8 from 2^14 points on (2^18: digits + sort 0.31 -> 0.17 ms with 8)
+    p.nslabs = t.nslabs ? t.nslabs
+             : (unsigned)std::min<size_t>(64, std::max<size_t>(npoints / 131072, std::min<size_t>(8, std::max<size_t>(1, npoints / 2048))));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
     // fan-in of the record tree (< 3 would never shrink the list): 4 up to 2^20 points, where the buckets are longer
     // than the join's walk and the tree does the work -- one addition per work item and level instead of three

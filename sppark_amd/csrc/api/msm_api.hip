@@ -22,6 +22,9 @@ extern template __global__ void k_reduce_tail<msm_fp_d>(bucket_m*, u32*, bucket_
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_level1_lat<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
+extern template __global__ void k_bucket_levelN_lat<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
+                                                          unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_bits<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_sum<msm_fp_d>(bucket_m*, const bucket_m*, unsigned);
 // ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)

@@ -56,7 +56,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
     unsigned groups = 0;                // window groups (1 = everything on one stream)
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
-    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end
+    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
@@ -149,6 +149,7 @@ public:
     static_assert(INTERNAL || sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
     static constexpr unsigned MAX_WINS = 128;
+    static constexpr size_t LAT_LANES = 65536;              // one wave per SIMD on 256 CUs
 
 private:
     const gpu_info* gpu;
@@ -621,8 +622,17 @@ private:
         {
             unsigned nitems = p.NB / p.K1;
             size_t nthr = (size_t)p.nwins * nitems;
-            hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                               A1, W1, buckets, p.NB, p.K1, p.nwins, multi ? (const u32*)nullptr : (const u32*)(blob + l.off[0]));
+            // grids of at most one resident round (one wave per SIMD: 65 536 lanes) are chains of dependent additions:
+            // the _lat kernels (no register cap, products in pairs); larger ones are work: two waves per SIMD
+            const u32* offp = multi ? (const u32*)nullptr : (const u32*)(blob + l.off[0]);
+            bool lat = false;
+            if constexpr (INTERNAL) lat = nthr <= LAT_LANES && tune.join != 3;
+            if constexpr (INTERNAL) {
+                if (lat) hipLaunchKernelGGL(k_bucket_level1_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                            A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
+            }
+            if (!lat) hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                         A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
             HIP_OK(hipGetLastError());
             unsigned lgG = lg2_floor(p.K1);
             bucket_t *ia = A1, *iw = W1, *oa = A2, *ow = W2;
@@ -644,8 +654,14 @@ private:
                 }
                 unsigned K = std::min(p.K, nitems);
                 nthr = (size_t)p.nwins * (nitems / K);
-                hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                                   oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                lat = false;
+                if constexpr (INTERNAL) lat = nthr <= LAT_LANES && tune.join != 3;
+                if constexpr (INTERNAL) {
+                    if (lat) hipLaunchKernelGGL(k_bucket_levelN_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                                oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                }
+                if (!lat) hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                             oa, ow, ia, iw, nitems, K, lgG, p.nwins);
                 HIP_OK(hipGetLastError());
                 nitems /= K; lgG += lg2_floor(K);
                 std::swap(ia, oa); std::swap(iw, ow);

@@ -454,7 +454,9 @@ SPPARK_DEVFN xyzz_dev<FP> bucket_load(const xyzz_mem<FP::N>* row, const u32* o, 
     if (o != nullptr && o[b + 1] == o[b]) { xyzz_dev<FP> z; z.set_inf(); return z; }
     return xyzz_dev<FP>::load(&row[b]);
 }
-template<class FP>
+// LAT: the low-latency additions (products in pairs): for grids of at most one resident round of waves, where the
+// chain of 2(K-1) dependent additions, not the number of additions, is the time (k_bucket_level1_lat / _levelN_lat)
+template<class FP, bool LAT = false>
 SPPARK_DEVFN void bucket_level1_item(xyzz_mem<FP::N>* A, xyzz_mem<FP::N>* Wt, const xyzz_mem<FP::N>* buckets,
                                      unsigned NB, unsigned K, unsigned nwins, size_t id, const u32* off = nullptr)
 {
@@ -465,8 +467,8 @@ SPPARK_DEVFN void bucket_level1_item(xyzz_mem<FP::N>* A, xyzz_mem<FP::N>* Wt, co
     const u32* o = off ? off + (size_t)w * (NB + 1) + (size_t)u * K : nullptr;
     xyzz_dev<FP> acc = bucket_load<FP>(row, o, K - 1), ret = acc;
     for (unsigned j = K - 1; j--;) {
-        bucket_add<FP>(acc, bucket_load<FP>(row, o, j));
-        bucket_add<FP>(ret, acc);
+        if (LAT) { bucket_add_fast<FP>(acc, bucket_load<FP>(row, o, j)); bucket_add_fast<FP>(ret, acc); }
+        else     { bucket_add<FP>(acc, bucket_load<FP>(row, o, j)); bucket_add<FP>(ret, acc); }
     }
     acc.store(&A[id]); ret.store(&Wt[id]);
 }
@@ -479,10 +481,17 @@ void k_bucket_level1(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __restric
                      const xyzz_mem<FP::N>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins,
                      const u32* __restrict__ off)
 {   bucket_level1_item<FP>(A, Wt, buckets, NB, K, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x, off);   }
+// the same for small grids: one wave per SIMD (no register cap, no spills), products in pairs
+template<class FP>
+__global__ __launch_bounds__(256)
+void k_bucket_level1_lat(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __restrict__ Wt,
+                         const xyzz_mem<FP::N>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins,
+                         const u32* __restrict__ off)
+{   bucket_level1_item<FP, true>(A, Wt, buckets, NB, K, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x, off);   }
 
 // level >= 2: chunk u of K items (A_j, Wt_j), each item spanning 2^lgG buckets:
 //   A'[u] = sum_j A_j      Wt'[u] = sum_j Wt_j + 2^lgG * sum_j j*A_j
-template<class FP>
+template<class FP, bool LAT = false>
 SPPARK_DEVFN void bucket_levelN_item(xyzz_mem<FP::N>* A2, xyzz_mem<FP::N>* Wt2,
                                      const xyzz_mem<FP::N>* A1, const xyzz_mem<FP::N>* Wt1,
                                      unsigned nitems, unsigned K, unsigned lgG, unsigned nwins, size_t id)
@@ -494,14 +503,15 @@ SPPARK_DEVFN void bucket_levelN_item(xyzz_mem<FP::N>* A2, xyzz_mem<FP::N>* Wt2,
     xyzz_dev<FP> acc, r, sw;
     acc.set_inf(); r.set_inf();
     sw = xyzz_dev<FP>::load(&Wt1[base]);
+    auto add = [](xyzz_dev<FP>& a, const xyzz_dev<FP>& b) { if (LAT) bucket_add_fast<FP>(a, b); else bucket_add<FP>(a, b); };
     for (unsigned j = K - 1; j >= 1; j--) {
-        bucket_add<FP>(acc, xyzz_dev<FP>::load(&A1[base + j]));
-        bucket_add<FP>(r, acc);
-        bucket_add<FP>(sw, xyzz_dev<FP>::load(&Wt1[base + j]));
+        add(acc, xyzz_dev<FP>::load(&A1[base + j]));
+        add(r, acc);
+        add(sw, xyzz_dev<FP>::load(&Wt1[base + j]));
     }
-    bucket_add<FP>(acc, xyzz_dev<FP>::load(&A1[base]));
-    for (unsigned k = 0; k < lgG; k++) bucket_dbl<FP>(r);
-    bucket_add<FP>(sw, r);
+    add(acc, xyzz_dev<FP>::load(&A1[base]));
+    for (unsigned k = 0; k < lgG; k++) { if (LAT) bucket_dbl_fast<FP>(r); else bucket_dbl<FP>(r); }
+    add(sw, r);
     acc.store(&A2[id]); sw.store(&Wt2[id]);
 }
 
@@ -511,6 +521,12 @@ void k_bucket_levelN(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restri
                      const xyzz_mem<FP::N>* __restrict__ A1, const xyzz_mem<FP::N>* __restrict__ Wt1,
                      unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)
 {   bucket_levelN_item<FP>(A2, Wt2, A1, Wt1, nitems, K, lgG, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+template<class FP>
+__global__ __launch_bounds__(256)
+void k_bucket_levelN_lat(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restrict__ Wt2,
+                         const xyzz_mem<FP::N>* __restrict__ A1, const xyzz_mem<FP::N>* __restrict__ Wt1,
+                         unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)
+{   bucket_levelN_item<FP, true>(A2, Wt2, A1, Wt1, nitems, K, lgG, nwins, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // ---------------------------------------------------------------------------
 // Top of the bucket sums.  Once a window is down to M = 2^m <= BUCKET_TOP_MAX items (A_j, Wt_j) of

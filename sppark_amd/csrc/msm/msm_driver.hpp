@@ -588,7 +588,9 @@ private:
             // segments of <= JOIN_WALK records (with uniform scalars: all of them) in one launch; the tree
             // below then only sees the records of longer segments and returns at once when there are none
             const u32* skip = nullptr;
-            if (tune.join != 1) {
+            // (not when the average bucket is longer than four runs: every segment is then longer than the join's walk
+            // and the launch finds nothing to do -- below ~2^19 points)
+            if (tune.join != 1 && (size_t)p.n / p.NB <= (size_t)4 * p.L) {
                 u32* keyC = (u32*)(blob + l.keyC); u32* flag = (u32*)(blob + l.flag);
                 HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
                 const size_t nthr = nrec / 2 + 1;

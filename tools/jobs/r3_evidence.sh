@@ -2,7 +2,7 @@
 # WRITE_SIZE, separate, counters only), SQ counters of k_accumulate, then bench.py itself.  Outputs: gpurun_out/r3e_*
 set -x
 R=$PWD; mkdir -p $R/gpurun_out
-timeout 1800 python -m pytest tests -m gpu -x -q > $R/gpurun_out/r3e_pytest_gpu.log 2>&1; tail -3 $R/gpurun_out/r3e_pytest_gpu.log
+timeout 1800 python -m pytest tests -m gpu -x -q --timeout 300 > $R/gpurun_out/r3e_pytest_gpu.log 2>&1; tail -3 $R/gpurun_out/r3e_pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_r3e $R/gpurun_out/prof_r3e_fetch $R/gpurun_out/prof_r3e_write
 (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r3e -o bench -- python bench.py > $R/gpurun_out/r3e_bench_prof.log 2>&1); tail -c 300 $R/gpurun_out/r3e_bench_prof.log
@@ -22,6 +22,6 @@ rm -f gpurun_out/pmc_msm_acc3.txt
 bash tools/gpu_pmc_job.sh msm_acc3 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU|SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" -- python tools/gpu_msm_one.py 26 0 | grep -i "accumulate\|kernel "
 timeout 900 python bench.py > $R/gpurun_out/r3e_bench_final.json 2> $R/gpurun_out/r3e_bench_final.err; tail -c 600 $R/gpurun_out/r3e_bench_final.json
 timeout 300 env NTT_LGS=12,16,20,22,24,26 python tools/gpu_ntt_bench.py > $R/gpurun_out/r3e_ntt_bench.log 2>&1
-timeout 300 python tools/gpu_msm_tail.py ab 14 16 18 20 22 23 24 25 26 > $R/gpurun_out/r3e_msm_sizes.log 2>&1; grep -v amdgpu $R/gpurun_out/r3e_msm_sizes.log
+timeout 300 python tools/gpu_msm_tail.py ab 12 14 16 18 19 20 21 22 23 24 25 26 > $R/gpurun_out/r3e_msm_sizes.log 2>&1; grep -v amdgpu $R/gpurun_out/r3e_msm_sizes.log
 rm -rf gpurun_out/prof_r3e gpurun_out/prof_r3e_fetch gpurun_out/prof_r3e_write gpurun_out/prof_tl
 du -sh gpurun_out

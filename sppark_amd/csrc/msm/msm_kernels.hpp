@@ -552,19 +552,17 @@ SPPARK_DEVFN void lds_tree_sum(xyzz_dev<FP>& acc, xyzz_mem<FP::N>* img, unsigned
     }
 }
 
+// The per-lane parts of the two kernels as functions of (b, w, tid), so that tests/emu runs the same index math on
+// the host (the LDS tree between them is a plain pairwise reduction).
+// items of a lane: j = lo | i << p | hi << (p + lgI), bit b inside the i field, so that every lane
+// owns as many selected items as any other
 template<class FP>
-__global__ __launch_bounds__(BUCKET_TOP_NT, 2)
-void k_bucket_top_bits(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ A,
-                       const xyzz_mem<FP::N>* __restrict__ Wt, unsigned nitems, unsigned m, unsigned lgG)
+SPPARK_DEVFN xyzz_dev<FP> bucket_top_gather(const xyzz_mem<FP::N>* A, const xyzz_mem<FP::N>* Wt,
+                                            unsigned nitems, unsigned m, unsigned b, unsigned w, unsigned tid, unsigned nt)
 {
-    extern __shared__ unsigned char top_lds[];
-    xyzz_mem<FP::N>* img = reinterpret_cast<xyzz_mem<FP::N>*>(top_lds);
-    const unsigned b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const xyzz_mem<FP::N>* src = (b == m ? Wt : A) + (size_t)w * nitems;
-    // items of a lane: j = lo | i << p | hi << (p + lgI), bit b inside the i field, so that every lane
-    // owns as many selected items as any other
     unsigned lgI = 0;
-    while ((BUCKET_TOP_NT << lgI) < nitems) lgI++;
+    while ((nt << lgI) < nitems) lgI++;
     const unsigned p = b >= m ? 0 : (b < m - lgI ? b : m - lgI);
     const unsigned lo = tid & ((1u << p) - 1), hi = tid >> p;
     xyzz_dev<FP> acc; acc.set_inf();
@@ -573,14 +571,37 @@ void k_bucket_top_bits(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N
         const unsigned j = lo | (i << p) | (hi << (p + lgI));
         if (j < nitems && (b == m || ((j >> b) & 1))) bucket_add_fast<FP>(acc, xyzz_dev<FP>::load(&src[j]));
     }
-    lds_tree_sum<FP>(acc, img, tid, BUCKET_TOP_NT);
-    if (tid == 0) {
-        if (b < m) {
-            #pragma unroll 1
-            for (unsigned k = 0; k < b + lgG; k++) bucket_dbl_fast<FP>(acc);
-        }
-        acc.store(&parts[(size_t)w * (m + 1) + b]);
+    return acc;
+}
+// lane 0 after the tree: the weight 2^(b + lgG) of bit b (none for the plain sum of the Wt's, b == m)
+template<class FP>
+SPPARK_DEVFN void bucket_top_finish(xyzz_dev<FP>& acc, xyzz_mem<FP::N>* parts, unsigned m, unsigned lgG, unsigned b, unsigned w)
+{
+    if (b < m) {
+        #pragma unroll 1
+        for (unsigned k = 0; k < b + lgG; k++) bucket_dbl_fast<FP>(acc);
     }
+    acc.store(&parts[(size_t)w * (m + 1) + b]);
+}
+template<class FP>
+SPPARK_DEVFN xyzz_dev<FP> bucket_top_sum_gather(const xyzz_mem<FP::N>* parts, unsigned m, unsigned w, unsigned tid)
+{
+    xyzz_dev<FP> acc; acc.set_inf();
+    if (tid <= m) acc = xyzz_dev<FP>::load(&parts[(size_t)w * (m + 1) + tid]);
+    return acc;
+}
+
+template<class FP>
+__global__ __launch_bounds__(BUCKET_TOP_NT, 2)
+void k_bucket_top_bits(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ A,
+                       const xyzz_mem<FP::N>* __restrict__ Wt, unsigned nitems, unsigned m, unsigned lgG)
+{
+    extern __shared__ unsigned char top_lds[];
+    xyzz_mem<FP::N>* img = reinterpret_cast<xyzz_mem<FP::N>*>(top_lds);
+    const unsigned b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    xyzz_dev<FP> acc = bucket_top_gather<FP>(A, Wt, nitems, m, b, w, tid, BUCKET_TOP_NT);
+    lds_tree_sum<FP>(acc, img, tid, BUCKET_TOP_NT);
+    if (tid == 0) bucket_top_finish<FP>(acc, parts, m, lgG, b, w);
 }
 
 template<class FP>
@@ -590,8 +611,7 @@ void k_bucket_top_sum(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* 
     extern __shared__ unsigned char top_lds[];
     xyzz_mem<FP::N>* img = reinterpret_cast<xyzz_mem<FP::N>*>(top_lds);
     const unsigned w = blockIdx.x, tid = threadIdx.x;
-    xyzz_dev<FP> acc; acc.set_inf();
-    if (tid <= m) acc = xyzz_dev<FP>::load(&parts[(size_t)w * (m + 1) + tid]);
+    xyzz_dev<FP> acc = bucket_top_sum_gather<FP>(parts, m, w, tid);
     lds_tree_sum<FP>(acc, img, tid, 32);
     if (tid == 0) acc.store(&out[w]);
 }

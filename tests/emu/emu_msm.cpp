@@ -10,16 +10,18 @@
 // tests/test_emulation.py.
 //
 // WHAT IT COVERS: the product's own bodies of recode_digits / load_scalar_abs, accumulate_chunk,
-// join_runs_item, reduce_runs_chunk, bucket_level1_item / bucket_levelN_item, the point conversion
-// and finalisation, and the field / point classes' C paths.
+// join_runs_item, reduce_runs_chunk, bucket_level1_item / bucket_levelN_item, bucket_top_gather /
+// bucket_top_finish / bucket_top_sum_gather, the point conversion and finalisation, and the field /
+// point classes' C paths.
 // WHAT IT DOES NOT: the sort.  The grouped index list is produced below by a PLAIN HOST COUNTING
 // SORT with the same output contract (indices grouped by bucket, offsets per bucket) -- it is not a
 // translation of msm_sort_kernels.hpp: the LDS-staged scatter (k_scatterA_staged), both k_sortB
 // paths, the k_big_* split for oversized partitions, the per-window k_lo width (window_lb), the
-// window-group indexing, the subset-sum top of the bucket sums (k_bucket_top_bits / _sum) and
-// k_bitmap_accumulate are work-group-level kernels (LDS, barriers, cross-lane scans) and are checked
-// by the GPU suite only (tests/test_msm_gpu.py: sort partition paths, oversized partitions,
-// bucket-sum top, window groups, bitmaps).
+// window-group indexing and k_bitmap_accumulate are work-group-level kernels (LDS, barriers,
+// cross-lane scans) and are checked by the GPU suite only (tests/test_msm_gpu.py: sort partition
+// paths, oversized partitions, window groups, bitmaps).  The subset-sum top of the bucket sums
+// (k_bucket_top_bits / _sum) IS covered: its per-lane functions (item -> lane map, bit selection,
+// doublings) run here, with the LDS tree between them as a plain pairwise reduction.
 #define SPPARK_HOST_EMULATION 1
 #include "../../sppark_amd/csrc/msm/curve_select.hpp"
 #include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
@@ -132,7 +134,8 @@ static void finalize_sum(M* out, const xyzz_mem<F::N>* in)
 
 extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                        const unsigned char* scalars, int mont,
-                       unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs, int join, unsigned* join_stats)
+                       unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs, int join, unsigned* join_stats,
+                       unsigned top /* bucket sums: items per window handed to the subset-sum top; 0 = 4096, 1 = never */)
 {
 #ifdef SPPARK_G2                                 // the same pipeline over Fp2 (G2)
     typedef fp2_host<curve_p::fp> fp_h;
@@ -269,6 +272,30 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     unsigned lgG = lg2_floor(p.K);
     inst_m *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
     while (nitems > 1) {
+        // the subset-sum top (k_bucket_top_bits / k_bucket_top_sum), as msm_driver.hpp hands over to it: the per-lane parts
+        // are the product's own functions, the LDS tree between them a plain pairwise reduction with the same additions
+        if (top != 1 && nitems <= (top ? top : BUCKET_TOP_MAX) && nitems >= 32 && (nitems & (nitems - 1)) == 0 && p.NB / p.K >= 32) {
+            const unsigned m = lg2_floor(nitems);
+            std::vector<inst_m> parts((size_t)p.nwins * (m + 1));
+            auto tree = [&](std::vector<xyzz_dev<inst_fp>>& acc, unsigned nt) {
+                for (unsigned s = nt >> 1; s >= 1; s >>= 1)
+                    for (unsigned tid = 0; tid < s; tid++) bucket_add_fast<inst_fp>(acc[tid], acc[tid + s]);
+            };
+            for (unsigned w = 0; w < p.nwins; w++) {
+                for (unsigned b = 0; b <= m; b++) {
+                    std::vector<xyzz_dev<inst_fp>> acc(BUCKET_TOP_NT);
+                    for (unsigned tid = 0; tid < BUCKET_TOP_NT; tid++) acc[tid] = bucket_top_gather<inst_fp>(ia, iw, nitems, m, b, w, tid, BUCKET_TOP_NT);
+                    tree(acc, BUCKET_TOP_NT);
+                    bucket_top_finish<inst_fp>(acc[0], parts.data(), m, lgG, b, w);
+                }
+                std::vector<xyzz_dev<inst_fp>> acc(32);
+                for (unsigned tid = 0; tid < 32; tid++) acc[tid] = bucket_top_sum_gather<inst_fp>(parts.data(), m, w, tid);
+                tree(acc, 32);
+                acc[0].store(&ow[w]);
+            }
+            std::swap(iw, ow);
+            break;
+        }
         unsigned Kc = std::min(p.K, nitems);
         size_t nthr = (size_t)p.nwins * (nitems / Kc);
         for (size_t id = 0; id < nthr; id++) bucket_levelN_item<inst_fp>(oa, ow, ia, iw, nitems, Kc, lgG, p.nwins, id);

@@ -33,7 +33,7 @@ def _emu(feature, g2=False):
     vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
     L.emu_field_op.argtypes = [ci, ci, vp, vp, vp, sz]
     L.emu_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
-    L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu, ci, vp]
+    L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu, ci, vp, cu]
     L.emu_pairs_check.argtypes = [vp, sz, sz]
     return L
 
@@ -75,7 +75,7 @@ def test_msm_pipeline_on_host(oracle, curve):
                                          (300, 2, 4, 4, 2, 1, False), (300, 16, 64, 32, 8, 1, False), (500, 19, 8, 8, 8, 2, True)):
         pts, sc = recipe.msm_inputs(curve, n, 1234 + n + wb, flagged=flagged)
         out = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None)
+        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None, 0)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
 
 
@@ -89,7 +89,7 @@ def test_msm_g2_pipeline_on_host(oracle, curve):
                                          (500, 7, 4, 4, 2, 3, False), (300, 11, 16, 8, 4, 2, True)):
         pts, sc = recipe.msm_inputs(curve, n, 4321 + n + wb, flagged=flagged)
         out = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None)
+        L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None, 0)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
     # all points equal (doubling branch) and all scalars equal
     pts, sc = recipe.msm_inputs(curve, 400, 5, edge=False, flagged=True)
@@ -97,7 +97,7 @@ def test_msm_g2_pipeline_on_host(oracle, curve):
     s_eq = sc.copy(); s_eq[:] = sc[0]
     for p_, s_ in ((same, sc), (pts, s_eq)):
         out = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(out), P(p_), p_.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2, 1, None)
+        L.emu_msm(P(out), P(p_), p_.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2, 1, None, 0)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, p_, s_, algo=0, param=4)).all()
 
 
@@ -116,7 +116,7 @@ def test_msm_skewed_scalars_on_host(oracle):
     for s in cases:
         for p in (pts, same_pts):
             out = np.zeros(144, dtype=np.uint8)
-            L.emu_msm(P(out), P(p), 96, n, P(s), 0, 8, 8, 4, 4, 2, 1, None)
+            L.emu_msm(P(out), P(p), 96, n, P(s), 0, 8, 8, 4, 4, 2, 1, None, 0)
             assert (O.jac_to_affine(0, out) == O.msm_affine(0, p, s, algo=0, param=4)).all()
 
 
@@ -128,7 +128,7 @@ def test_msm_montgomery_scalars_on_host(oracle):
     for i in range(200):
         mont[i] = O.field_op(O.FIELD_BN_FR, 4, sc[i].view(np.uint64)).view(np.uint8)
     out = np.zeros(96, dtype=np.uint8)
-    L.emu_msm(P(out), P(pts), 64, 200, P(mont), 1, 0, 0, 0, 0, 0, 1, None)
+    L.emu_msm(P(out), P(pts), 64, 200, P(mont), 1, 0, 0, 0, 0, 0, 1, None, 0)
     assert (O.jac_to_affine(1, out) == O.msm_affine(1, pts, sc)).all()
 
 
@@ -148,7 +148,7 @@ def test_msm_short_segment_join_on_host(oracle):
         for join in (1, 0):
             out = np.zeros(144, dtype=np.uint8)
             stats = np.zeros(2, dtype=np.uint32)
-            L.emu_msm(P(out), P(pts), 96, n, P(s), 0, wb, LL, 4, 4, 2, join, P(stats))
+            L.emu_msm(P(out), P(pts), 96, n, P(s), 0, wb, LL, 4, 4, 2, join, P(stats), 0)
             assert (O.jac_to_affine(0, out) == exp).all(), (wb, LL, join)
             if join and expect_long is not None:
                 assert bool(stats[0]) == expect_long, (wb, LL, stats)
@@ -163,3 +163,17 @@ def test_low_latency_point_ops_on_host(oracle, curve, feature):
     L = _emu(feature)
     pts, _ = recipe.msm_inputs(curve, 64, 2024, edge=False)
     assert L.emu_pairs_check(P(pts), pts.shape[1], 64) == 0
+
+
+def test_msm_bucket_sum_top_on_host(oracle):
+    """The subset-sum top of the bucket sums (bucket_top_gather / _finish / _sum_gather): hand-over at 32 ... 4096 partial
+    sums per window, chunks of 4 and 8, against the oracle and against the chunked levels alone (top = 1)."""
+    O = oracle
+    L = _emu("BLS12_381")
+    n = 700
+    pts, sc = recipe.msm_inputs(0, n, 4242, edge=False)
+    exp = O.msm_affine(0, pts, sc, algo=0, param=4)
+    for wb, K, top in ((9, 4, 0), (11, 8, 0), (13, 4, 256), (13, 8, 32), (16, 8, 0), (16, 8, 1)):
+        out = np.zeros(144, dtype=np.uint8)
+        L.emu_msm(P(out), P(pts), 96, n, P(sc), 0, wb, 8, 4, K, 2, 1, None, top)
+        assert (O.jac_to_affine(0, out) == exp).all(), (wb, K, top)

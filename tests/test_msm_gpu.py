@@ -268,6 +268,30 @@ def test_msm_tunables(oracle, libs, tune):
     ctx.close()
 
 
+@pytest.mark.parametrize("curve,name", [(0, "bls12_381"), (1, "bn254")])
+def test_msm_tail_variants(oracle, libs, curve, name):
+    """The tail of an MSM (record list + bucket sums) in every form the driver can run it: k_join_runs on / off,
+    with and without the one-launch narrow end of the tree (k_reduce_tail) and the low-latency bucket-sum kernels,
+    first-level chunks of 4 / 16 -- on inputs where the join resolves everything (many buckets, short segments), where
+    it resolves nothing (one bucket holds all entries: the tree does the work) and in between."""
+    import sppark_amd
+    O = oracle
+    ctx = sppark_amd.MsmContext(name)
+    n = 40000
+    pts, sc = recipe.msm_inputs(curve, n, 23, ndistinct=600, edge=False)
+    s_eq = sc.copy(); s_eq[:] = sc[1]
+    s_two = sc.copy(); s_two[: n // 3] = sc[0]; s_two[n // 3:] = sc[1]
+    for scal, plans in ((sc, (dict(wbits=14, L=8), dict(wbits=10, L=16), dict())), (s_eq, (dict(wbits=12, L=8), dict())),
+                        (s_two, (dict(wbits=9, L=4, F=4),))):
+        exp = O.msm_affine(curve, pts, scal, algo=0, param=8)
+        for plan in plans:
+            for join, k1 in ((0, 0), (1, 0), (2, 0), (3, 0), (0, 4), (0, 16)):
+                ctx.tune(**plan); ctx.tune_tail(join, k1)
+                out = ctx.invoke(pts, scal)
+                assert (sppark_amd.to_affine(out, name) == exp).all(), (plan, join, k1)
+    ctx.close()
+
+
 def test_msm_skewed_scalars(oracle, libs):
     """SURVEY 8(d) skew cases: all scalars equal, 50% zeros, 16-bit scalars,
     all points equal."""

@@ -376,3 +376,24 @@ def test_ntt_root_convention_variants(oracle, libs, lib, field):
         assert not (y == f(x, 0, 0, 0)).all()
     finally:
         O.set_root_conventions(False, False)
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_ntt_plan_knobs_in_a_fresh_process(oracle, libs, field):
+    """The plan knobs are read once per process: the 8-stage plan (SPPARK_NTT_R64_MIN=99, what the single-word fields ran
+    until round 3 and the 256-bit fields still run) and the radix-64 plan with two small inter-pass tables everywhere
+    (SPPARK_NTT_R64_DIRECT=12) against the oracle, each in its own interpreter."""
+    import subprocess, sys
+    code = (
+        "import sys, os, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests', 'golden'))\n"
+        "import oracle as O, recipe, sppark_amd\n"
+        "f = O.ntt_gl64 if %r == 'gl64' else O.ntt_bb31\n"
+        "for lg in (12, 13, 16, 18, 20):\n"
+        "    x = recipe.ntt_input(%r, lg, 40 + lg)\n"
+        "    for order, direction in ((1, 0), (2, 1), (0, 0), (3, 1)):\n"
+        "        y = x.copy(); sppark_amd.compute_ntt(0, y, order, direction, 0, %r)\n"
+        "        assert (y == f(x, order, direction, 0)).all(), (lg, order, direction)\n"
+        "print('ok')\n") % (os.path.dirname(HERE), os.path.dirname(HERE), field, field, field)
+    for env in ({"SPPARK_NTT_R64_MIN": "99"}, {"SPPARK_NTT_R64_DIRECT": "12"}, {"SPPARK_NTT_R64_DIRECT": "24"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stderr[-2000:])

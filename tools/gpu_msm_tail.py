@@ -62,9 +62,9 @@ for lg in (int(a) for a in args):
         ctx.tune(); ctx.tune_tail()
         auto = ctx.plan(n)["window_bits"]
         best = (1e9, "")
-        for wb in range(max(4, auto - 1), min(lg, auto + 6)):
-            for L in (4, 8, 16, 32, 64):
-                for F in (4, 8):
+        for wb in range(max(4, auto - 1), min(lg, auto + 8)):
+            for L in (8, 16, 32, 64):
+                for F in (4,):
                     if (n * ((255 + wb - 1) // wb)) // L < 4096:
                         continue
                     d = run("wbits=%d L=%d F=%d" % (wb, L, F), wbits=wb, L=L, F=F)

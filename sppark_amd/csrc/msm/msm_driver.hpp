@@ -74,8 +74,10 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // measured optima (profiles/r01_msm_small_sweep.log): ~2^4 entries per bucket at
     // 2^20..2^26; below that the serial depth of the reduction levels dominates and
     // much smaller windows (more, shorter windows in parallel) win
-    unsigned autow = lg >= 22 ? std::min(22u, lg - 4) : lg >= 20 ? 16u : lg == 19 ? 11u
-                   : lg >= 16 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
+    // (round 3, with the sort split following the size and the cheaper tail: 2^17..2^19 moved from 8 / 8 / 11 to
+    // 14 / 15 / 16 bits -- 2^18: 2.15 -> 1.82 ms, 2^19: 3.10 -> 2.42 ms, profiles/r03_msm_small_grid2.log)
+    unsigned autow = lg >= 22 ? std::min(22u, lg - 4) : lg >= 19 ? 16u : lg == 18 ? 15u : lg == 17 ? 14u
+                   : lg == 16 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
     p.wbits = t.wbits ? t.wbits : autow;
     p.wbits = std::min(24u, std::max(2u, p.wbits));
     p.nwins = (scalar_bits - 1) / p.wbits + 1;      // as pippenger.cuh:365
@@ -104,7 +106,7 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // window.  2^23: tail 3.46 -> 2.67 ms with 128, 2^26: 11.5 -> 10.4 ms with 256, profiles/r03_msm_tail.log)
     // Below 2^22 points: 8..64 entries, twice what round 2 used (2^14..2^18: -5..-9 %, profiles/r03_msm_small_grid.log)
     unsigned L = t.L ? t.L : lg >= 22 ? (lg >= 25 ? 256u : 128u)
-                           : (unsigned)std::min<size_t>(64, std::max<size_t>(8, entries / 131072));
+                           : 1u << lg2_floor(std::min<size_t>(64, std::max<size_t>(8, entries / 131072)));
     p.L = L;
     p.chunks_per_win = (p.n + L - 1) / L;
     // point slabs of the level-A histogram / scatter: >= 8 from 2^14 points on (2^18: digits + sort 0.31 -> 0.17 ms with 8)

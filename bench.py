@@ -229,7 +229,10 @@ def main():
                "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "whole forward transform vs 16 B/element algorithmic (one read + one write of the array)"}}
+                            "traffic": 3 * NTT_BYTES_PER_ELEM * (1 << lg) / 1e9 if lg == 24 else None, "traffic_unit": "GB per transform",
+                            "note": "whole forward transform vs 16 B/element algorithmic (one read + one write of the array); traffic = "
+                                    "the three launches' FETCH_SIZE (x2) + WRITE_SIZE from the committed rocprofv3 --pmc passes at 2^24 "
+                                    "(profiles/r03_ntt_gl64_pmc.txt: 268 MB per launch; a recorded constant, not measured in this run)"}}
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:

@@ -191,6 +191,20 @@ SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affi
 SppError sppark_msm_set_points(sppark_msm_ctx *ctx, const void *points, size_t npoints,
                                size_t ffi_affine_sz);
 size_t   sppark_msm_preloaded(const sppark_msm_ctx *ctx);
+/* Fixed-base mode of the preloaded bases (G1 contexts; no counterpart in the reference, whose msm_t keeps the
+ * bases themselves, pippenger.cuh:351-385): besides the points, the context keeps 2^(off_j) * P_i for every
+ * window j of a wide signed-digit split of the scalar (W = ceil(scalar bits / c) windows, c ~ lg npoints, at
+ * most 26; W x the memory, built once on the device with one field inversion per entry).
+ * sppark_msm_invoke(ctx, out, NULL, npoints, ...) over EXACTLY these npoints points then sorts the
+ * W * npoints (digit, multiple) pairs into ONE set of 2^(c-1) buckets: no per-window bucket sums, no
+ * doublings between windows, W instead of ~12 additions per point.  Any other length falls back to the
+ * ordinary path on the points themselves; the result is the same group element either way.
+ * sppark_msm_fixed_base_windows: W of the tables the context holds, 0 without them.  Refused
+ * (hipErrorInvalidValue) when W * npoints >= 2^31.  sppark_msm_tune's wbits, when set, is the c the
+ * tables are built with (8..26); sppark_msm_tune_pipeline's chunking switches the mode off. */
+SppError sppark_msm_set_points_fixed_base(sppark_msm_ctx *ctx, const void *points, size_t npoints,
+                                          size_t ffi_affine_sz);
+unsigned sppark_msm_fixed_base_windows(const sppark_msm_ctx *ctx);
 /* mont != 0: scalars are in Montgomery form (msm_t::invoke's `mont`).
  * points == NULL: use the preloaded points (ffi_affine_sz is then ignored). */
 SppError sppark_msm_invoke(sppark_msm_ctx *ctx, void *out, const void *points, size_t npoints,

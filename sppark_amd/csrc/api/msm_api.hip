@@ -331,7 +331,7 @@ SPPARK_FFI RustError sppark_msm_tune(sppark_msm_ctx* ctx, unsigned wbits, unsign
                                      unsigned K, unsigned nslabs)
 {
     return guarded([&] {
-        if ((K & (K - 1)) || wbits > 24) HIP_OK(hipErrorInvalidValue);
+        if ((K & (K - 1)) || wbits > 26) HIP_OK(hipErrorInvalidValue);     // (25, 26: fixed-base tables only; an ordinary plan stops at 24)
         ctx->impl.tune.wbits = wbits; ctx->impl.tune.L = L; ctx->impl.tune.F = F;
         ctx->impl.tune.K = K; ctx->impl.tune.nslabs = nslabs;
     });
@@ -374,6 +374,12 @@ SPPARK_FFI RustError sppark_msm_invoke(sppark_msm_ctx* ctx, void* out, const voi
 }
 SPPARK_FFI RustError sppark_msm_set_points(sppark_msm_ctx* ctx, const void* points, size_t npoints, size_t ffi_affine_sz)
 {   return guarded([&] { ctx->impl.preload(points, npoints, ffi_affine_sz); });   }
+// the same, and the fixed-base tables of the points are built too (G1 fields with their own bucket records): later
+// sppark_msm_invoke(ctx, out, NULL, npoints, ...) calls over exactly these npoints points run as ONE window over
+// windows x npoints (digit, multiple) pairs; windows x the memory of the plain copy
+SPPARK_FFI RustError sppark_msm_set_points_fixed_base(sppark_msm_ctx* ctx, const void* points, size_t npoints, size_t ffi_affine_sz)
+{   return guarded([&] { ctx->impl.preload(points, npoints, ffi_affine_sz, true); });   }
+SPPARK_FFI unsigned sppark_msm_fixed_base_windows(const sppark_msm_ctx* ctx) { return ctx->impl.fixed_base_windows(); }
 SPPARK_FFI size_t sppark_msm_preloaded(const sppark_msm_ctx* ctx) { return ctx->impl.preloaded(); }
 SPPARK_FFI RustError sppark_msm_enable_timing(sppark_msm_ctx* ctx, int on)
 {   return guarded([&] { ctx->impl.enable_timing(on != 0); });   }

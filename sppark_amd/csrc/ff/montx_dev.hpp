@@ -430,6 +430,26 @@ template<class P, int LB> struct montx_dev {
         return r;
     }
 
+    // a^(p-2) = 1/a by square-and-multiply over the words of the modulus (|*this| normalised, value != 0 mod p;
+    // result normalised, < 2p).  ~NBITS squares + NBITS/2 products: used once per table entry of the fixed-base
+    // mode (msm_kernels.hpp k_fixed_base_table), never on an MSM's hot path.
+    SPPARK_DEVFN montx_dev inverse() const
+    {
+        montx_dev r = one();
+        bool started = false;
+        #pragma unroll 1
+        for (int w = NW - 1; w >= 0; w--) {
+            u32 e = 0, borrow = 2;                              // word w of p - 2 (BLS12-377's p ends in ...00000001)
+            for (int k = 0; k <= w; k++) { e = P::MOD[k] - borrow; borrow = P::MOD[k] < borrow ? 1u : 0u; }
+            #pragma unroll 1
+            for (int b = 31; b >= 0; b--) {
+                if (started) r = r.sqr();
+                if ((e >> b) & 1u) { r = started ? r * *this : *this; started = true; }
+            }
+        }
+        return r;
+    }
+
     // value == 0 (mod p) for a NORMALISED value < KMAX*p: it must be one of 0, p, 2p, ...;
     // the low limb filters out almost everything before the exact comparison.
     template<int KMAX> SPPARK_DEVFN bool is_zero_mod() const

@@ -49,6 +49,7 @@ struct msm_plan {
     unsigned K;                         // bucket-reduction chunk
     unsigned K1;                        // ... of the first level (buckets per work item)
     unsigned G, wpg;                    // window groups, windows per group (the last group may be shorter)
+    unsigned big;                       // level-A partitions above this many entries go to the cooperative level B (0 = the tunable / 2^18)
 };
 
 struct msm_tunables {                   // 0 = automatic
@@ -131,6 +132,7 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     G = std::max(1u, std::min(G, p.nwins));
     p.wpg = (p.nwins + G - 1) / G;
     p.G = (p.nwins + p.wpg - 1) / p.wpg;
+    p.big = 0;
     return p;
 }
 
@@ -152,6 +154,7 @@ public:
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
     static constexpr unsigned MAX_WINS = 128;
     static constexpr size_t LAT_LANES = 65536;              // one wave per SIMD on 256 CUs
+    static constexpr size_t FIXED_BASE_MIN = (size_t)1 << 23;      // points from which set_points_fixed_base builds tables by itself
 
 private:
     const gpu_info* gpu;
@@ -172,6 +175,7 @@ private:
     std::vector<hipEvent_t> tev;        // timing events: [0] start, [1] end, [2+2g], [3+2g] around k_accumulate of group g
     unsigned char* pre_points = nullptr;    // points kept on the device by preload() (msm_t ctor with points, pippenger.cuh:351-385)
     size_t pre_n = 0, pre_stride = 0;
+    unsigned pre_fb_wbits = 0, pre_fb_nwins = 0;    // fixed-base tables: window bits / windows they were built for (0: none)
     float last_ms[4] = {0, 0, 0, 0};    // [0] before the first accumulation, [1] accumulation kernels, [2] whole device part, [3] accumulate launches
     unsigned last_chunks = 0;
     bool timing = false;
@@ -387,13 +391,39 @@ public:
     // Keep a copy of |np| points in HBM for later invoke(out, nullptr, n <= np, scalars, ...)
     // calls: the reference's msm_t(points, np, ffi_affine_sz) + invoke(out, scalars)
     // (pippenger.cuh:351-385,604-605).  |points| may be a host or a device pointer; np == 0 drops the copy.
-    void preload(const void* points, size_t np, size_t ffi_affine_sz)
+    // |fixed_base| (fields with their own records only): also keep the multiples 2^(off_j) * P_i of every point for
+    // every window j (k_fixed_base_table), nwins x the memory; invoke(out, nullptr, np, ...) over exactly these np points
+    // then runs as ONE window over nwins * np (digit, multiple) pairs -- fixed_plan() / invoke_fixed().
+    void preload(const void* points, size_t np, size_t ffi_affine_sz, bool fixed_base = false)
     {
         HIP_OK(hipSetDevice(gpu->hip_id));
         HIP_OK(hipStreamSynchronize(stream));
         join_default_stream();
         if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
+        pre_fb_wbits = pre_fb_nwins = 0;
         if (np == 0) return;
+        if (fixed_base && !INTERNAL) HIP_OK(hipErrorNotSupported);
+        // measured (profiles/r03_msm_fixed_base.log): the one-window MSM wins from 2^24 points on and loses below 2^23
+        // (the tables are gathered from HBM without reuse; the plain path's points are shared by all its windows).  Below the
+        // threshold the call is a plain preload unless a window width was forced (tests, measurements).
+        if (fixed_base && !tune.wbits && np < FIXED_BASE_MIN) fixed_base = false;
+        unsigned fb_w = 0, fb_nw = 1;
+        if (fixed_base) {
+            // window: the c <= 26 with the least arithmetic -- W(c) * np mixed additions into the buckets + two full
+            // additions (~3 mixed ones) for each of the 2^(c-1) buckets of the ONE bucket set
+            // (2^26 points: c = 24, W = 11; c = 26, W = 10 costs the same and 4 x the buckets)
+            if (tune.wbits) fb_w = std::min(26u, std::max(8u, tune.wbits));
+            else {
+                double best = 0;
+                for (unsigned c = 8; c <= 26; c++) {
+                    const double cost = (double)((FRp::NBITS - 1) / c + 1) * (double)np + 3.0 * (double)((size_t)1 << (c - 1));
+                    if (fb_w == 0 || cost < best) { best = cost; fb_w = c; }
+                }
+            }
+            fb_nw = (FRp::NBITS - 1) / fb_w + 1;
+            fb_w = FRp::NBITS / fb_nw + (FRp::NBITS % fb_nw ? 1 : 0);
+            if ((size_t)fb_nw * np >= ((size_t)1 << 31)) HIP_OK(hipErrorInvalidValue);
+        }
         if (points == nullptr || ffi_affine_sz < 2 * FP_BYTES || np > (1u << 31)) HIP_OK(hipErrorInvalidValue);
         struct dev_buf {                // staging copy of host-resident points: freed on every exit path
             unsigned char* p = nullptr;
@@ -408,8 +438,13 @@ public:
                     HIP_OK(hipMemcpyAsync(staging.p, points, np * ffi_affine_sz, hipMemcpyHostToDevice, stream));
                     src = staging.p;
                 }
-                HIP_OK(hipMalloc((void**)&pre_points, np * conv_stride()));
+                HIP_OK(hipMalloc((void**)&pre_points, (size_t)fb_nw * np * conv_stride()));
                 launch_convert(pre_points, src, (unsigned)np, ffi_affine_sz);
+                if (fixed_base) {
+                    hipLaunchKernelGGL(k_fixed_base_table<fp_d>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream,
+                                       pre_points, (unsigned)np, fb_nw, (unsigned)FRp::NBITS);
+                    HIP_OK(hipGetLastError());
+                }
             } else {
                 HIP_OK(hipMalloc((void**)&pre_points, np * ffi_affine_sz));
                 HIP_OK(hipMemcpyAsync(pre_points, points, np * ffi_affine_sz,
@@ -421,7 +456,9 @@ public:
             throw;
         }
         pre_n = np; pre_stride = ffi_affine_sz;
+        if (fixed_base) { pre_fb_wbits = fb_w; pre_fb_nwins = fb_nw; }
     }
+    unsigned fixed_base_windows() const { return pre_fb_nwins; }
     size_t preloaded() const { return pre_n; }
 
 private:
@@ -470,8 +507,10 @@ private:
     // ---- one complete MSM over device-resident data, asynchronously on stream (+ aux) ----------
     // d_points: wire points (stride, flagged) or, when preconverted, the field's own records.
     // h_out: nwins window sums in pinned host memory, valid once |stream| has been synchronised.
+    // |fb_n| != 0: fixed-base mode -- |p| describes ONE window over fb_nwins * fb_n entries; the digits come from the
+    // fb_n scalars cut into fb_nwins real windows (digit (w, i) is entry w * fb_n + i of the one window)
     void sort_group(hipStream_t ss, const msm_plan& p, const layout& l, unsigned b, unsigned w0, unsigned wn,
-                    const u32* d_scalars, bool mont)
+                    const u32* d_scalars, bool mont, unsigned fb_n = 0, unsigned fb_nwins = 0)
     {
         u32* digits = (u32*)(blob + l.digits[b]);
         u32* sorted = (u32*)(blob + l.sorted[b]);
@@ -482,9 +521,15 @@ private:
         u32* offA = (u32*)(blob + l.offA[b]);
         // local index of the first short window of this group (window_len: the first nbits % nwins are long)
         const unsigned nlong = p.nbits % p.nwins, sf = nlong == 0 ? wn : (nlong > w0 ? std::min(wn, nlong - w0) : 0u);
-        unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
-                           digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
+        if (fb_n) {
+            unsigned grid = std::min<unsigned>((fb_n + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
+                               digits, d_scalars, fb_n, fb_nwins, (unsigned)FRp::NBITS, (int)mont, 0u, fb_nwins);
+        } else {
+            unsigned grid = std::min<unsigned>((p.n + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(k_breakdown<fr_d>, dim3(grid), dim3(256), 0, ss,
+                               digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
+        }
         HIP_OK(hipGetLastError());
         size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + SORT_NT * 4 + (size_t)SORTB_STAGE * 4;
         // (the attribute is per device and sticky: raised once to the largest size asked for so far,
@@ -509,7 +554,7 @@ private:
             hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
                                partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         HIP_OK(hipGetLastError());
-        const unsigned big = tune.big ? tune.big : (1u << 18);
+        const unsigned big = tune.big ? tune.big : p.big ? p.big : (1u << 18);
         u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
         HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
         hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
@@ -519,14 +564,21 @@ private:
         hipLaunchKernelGGL(k_big_find, dim3((p.NA * wn + 255) / 256), dim3(256), 0, ss,
                            nbig, blist, off, offA, p.NA, p.LB, sf, wn, big);
         size_t ldsBig = ((size_t)1 << p.LB) * 4;
-        hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf);
-        hipLaunchKernelGGL(k_big_scan, dim3(64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB, sf);
-        hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsBig, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf);
+        // slices per listed partition: 64 (one whole window in a partition), or about half of what k_big_scatter stages
+        // in LDS when the AVERAGE partition is already near the threshold (the one-window plan of the fixed-base mode,
+        // whose partitions differ by a factor of two)
+        const size_t avg = (size_t)p.n / p.NA;
+        const unsigned split = avg > big / 2 ? (unsigned)std::min<size_t>(SORTB_SPLIT, avg / (BIG_STAGE / 2) + 1) : SORTB_SPLIT;
+        hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split);
+        hipLaunchKernelGGL(k_big_scan, dim3(p.NA > 64 && avg > big / 2 ? 1024 : 64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB, sf);
+        const size_t ldsSc = big_scatter_lds(p.LB);
+        if (ldsSc > 65536) lds_attr((const void*)k_big_scatter, ldsSc);
+        hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsSc, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split);
         HIP_OK(hipGetLastError());
     }
 
     void enqueue(const msm_plan& p, const layout& l, const unsigned char* d_points, size_t stride, bool preconverted,
-                 const u32* d_scalars, bool mont, std_bucket_t* h_out, bool first_timed)
+                 const u32* d_scalars, bool mont, std_bucket_t* h_out, bool first_timed, unsigned fb_n = 0, unsigned fb_nwins = 0)
     {
         const bool flagged = !preconverted && stride > 2 * FP_BYTES;
         const bool multi = p.G > 1;
@@ -552,7 +604,7 @@ private:
             const unsigned b = multi ? (gseq & 1) : 0, w0 = g * p.wpg, wn = std::min(p.wpg, p.nwins - w0);
             if (g == 0) {
                 // first group: on the main stream, at full width (stream order protects the set)
-                sort_group(stream, p, l, b, w0, wn, d_scalars, mont);
+                sort_group(stream, p, l, b, w0, wn, d_scalars, mont, fb_n, fb_nwins);
                 if (INTERNAL && !preconverted) {    // wire points -> the field's own records (2 products per point)
                     launch_convert(blob + l.conv, d_points, p.n, stride);
                     d_points = blob + l.conv;
@@ -698,6 +750,69 @@ private:
         return out;
     }
 
+    // The plan of a fixed-base MSM: ONE window of |wbits| bits over fb_nwins * n entries (the multiples are baked into
+    // the table, so every window's digits select from one bucket set).
+    msm_plan fixed_plan(size_t n) const
+    {
+        msm_plan p;
+        const size_t entries = (size_t)pre_fb_nwins * n;
+        const unsigned lg = lg2_floor(entries ? entries : 1);
+        p.n = (unsigned)entries; p.wbits = pre_fb_wbits; p.nwins = 1; p.nbits = pre_fb_wbits;
+        p.NB = 1u << (p.wbits - 1);
+        // level-A partitions of ~2^14 entries as in make_plan, but never more than the 2^12 the LDS-staged scatter
+        // takes: with 2^15 partitions the direct scatter (8-byte stores to 32 768 open rows) alone is 16.7 ms at
+        // 11 x 2^26 entries, against 4.8 ms staged; the partitions are then ~2^17.5 entries and go to level B's
+        // cooperative form in slices (profiles/r03_msm_fixed_base.log)
+        unsigned hb = lg > 14 ? lg - 14 : 0;
+        hb = std::min(std::max(hb, 10u), std::min(p.wbits - 1, 12u));
+        p.LB = tune.LB ? std::min(tune.LB, p.wbits - 1) : p.wbits - 1 - hb;
+        if (p.LB > 13) p.LB = 13;
+        if (p.wbits - 1 - p.LB > 15) p.LB = p.wbits - 1 - 15;
+        p.HB = p.wbits - 1 - p.LB; p.NA = 1u << p.HB;
+        p.L = tune.L ? tune.L : 1u << lg2_floor(std::min<size_t>(256, std::max<size_t>(8, entries / 131072)));
+        p.chunks_per_win = (p.n + p.L - 1) / p.L;
+        p.nslabs = tune.nslabs ? tune.nslabs : (unsigned)std::min<size_t>(1024, std::max<size_t>(entries / 131072, std::min<size_t>(8, std::max<size_t>(1, entries / 2048))));
+        p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
+        p.F = std::max(4u, tune.F ? tune.F : 8u);
+        p.K = std::min(tune.K ? tune.K : 8u, p.NB);
+        p.K1 = std::min(tune.K1 ? tune.K1 : (p.NB >= (1u << 21) ? 16u : p.NB == (1u << 15) ? 8u : p.K), p.NB);
+        p.G = 1; p.wpg = 1;
+        // every partition beyond level B's register form goes to the cooperative form in LDS-staged slices: the
+        // partitions are ALL of one size class here, and one work-group walking 50..300 K entries twice is the slower way
+        // (2^25 points: digits + sort 9.1 -> 6.4 ms, 2^24: 4.2 -> 3.3 ms)
+        p.big = SORTB_STAGE;
+        return p;
+    }
+
+    // out = sum s_i * P_i over the preloaded points through their fixed-base tables: device-resident scalars or host
+    // scalars (copied in one piece), one pass, one window.
+    void invoke_fixed(point_t& out, size_t npoints, const void* scalars, bool mont)
+    {
+        const msm_plan p = fixed_plan(npoints);
+        const layout l = make_layout(p, false);
+        const bool sc_dev = is_device_pointer(scalars);
+        reserve(l.total);
+        reserve_sums(MAX_WINS);
+        const u32* d_scalars = (const u32*)scalars;
+        if (!sc_dev) {
+            reserve_stage(2 * align_up(npoints * SCALAR_BYTES));
+            HIP_OK(hipMemcpyAsync(stage, scalars, npoints * SCALAR_BYTES, hipMemcpyHostToDevice, stream));
+            d_scalars = (const u32*)stage;
+        }
+        enqueue(p, l, pre_points, conv_stride(), true, d_scalars, mont, h_sums, true, (unsigned)npoints, pre_fb_nwins);
+        HIP_OK(hipStreamSynchronize(stream));
+        last_chunks = 1;
+        if (timing) {
+            float acc = 0;
+            HIP_OK(hipEventElapsedTime(&acc, tev[2], tev[3]));
+            HIP_OK(hipEventElapsedTime(&last_ms[0], tev[0], tev[2]));
+            last_ms[1] = acc;
+            HIP_OK(hipEventElapsedTime(&last_ms[2], tev[0], tev[1]));
+            last_ms[3] = 1.f;
+        }
+        out = horner(h_sums, p);                            // one window: its sum is the result
+    }
+
 public:
     // Bitmap batch addition (msm/batch_addition.cuh:25-132): out = sum of the selected points.
     // points / bitmap / refmap (nullable): host or device pointers; maps are ceil(n/32) words.
@@ -784,6 +899,11 @@ public:
         }
         if (scalars == nullptr || ffi_affine_sz < 2 * FP_BYTES) HIP_OK(hipErrorInvalidValue);
         join_default_stream();
+        // fixed-base tables cover exactly the preloaded vector: any other length runs the ordinary path on its first level
+        if (preconverted && pre_fb_nwins && npoints == pre_n && tune.chunk == 0 && tune.max_scratch == 0) {
+            invoke_fixed(out, npoints, scalars, mont);
+            return;
+        }
 
         const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);
         const bool host = !pts_dev || !sc_dev;

@@ -630,6 +630,64 @@ void k_convert_points(unsigned char* __restrict__ dst, const unsigned char* __re
     if (i < n) affine_loader<FP>::template convert<FLAGGED>(dst, src, i, stride);
 }
 
+// ---------------------------------------------------------------------------
+// Fixed-base tables for preloaded points (msm_t::preload(..., fixed_base)): for every point P_i the affine
+// multiples 2^(off_j) * P_i, off_j = the first bit of window j, j < nwins, as records of the field's own format:
+// table[j * n + i].  With them all windows of an MSM share ONE bucket set (entry (j, i) of the digit array is the
+// point j * n + i of a one-window MSM over nwins * n points): no Horner, the bucket sums once instead of per window,
+// and a window as wide as 26 bits (10 instead of 12 additions per point at 2^26 points).  The reference's analogue is
+// the msm_t that keeps its bases on the device (msm/pippenger.cuh:351-385); the tables themselves are new.
+// One work item per point: off_j doublings in XYZZ, then x = X / ZZ, y = Y / ZZZ with one inversion per eight entries
+// (Fermat: ~570 products; a one-time cost of set_points: 2^26 points x 11 windows in ~4 s).  Infinity stays infinity.
+// ---------------------------------------------------------------------------
+template<class FP>
+SPPARK_DEVFN void fixed_base_table_item(unsigned char* table, unsigned n, unsigned nwins, unsigned nbits, size_t i)
+{
+    typedef affine_loader<FP> AL;
+    constexpr unsigned GROUP = 8;                   // entries normalised with ONE inversion (Montgomery's trick; local arrays: scratch)
+    if (i >= n) return;
+    affine_dev<FP> p = load_affine<FP, false>(table, i, 0);           // level 0 = the converted points themselves
+    xyzz_dev<FP> acc; acc.set(p, false);
+    #pragma unroll 1
+    for (unsigned j0 = 1; j0 < nwins; j0 += GROUP) {
+        const unsigned cnt = nwins - j0 < GROUP ? nwins - j0 : GROUP;
+        xyzz_dev<FP> sv[GROUP]; FP pre[GROUP]; bool inf[GROUP];
+        FP run = FP::one();                         // product of ZZ * ZZZ over the finite entries so far
+        #pragma unroll 1
+        for (unsigned g = 0; g < cnt; g++) {
+            #pragma unroll 1
+            for (unsigned k = 0; k < window_len(j0 + g - 1, nwins, nbits); k++) acc.dbl();
+            const FP zz = acc.ZZ * acc.ZZZ;         // ZZ, ZZZ normalised
+            // (ZZ == 0 mod p without all-zero limbs: the double of a point of order two, which BLS12-377's curve has)
+            inf[g] = acc.is_inf() || zz.template is_zero_mod<2>();
+            if (inf[g]) acc.set_inf();
+            sv[g] = acc; pre[g] = run;
+            if (!inf[g]) run = run * zz;
+        }
+        FP inv = run.inverse();                     // 1 / (all of them); peeled from the back
+        #pragma unroll 1
+        for (unsigned g = cnt; g--;) {
+            u32 w[AL::STRIDE / 4] = {};
+            if (inf[g]) {
+                w[FP::NL - 1] = 0x80000000u;        // the flag of an infinite record (bit 31 of X's top limb)
+            } else {
+                const FP zz = sv[g].ZZ * sv[g].ZZZ;
+                const FP iz = inv * pre[g];         // 1 / (ZZ * ZZZ) of entry g
+                inv = inv * zz;
+                const FP x = sv[g].X * (iz * sv[g].ZZZ), y = sv[g].Y * (iz * sv[g].ZZ);    // fat left operands; < 2p, normalised
+                x.to_wire(w); y.to_wire(w + FP::NL);
+            }
+            uint4* q = reinterpret_cast<uint4*>(table + ((size_t)(j0 + g) * n + i) * (size_t)AL::STRIDE);
+            #pragma unroll
+            for (unsigned k = 0; k < AL::STRIDE / 16; k++) q[k] = make_uint4(w[4*k], w[4*k+1], w[4*k+2], w[4*k+3]);
+        }
+    }
+}
+template<class FP>
+__global__ __launch_bounds__(256)
+void k_fixed_base_table(unsigned char* __restrict__ table, unsigned n, unsigned nwins, unsigned nbits)
+{   fixed_base_table_item<FP>(table, n, nwins, nbits, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+
 template<class FP, int STD_WORDS>
 __global__ __launch_bounds__(64)
 void k_finalize(xyzz_mem<STD_WORDS>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ in, unsigned count)

@@ -365,7 +365,11 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
 // (slice, bucket) and LDS cursors inside it.  In the uniform case the list is empty and the three
 // kernels return at once.
 // ---------------------------------------------------------------------------
+// |split| slices per listed partition: 64 for the skewed case (a whole window in one partition); the one-window plan
+// of the fixed-base mode, whose partitions are ALL a few hundred thousand entries, asks for slices of ~16 K entries
+// (one reservation per (slice, bucket) is then one global atomic per ~8 entries, not per entry).
 static constexpr unsigned SORTB_SPLIT = 64;
+static constexpr int BIG_UNROLL = 4;        // loads in flight per lane in the slice loops
 
 __global__ __launch_bounds__(256)
 void k_big_find(u32* __restrict__ nbig, u32* __restrict__ list, u32* __restrict__ off,
@@ -382,33 +386,40 @@ void k_big_find(u32* __restrict__ nbig, u32* __restrict__ list, u32* __restrict_
 }
 
 // slice s of listed partition b; returns false when the work item does not exist
-__device__ inline bool big_slice(const u32* nbig, const u32* list, const u32* offA, unsigned NA, unsigned item,
+__device__ inline bool big_slice(const u32* nbig, const u32* list, const u32* offA, unsigned NA, unsigned item, unsigned split,
                                  unsigned& w, unsigned& khi, unsigned& lo, unsigned& hi)
 {
-    const unsigned b = item / SORTB_SPLIT, s = item % SORTB_SPLIT;
+    const unsigned b = item / split, s = item % split;
     if (b >= *nbig) return false;
     w = list[b] / NA; khi = list[b] % NA;
     const u32* oA = offA + (size_t)w * (NA + 1);
     const unsigned begin = oA[khi], end = oA[khi + 1];
-    const unsigned per = (end - begin + SORTB_SPLIT - 1) / SORTB_SPLIT;
+    const unsigned per = (end - begin + split - 1) / split;
     lo = min(end, begin + s * per); hi = min(end, lo + per);
     return true;
 }
 
 __global__ __launch_bounds__(1024)
 void k_big_hist(u32* __restrict__ off, const uint2* __restrict__ partA, const u32* __restrict__ offA,
-                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned n, unsigned NA, unsigned LBL, unsigned short_from)
+                const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned n, unsigned NA, unsigned LBL, unsigned short_from,
+                unsigned split)
 {
     extern __shared__ u32 lds[];
     const unsigned tid = threadIdx.x;
     for (unsigned item = blockIdx.x; ; item += gridDim.x) {
         unsigned w, khi, lo, hi;
-        if (!big_slice(nbig, list, offA, NA, item, w, khi, lo, hi)) return;
+        if (!big_slice(nbig, list, offA, NA, item, split, w, khi, lo, hi)) return;
         const unsigned LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
         __syncthreads();
         const uint2* src = partA + (size_t)w * n;
-        for (unsigned i = lo + tid; i < hi; i += 1024) atomicAdd(&lds[src[i].y], 1u);
+        for (unsigned i = lo + tid; i < hi; i += BIG_UNROLL * 1024) {
+            u32 k[BIG_UNROLL];
+            #pragma unroll
+            for (int u = 0; u < BIG_UNROLL; u++) { unsigned j = i + u * 1024; k[u] = j < hi ? src[j].y : 0xffffffffu; }
+            #pragma unroll
+            for (int u = 0; u < BIG_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&lds[k[u]], 1u);
+        }
         __syncthreads();
         u32* o = off + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
         for (unsigned j = tid; j < NL; j += 1024) if (lds[j]) atomicAdd(&o[j], lds[j]);
@@ -443,29 +454,83 @@ void k_big_scan(u32* __restrict__ off, u32* __restrict__ cur, const u32* __restr
     }
 }
 
+// Slices of at most BIG_STAGE entries (the one-window plan: every partition listed, ~45 slices each) are read ONCE
+// into registers, reserved per bucket, put in bucket order in LDS together with their destinations and written out as
+// runs -- the direct form below reads the slice twice and stores 4 bytes per lane to 2^LB open rows (7.1 ms for
+// 11 x 2^26 entries, staged: see profiles/r03_msm_fixed_base.log).  LDS: 2^LB cursors + 2^LB (global - local) offsets
+// + 16 scan words + BIG_STAGE (index, destination) pairs.
+static constexpr int BIG_PER = 8;
+static constexpr unsigned BIG_STAGE = BIG_PER * 1024;
+static inline size_t big_scatter_lds(unsigned LB) { return ((size_t)2 << LB) * 4 + 64 + (size_t)BIG_STAGE * 8; }
+
 __global__ __launch_bounds__(1024)
 void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2* __restrict__ partA,
                    const u32* __restrict__ offA, const u32* __restrict__ nbig, const u32* __restrict__ list,
-                   unsigned n, unsigned NA, unsigned LBL, unsigned short_from)
+                   unsigned n, unsigned NA, unsigned LBL, unsigned short_from, unsigned split)
 {
     extern __shared__ u32 lds[];
     const unsigned tid = threadIdx.x;
+    u32* const gdl = lds + ((size_t)1 << LBL);              // (global - local) start of the slice's run of bucket j
+    u32* const wsum = gdl + ((size_t)1 << LBL);
+    u32* const st_idx = wsum + 16;
+    u32* const st_dst = st_idx + BIG_STAGE;
     for (unsigned item = blockIdx.x; ; item += gridDim.x) {
         unsigned w, khi, lo, hi;
-        if (!big_slice(nbig, list, offA, NA, item, w, khi, lo, hi)) return;
+        if (!big_slice(nbig, list, offA, NA, item, split, w, khi, lo, hi)) return;
         const unsigned LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
         __syncthreads();
         const uint2* src = partA + (size_t)w * n;
-        for (unsigned i = lo + tid; i < hi; i += 1024) atomicAdd(&lds[src[i].y], 1u);
-        __syncthreads();
         u32* c = cur + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
-        for (unsigned j = tid; j < NL; j += 1024) if (lds[j]) lds[j] = atomicAdd(&c[j], lds[j]);   // reserve a range
-        __syncthreads();
         u32* dst = sorted + (size_t)w * n;
-        for (unsigned i = lo + tid; i < hi; i += 1024) {
-            const uint2 r = src[i];
-            dst[atomicAdd(&lds[r.y], 1u)] = r.x;
+        if (hi - lo <= BIG_STAGE) {                         // uniform over the work-group
+            uint2 r[BIG_PER];
+            #pragma unroll
+            for (int u = 0; u < BIG_PER; u++) { unsigned jx = lo + u * 1024 + tid; r[u] = jx < hi ? src[jx] : make_uint2(0, 0xffffffffu); }
+            #pragma unroll
+            for (int u = 0; u < BIG_PER; u++) if (r[u].y != 0xffffffffu) atomicAdd(&lds[r[u].y], 1u);
+            __syncthreads();
+            // local exclusive scan of the bucket counts; one global reservation per occupied bucket
+            const unsigned per = (NL + 1023) / 1024, b0 = min(NL, tid * per), b1 = min(NL, b0 + per);
+            u32 sum = 0;
+            #pragma unroll 1
+            for (unsigned b = b0; b < b1; b++) sum += lds[b];
+            u32 all;
+            u32 run = block_scan_excl(sum, wsum, &all);
+            #pragma unroll 1
+            for (unsigned b = b0; b < b1; b++) {
+                const u32 cb = lds[b];
+                if (cb) gdl[b] = atomicAdd(&c[b], cb) - run;
+                lds[b] = run; run += cb;
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int u = 0; u < BIG_PER; u++)
+                if (r[u].y != 0xffffffffu) {
+                    const u32 pos = atomicAdd(&lds[r[u].y], 1u);
+                    st_idx[pos] = r[u].x; st_dst[pos] = pos + gdl[r[u].y];
+                }
+            __syncthreads();
+            for (unsigned i = tid; i < hi - lo; i += 1024) dst[st_dst[i]] = st_idx[i];
+            __syncthreads();
+            continue;
+        }
+        for (unsigned i = lo + tid; i < hi; i += BIG_UNROLL * 1024) {
+            u32 k[BIG_UNROLL];
+            #pragma unroll
+            for (int u = 0; u < BIG_UNROLL; u++) { unsigned jx = i + u * 1024; k[u] = jx < hi ? src[jx].y : 0xffffffffu; }
+            #pragma unroll
+            for (int u = 0; u < BIG_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&lds[k[u]], 1u);
+        }
+        __syncthreads();
+        for (unsigned jx = tid; jx < NL; jx += 1024) if (lds[jx]) lds[jx] = atomicAdd(&c[jx], lds[jx]);   // reserve a range
+        __syncthreads();
+        for (unsigned i = lo + tid; i < hi; i += BIG_UNROLL * 1024) {
+            uint2 r[BIG_UNROLL];
+            #pragma unroll
+            for (int u = 0; u < BIG_UNROLL; u++) { unsigned jx = i + u * 1024; r[u] = jx < hi ? src[jx] : make_uint2(0, 0xffffffffu); }
+            #pragma unroll
+            for (int u = 0; u < BIG_UNROLL; u++) if (r[u].y != 0xffffffffu) dst[atomicAdd(&lds[r[u].y], 1u)] = r[u].x;
         }
         __syncthreads();
     }

@@ -115,6 +115,10 @@ def load(name):
         L.sppark_msm_invoke.restype = _Error
         L.sppark_msm_set_points.argtypes = [vp, vp, sz, sz]
         L.sppark_msm_set_points.restype = _Error
+        L.sppark_msm_set_points_fixed_base.argtypes = [vp, vp, sz, sz]
+        L.sppark_msm_set_points_fixed_base.restype = _Error
+        L.sppark_msm_fixed_base_windows.argtypes = [vp]
+        L.sppark_msm_fixed_base_windows.restype = cu
         L.sppark_msm_preloaded.argtypes = [vp]
         L.sppark_msm_preloaded.restype = sz
         L.sppark_msm_enable_timing.argtypes = [vp, ci]

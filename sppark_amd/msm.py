@@ -131,16 +131,22 @@ class MsmContext:
         keys = ("window_bits", "windows", "buckets_per_window", "run_length", "partitions", "low_bits", "fan_in", "bucket_chunk")
         return dict(zip(keys, [int(v) for v in out]))
 
-    def set_points(self, points, npoints=None, ffi_affine_sz=None):
+    def set_points(self, points, npoints=None, ffi_affine_sz=None, fixed_base=False):
         """Keep a copy of the bases in HBM (msm_t(points, np, ffi_affine_sz),
-        msm/pippenger.cuh:351-385); invoke(None, scalars) then uses them."""
+        msm/pippenger.cuh:351-385); invoke(None, scalars) then uses them.
+        fixed_base: also build the per-window multiples of every point (include/sppark_amd.h,
+        sppark_msm_set_points_fixed_base); invoke(None, scalars) over all of them is then one window."""
         stride = ffi_affine_sz or 2 * self.fb
         if points is None:
             ffi.check(self.L, self.L.sppark_msm_set_points(self.h, None, 0, stride))
             return
         n = npoints if npoints is not None else _npoints(points, stride)
         pp, _k = ffi.as_pointer(points)
-        ffi.check(self.L, self.L.sppark_msm_set_points(self.h, pp, n, stride))
+        fn = self.L.sppark_msm_set_points_fixed_base if fixed_base else self.L.sppark_msm_set_points
+        ffi.check(self.L, fn(self.h, pp, n, stride))
+
+    def fixed_base_windows(self):
+        return int(self.L.sppark_msm_fixed_base_windows(self.h))
 
     def preloaded(self):
         return int(self.L.sppark_msm_preloaded(self.h))

@@ -315,3 +315,62 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     memcpy(out_jac, &out, sizeof(out));
     return 0;
 }
+
+// Fixed-base mode (msm_kernels.hpp fixed_base_table_item): build the tables of 2^(off_j) * P_i with the product's
+// own work item, recode the scalars with the product's recode_digits for the REAL (n, nwins, nbits), and sum the
+// nwins * n (digit, table entry) pairs into ONE bucket set with the entry index w * n + i -- the index contract of
+// msm_driver.hpp's fixed_plan() / invoke_fixed().  The grouped walk itself (accumulate_chunk etc.) is emu_msm's
+// subject; here the buckets are filled in entry order and summed by the running-sum rule.  G1 fields with their
+// own records only (returns 1 otherwise).
+template<class FPX> static int fixed_base_emu(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
+                                              const unsigned char* scalars, unsigned wbits)
+{
+    if constexpr (field_is_internal<FPX>::value) {
+        typedef FPX F;
+        typedef mont_host<curve_p::fp> fp_h;
+        typedef jacobian_host<fp_h> point_t;
+        typedef xyzz_dev<F> B;
+        const unsigned nbits = curve_p::fr::NBITS, n = (unsigned)npoints;
+        unsigned nwins = (nbits - 1) / wbits + 1;
+        wbits = nbits / nwins + (nbits % nwins ? 1 : 0);
+        const unsigned NB = 1u << (wbits - 1);
+        const size_t S = affine_loader<F>::STRIDE;
+        std::vector<uint4> table((size_t)nwins * n * S / 16 + 1);
+        const bool flagged = stride > 2 * sizeof(fp_h);
+        for (size_t i = 0; i < n; i++) {
+            if (flagged) affine_loader<F>::template convert<true>((unsigned char*)table.data(), points, i, (unsigned)stride);
+            else         affine_loader<F>::template convert<false>((unsigned char*)table.data(), points, i, (unsigned)stride);
+        }
+        for (size_t i = 0; i < n; i++) fixed_base_table_item<F>((unsigned char*)table.data(), n, nwins, nbits, i);
+        std::vector<u32> digits((size_t)nwins * n), sc32((size_t)n * fr_d::N + 8);
+        memcpy(sc32.data(), scalars, (size_t)n * sizeof(fr_d));
+        for (unsigned i = 0; i < n; i++) {
+            bool flip;
+            fr_d s = load_scalar_abs<fr_d>(sc32.data(), i, 0, flip);
+            u32 limbs[fr_d::N + 2] = {0};
+            for (int k = 0; k < fr_d::N; k++) limbs[k] = s.v[k];
+            recode_digits(digits.data(), n, i, [&](unsigned k) { return limbs[k]; }, flip, nwins, nbits);
+        }
+        std::vector<B> bucket(NB);
+        for (auto& b : bucket) b.set_inf();
+        for (size_t e = 0; e < (size_t)nwins * n; e++) {
+            const u32 d = digits[e];
+            if (!d) continue;
+            bucket[(d & 0x7fffffffu) - 1].madd(load_affine<F, false>((const unsigned char*)table.data(), e, 0), d >> 31);
+        }
+        B run, sum; run.set_inf(); sum.set_inf();           // sum_b (b + 1) * bucket[b]
+        for (unsigned b = NB; b--;) { run.add(bucket[b]); sum.add(run); }
+        xyzz_mem<sizeof(fp_h) / 4> fin;
+        sum.store_std(&fin);
+        fp_h c[4];
+        memcpy(c, &fin, sizeof(c));
+        point_t out = point_t::from_xyzz(c[0], c[1], c[2], c[3]);
+        memcpy(out_jac, &out, sizeof(out));
+        return 0;
+    } else {
+        return 1;
+    }
+}
+extern "C" int emu_fixed_base(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
+                              const unsigned char* scalars, unsigned wbits)
+{   return fixed_base_emu<inst_fp>(out_jac, points, stride, npoints, scalars, wbits);   }

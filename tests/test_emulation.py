@@ -35,6 +35,7 @@ def _emu(feature, g2=False):
     L.emu_xyzz_op.argtypes = [ci, vp, vp, vp, sz]
     L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu, ci, vp, cu]
     L.emu_pairs_check.argtypes = [vp, sz, sz]
+    L.emu_fixed_base.argtypes = [vp, vp, sz, sz, vp, cu]
     return L
 
 
@@ -177,3 +178,17 @@ def test_msm_bucket_sum_top_on_host(oracle):
         out = np.zeros(144, dtype=np.uint8)
         L.emu_msm(P(out), P(pts), 96, n, P(sc), 0, wb, 8, 4, K, 2, 1, None, top)
         assert (O.jac_to_affine(0, out) == exp).all(), (wb, K, top)
+
+
+@pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])
+def test_fixed_base_tables_on_host(oracle, curve, feature):
+    """the fixed-base table work item (2^(off_j) * P_i, affine, one inversion per entry), the digit <-> table
+    entry contract (entry w * n + i) and the one-bucket-set sum against the oracle's MSM"""
+    O = oracle
+    L = _emu(feature)
+    fb = O.FP_BYTES[curve]
+    for n, wb, flagged in ((1, 8, False), (37, 9, True), (200, 13, False), (64, 17, True)):
+        pts, sc = recipe.msm_inputs(curve, n, 77 + n + wb, flagged=flagged)     # (edge cases: infinity, zero / r - 1 scalars)
+        out = np.zeros(3 * fb, dtype=np.uint8)
+        assert L.emu_fixed_base(P(out), P(pts), pts.shape[1], n, P(sc), wb) == 0
+        assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb)

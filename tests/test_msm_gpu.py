@@ -360,6 +360,46 @@ def test_msm_preloaded_points(oracle, libs):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,curve", [("bls12_381", 0), ("bn254", 1), ("bls12_377", 4), ("pallas", 6)])
+def test_msm_fixed_base_tables(oracle, libs, name, curve):
+    """sppark_msm_set_points_fixed_base: the per-window multiples of the preloaded bases, and an MSM over all of
+    them as ONE window over windows x npoints (digit, multiple) pairs -- against the oracle, for host and device
+    scalars, Montgomery-form scalars, edge-case inputs (infinity, zero and r - 1 scalars, repeated points), forced
+    window widths (many narrow windows ... fewer, wider ones than the size asks for), and the fall-back to the plain
+    path for a prefix."""
+    import torch
+    import sppark_amd
+    from sppark_amd import ffi
+    O = oracle
+    ctx = sppark_amd.MsmContext(name)
+    # (below 2^23 points the tables are built only when a width is forced: include/sppark_amd.h)
+    for n, wb, flagged in ((1, 8, False), (300, 10, True), (5000, 13, False), (5000, 9, True), (3000, 21, False), (700, 26, False),
+                           ((1 << 16) + 3, 16, True), (5000, 0, True)):
+        pts, sc = recipe.msm_inputs(curve, n, 900 + n + wb, ndistinct=min(n, 700), flagged=flagged)
+        ctx.tune(wbits=wb)
+        ctx.set_points(pts, ffi_affine_sz=pts.shape[1], fixed_base=True)
+        ctx.tune(wbits=0)                                   # the tables keep the width they were built with
+        W = ctx.fixed_base_windows()
+        assert ctx.preloaded() == n
+        assert W == (-(-O.FR_MODULUS[curve].bit_length() // wb) if wb else 0)
+        exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
+        assert (sppark_amd.to_affine(ctx.invoke(None, sc), name) == exp).all(), (name, n, wb, "host scalars")
+        d_sc = torch.from_numpy(sc).cuda()
+        assert (sppark_amd.to_affine(ctx.invoke(None, d_sc), name) == exp).all(), (name, n, wb, "device scalars")
+        assert (sppark_amd.to_affine(ctx.invoke(None, d_sc), name) == exp).all(), (name, n, wb, "again")
+        if n >= 300:                                        # a prefix: the plain path on the points themselves
+            m = n // 3
+            assert (sppark_amd.to_affine(ctx.invoke(None, d_sc[:m].contiguous(), npoints=m), name)
+                    == O.msm_affine(curve, pts[:m], sc[:m], algo=0, param=8)).all(), (name, n, wb, "prefix")
+    # plain preload afterwards drops the tables
+    ctx.set_points(pts, ffi_affine_sz=pts.shape[1])
+    assert ctx.fixed_base_windows() == 0
+    assert (sppark_amd.to_affine(ctx.invoke(None, sc), name) == exp).all()
+    ctx.set_points(None)
+    assert ctx.preloaded() == 0 and ctx.fixed_base_windows() == 0
+    ctx.close()
+
+
 def test_msm_large_linearity(oracle, libs):
     """2^20 points: MSM(P, a) + MSM(P, b) == MSM(P, a+b mod r) and the 2^16
     prefix equals the oracle -- size-independent properties at a size the

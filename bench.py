@@ -250,6 +250,23 @@ def main():
             ctx.invoke(None, sc)
         torch.cuda.synchronize()
         extras["bls12_381_g1_msm_preloaded_bases_points_per_s"] = 3 * n / (time.perf_counter() - t1)
+        # fixed-base mode of the same preloaded bases (include/sppark_amd.h sppark_msm_set_points_fixed_base: the
+        # per-window multiples of every point are built once, the MSM is ONE window over windows x n entries); from
+        # 2^23 points on; the table build is a one-time cost reported beside it.  Same scalars: same expected point.
+        if n >= (1 << 23):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            ctx.set_points(pts, fixed_base=True)
+            torch.cuda.synchronize()
+            fb = {"table_build_s": time.perf_counter() - t1, "windows": ctx.fixed_base_windows()}
+            fout = ctx.invoke(None, sc)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                fout = ctx.invoke(None, sc)
+            torch.cuda.synchronize()
+            fb["points_per_s"] = 3 * n / (time.perf_counter() - t1)
+            fb["equals_oracle"] = bool((sppark_amd.to_affine(fout) == expect).all())
+            assert fb["equals_oracle"], "fixed-base MSM differs from the oracle"
+            extras["bls12_381_g1_msm_fixed_base"] = fb
         ctx.set_points(None)
         bctx = sppark_amd.MsmContext("bn254", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
         bout = bctx.invoke(bpts, bsc)

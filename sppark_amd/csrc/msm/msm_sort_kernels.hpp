@@ -376,13 +376,22 @@ void k_big_find(u32* __restrict__ nbig, u32* __restrict__ list, u32* __restrict_
                 const u32* __restrict__ offA, unsigned NA, unsigned LBL, unsigned short_from, unsigned nwins, unsigned big)
 {
     const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= NA * nwins) return;
-    const unsigned w = id / NA, khi = id % NA, LB = window_lb(LBL, w, short_from);
-    const u32* oA = offA + (size_t)w * (NA + 1);
-    if (oA[khi + 1] - oA[khi] <= big) return;
-    list[atomicAdd(nbig, 1u)] = id;
-    u32* o = off + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
-    for (unsigned j = 0; j < (1u << LB); j++) o[j] = 0;                 // counters of the histogram step
+    bool listed = false;
+    if (id < NA * nwins) {
+        const unsigned w = id / NA, khi = id % NA;
+        const u32* oA = offA + (size_t)w * (NA + 1);
+        listed = oA[khi + 1] - oA[khi] > big;
+        if (listed) list[atomicAdd(nbig, 1u)] = id;
+    }
+    // counters of the histogram step: the wave clears the rows of its listed partitions together (one lane walking
+    // 2^LB words alone was 0.3 ms when every partition is listed -- the one-window plan of the fixed-base mode)
+    unsigned long long m = __ballot(listed);
+    while (m) {
+        const unsigned l = __builtin_ctzll(m); m &= m - 1;
+        const unsigned pid = (id & ~63u) + l, w = pid / NA, khi = pid % NA, LB = window_lb(LBL, w, short_from);
+        u32* o = off + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
+        for (unsigned j = threadIdx.x & 63; j < (1u << LB); j += 64) o[j] = 0;
+    }
 }
 
 // slice s of listed partition b; returns false when the work item does not exist

@@ -90,11 +90,21 @@ class ntt_engine {
     // fewer passes: 2^24 in 2.8 ms with S = 4, 3.3 ms with S = 6 (tools/gpu_ntt_wide_knobs.py).
     static constexpr unsigned S_MAX = sizeof(F) > 8 ? 4 : 8;
 
+    // 256-bit elements: tables up to 2^24 entries (512 MB; every sub-problem of the pass reads its table once, the small
+    // ones from L2 / the Infinity Cache).  The per-element alternative is a lo x hi product per twiddle: one of the ~3.5
+    // products per element and pass.  BLS12-381 Fr 2^24 forward (profiles/r03_ntt_wide_tables.log): 2.80 ms without
+    // tables, 2.43 with tables up to 2^16, 2.33 up to 2^20, 2.25 up to 2^24 -- even the table as large as the data pays,
+    // the passes are bound by their products.  SPPARK_NTT_WIDE_TABLE=<log2> moves the limit (0: no tables).
+    static unsigned wide_table_lg()
+    {
+        static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_WIDE_TABLE"); return e ? (unsigned)atoi(e) : 24u; }();
+        return v;
+    }
     // the inter-pass twiddle table of a pass on sub-problems of 2^lg_cur elements (built once per
     // (device, size, direction, pass shape); null when the pass generates its twiddles instead)
     const F* pass_table(int hip_dev, unsigned lg, int inverse, unsigned lg_cur, unsigned S, const ntt_tables<F>& T, hipStream_t stream)
     {
-        if (!ntt_gen_twiddles<F>::value || lg_cur > PASS_TABLE_MAX_LG || lg_cur <= S || S / 2 == 0) return nullptr;
+        if (lg_cur > (ntt_gen_twiddles<F>::value ? PASS_TABLE_MAX_LG : wide_table_lg()) || lg_cur <= S || S / 2 == 0) return nullptr;
         std::lock_guard<std::mutex> lk(mtx);
         table_set& ts = cache.find(std::make_tuple(hip_dev, lg, inverse))->second;
         auto key = std::make_pair(lg_cur, S);

@@ -231,9 +231,11 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
         // w^(col * rev_S(a*2^R2 + b)) = w^(col*rev(a)) * (w^(col << R1))^rev(b)
         constexpr bool GEN = ntt_gen_twiddles<F>::value;
         F pw[GEN ? (1u << R2) : 1];
-        const bool tabled = GEN && T.pass_tw != nullptr;        // uniform over the launch
+        const bool tabled = T.pass_tw != nullptr;               // uniform over the launch
+        // (wide elements: the table entry is loaded where it is used -- one product per element instead of the
+        // lo x hi product that makes the twiddle plus the one that applies it)
         if (GEN && geo.lgQ) {
-            if (tabled) {
+            if (GEN && tabled) {
                 #pragma unroll
                 for (unsigned b = 0; b < (1u << R2); b++)        // natural b here; used as pw[b] below
                     pw[b] = T.pass_tw[((size_t)((a << R2) + b) << geo.lgQ) + geo.c0 + c];
@@ -251,6 +253,7 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
                 x[b] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
                 if (geo.lgQ) {
                     if (GEN) x[b] = x[b] * pw[GEN ? (tabled ? b : bit_rev32(b, R2)) : 0];
+                    else if (tabled) x[b] = x[b] * T.pass_tw[((size_t)((a << R2) + b) << geo.lgQ) + geo.c0 + c];
                     else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
             }
@@ -261,6 +264,7 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
             for (unsigned b = 0; b < (1u << R2); b++) {
                 if (geo.lgQ) {
                     if (GEN) x[b] = x[b] * pw[GEN ? (tabled ? b : bit_rev32(b, R2)) : 0];
+                    else if (tabled) x[b] = x[b] * T.pass_tw[((size_t)((a << R2) + b) << geo.lgQ) + geo.c0 + c];
                     else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
                 if (P.apply_scale) x[b] = x[b] * T.scale;

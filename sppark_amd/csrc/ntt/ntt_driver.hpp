@@ -71,7 +71,7 @@ template<class F>
 class ntt_engine {
     struct table_set {
         F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale;
-        std::map<std::pair<unsigned, unsigned>, F*> pass_tw;    // (lg_cur, S) -> inter-pass twiddle table of that pass
+        std::map<std::tuple<unsigned, unsigned, int>, F*> pass_tw;  // (lg_cur, S, scaled) -> inter-pass twiddle table of that pass
         std::map<std::tuple<unsigned, unsigned, int>, F*> r64_tw;   // (kind, lg_cur, scaled) -> table of the radix-64 plan
     };
     // the radix-64 plan (ntt_r64_kernels.hpp): single-word fields, transforms of >= 2^12 elements
@@ -102,18 +102,20 @@ class ntt_engine {
     }
     // the inter-pass twiddle table of a pass on sub-problems of 2^lg_cur elements (built once per
     // (device, size, direction, pass shape); null when the pass generates its twiddles instead)
-    const F* pass_table(int hip_dev, unsigned lg, int inverse, unsigned lg_cur, unsigned S, const ntt_tables<F>& T, hipStream_t stream)
+    static bool has_pass_table(unsigned lg_cur, unsigned S)
+    {   return !(lg_cur > (ntt_gen_twiddles<F>::value ? PASS_TABLE_MAX_LG : wide_table_lg()) || lg_cur <= S || S / 2 == 0);   }
+    const F* pass_table(int hip_dev, unsigned lg, int inverse, unsigned lg_cur, unsigned S, int scaled, const ntt_tables<F>& T, hipStream_t stream)
     {
-        if (lg_cur > (ntt_gen_twiddles<F>::value ? PASS_TABLE_MAX_LG : wide_table_lg()) || lg_cur <= S || S / 2 == 0) return nullptr;
+        if (!has_pass_table(lg_cur, S)) return nullptr;
         std::lock_guard<std::mutex> lk(mtx);
         table_set& ts = cache.find(std::make_tuple(hip_dev, lg, inverse))->second;
-        auto key = std::make_pair(lg_cur, S);
+        auto key = std::make_tuple(lg_cur, S, scaled);
         auto it = ts.pass_tw.find(key);
         if (it != ts.pass_tw.end()) return it->second;
         F* tw = nullptr;
         const size_t n = (size_t)1 << lg_cur;
         HIP_OK(hipMalloc((void**)&tw, n * sizeof(F)));
-        hipLaunchKernelGGL(k_pass_table<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, T, lg_cur, S);
+        hipLaunchKernelGGL(k_pass_table<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, T, lg_cur, S, scaled);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(stream);      // visible to every later call on any stream
         if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
@@ -219,6 +221,14 @@ public:
         } else {
             pl = make_ntt_plan(lg, lgc, lgt, smax);
         }
+        int scale_pass = -1;                        // (the radix-64 plan folds the scaling into its own last table)
+        if (inverse && !rp.nsteps) {
+            unsigned best = ~0u;
+            for (unsigned i = 0; i < pl.npass; i++) {
+                const ntt_pass& q = pl.pass[gs ? i : pl.npass - 1 - i];
+                if (has_pass_table(q.lg_cur, q.S) && q.lg_cur < best) { best = q.lg_cur; scale_pass = (int)i; }
+            }
+        }
         for (unsigned i = 0; i < pl.npass; i++) {
             const bool last = i == pl.npass - 1;
             ntt_pass P;
@@ -252,8 +262,11 @@ public:
             } else {
                 P = pl.pass[gs ? i : pl.npass - 1 - i];
             }
-            P.apply_scale = inverse && last;
-            T.pass_tw = pass_table(gpu.hip_id, lg, inverse, P.lg_cur, P.S, T, stream);
+            // 1/n of an inverse transform: carried by the table of the tabled pass on the smallest sub-problems when the
+            // plan has one (a product per element saved), applied by the last pass otherwise
+            const bool scale_here = inverse && scale_pass == (int)i;
+            P.apply_scale = inverse && last && scale_pass < 0;
+            T.pass_tw = pass_table(gpu.hip_id, lg, inverse, P.lg_cur, P.S, scale_here ? 1 : 0, T, stream);
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);
             size_t lds = ntt_lds_elems(P) * sizeof(F);

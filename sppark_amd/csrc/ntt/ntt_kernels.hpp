@@ -462,17 +462,20 @@ __global__ __launch_bounds__(256) void k_tables(F* lo, F* hi, F* inner, F base, 
 {   table_item(lo, hi, inner, base, lg_n, h, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
 
 // pass_tw[(mid << lgQ) + col] = w_{n_cur}^(col * rev_S(mid)), n_cur = 2^lg_cur, lgQ = lg_cur - S
+// |scaled|: times T.scale (1/n of the inverse transform: every element of a tabled pass is multiplied by its entry
+// exactly once, so one pass's table can carry the scaling of the whole transform)
 template<class F>
-SPPARK_DEVFN void pass_table_item(F* tw, const ntt_tables<F>& T, unsigned lg_cur, unsigned S, size_t i)
+SPPARK_DEVFN void pass_table_item(F* tw, const ntt_tables<F>& T, unsigned lg_cur, unsigned S, size_t i, int scaled = 0)
 {
     const unsigned lgQ = lg_cur - S;
     if (i >= ((size_t)1 << lg_cur)) return;
     const size_t col = i & (((size_t)1 << lgQ) - 1), mid = i >> lgQ;
-    tw[i] = ntt_twiddle(T, (col * bit_rev32((unsigned)mid, S)) << (T.lg_n - lg_cur));
+    F t = ntt_twiddle(T, (col * bit_rev32((unsigned)mid, S)) << (T.lg_n - lg_cur));
+    tw[i] = scaled ? t * T.scale : t;
 }
 template<class F>
-__global__ __launch_bounds__(256) void k_pass_table(F* tw, ntt_tables<F> T, unsigned lg_cur, unsigned S)
-{   pass_table_item(tw, T, lg_cur, S, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+__global__ __launch_bounds__(256) void k_pass_table(F* tw, ntt_tables<F> T, unsigned lg_cur, unsigned S, int scaled)
+{   pass_table_item(tw, T, lg_cur, S, (size_t)blockIdx.x * blockDim.x + threadIdx.x, scaled);   }
 
 // ---- planning (host) ---------------------------------------------------------
 struct ntt_plan { ntt_pass pass[16]; unsigned npass; };

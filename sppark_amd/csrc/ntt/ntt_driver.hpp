@@ -88,6 +88,10 @@ class ntt_engine {
     // stages per pass.  256-bit elements: radix-4 x radix-4 (S = 4).  Larger register radices keep
     // 8 or 16 eight-word elements per lane (152 VGPRs, scratch) and measured slower in spite of
     // fewer passes: 2^24 in 2.8 ms with S = 4, 3.3 ms with S = 6 (tools/gpu_ntt_wide_knobs.py).
+    // Round 3, with the twiddle tables and the <3, 3> kernel freed of its scratch use (its eight-element write-out loop
+    // is above clang's #pragma-unroll budget; -mllvm -pragma-unroll-threshold=200000: 193 VGPRs, no scratch): 2.55 ms
+    // with S = 6 against 2.54 with S = 4 on the same box, S = 5 2.81 -- a third fewer instructions and two passes less
+    // buy nothing at two waves per SIMD (LDS: 256 B per lane).  Not instantiated.  profiles/r03_ntt_wide_stages.log
     static constexpr unsigned S_MAX = sizeof(F) > 8 ? 4 : 8;
 
     // 256-bit elements: tables up to 2^24 entries (512 MB; every sub-problem of the pass reads its table once, the small

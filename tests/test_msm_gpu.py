@@ -725,6 +725,40 @@ def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("curve,name,lg", [(0, "bls12_381", 23), (1, "bn254", 24), (0, "bls12_381", 26)])
+def test_msm_fixed_base_full_size_vs_oracle(oracle, libs, curve, name, lg):
+    """the fixed-base mode at the sizes it builds its tables by itself (>= 2^23 points: automatic window, 2^12
+    staged level-A partitions, the cooperative level B in LDS-staged slices on ALL partitions), against the ORACLE
+    through the period of the inputs: periodic scalars with the recipe's edge rows, then independent uniform scalars;
+    the size is NOT a power of two (ragged last slab / slice / run), and a prefix falls back to the plain path."""
+    import torch
+    import sppark_amd
+    from sppark_amd import synth
+    from oracle import fold
+    O = oracle
+    per = 2048
+    n = (1 << lg) + 3 * per
+    r = O.FR_MODULUS[curve]
+    base, sc = recipe.msm_inputs(curve, per, 2323 + lg, ndistinct=per, edge=True)
+    d_base = torch.from_numpy(base).cuda(); d_sc = torch.from_numpy(sc).cuda()
+    idx = torch.arange(n, device="cuda") % per
+    pts = d_base[idx].contiguous(); scal = d_sc[idx].contiguous()
+    ctx = sppark_amd.MsmContext(name, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.set_points(pts, fixed_base=True)
+    del pts
+    assert ctx.fixed_base_windows() >= 10 and ctx.preloaded() == n
+    got = sppark_amd.to_affine(ctx.invoke(None, scal), name)
+    assert (got == O.msm_affine(curve, base, fold.fold_scalars(scal, per, r), algo=0, param=8)).all()
+    del scal
+    rnd = synth.uniform_scalars(n, name, seed=5)
+    whole = sppark_amd.to_affine(ctx.invoke(None, rnd), name)
+    assert (whole == O.msm_affine(curve, base, fold.fold_scalars(rnd, per, r), algo=0, param=8)).all()
+    m = (n // 2 // per) * per                                    # a prefix: the plain path on the tables' first level
+    assert (sppark_amd.to_affine(ctx.invoke(None, rnd[:m].contiguous(), npoints=m), name)
+            == O.msm_affine(curve, base, fold.fold_scalars(rnd[:m].contiguous(), per, r), algo=0, param=8)).all()
+    ctx.close()
+
+
 # ------------------------------------------------- bucket sums: chunked levels vs the subset-sum top
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_msm_bucket_sum_top(oracle, libs, curve, name):

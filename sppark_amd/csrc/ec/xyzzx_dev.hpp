@@ -22,6 +22,9 @@ namespace sppark_amd {
 // coordinate fields with their own point/bucket records (converted on the way in and out)
 template<class FP> struct field_is_internal { static constexpr bool value = false; };
 template<class P, int LB> struct field_is_internal<montx_dev<P, LB>> { static constexpr bool value = true; };
+// ... of which the base field itself (G1): interleaved-pair point operations, gather prefetch, fixed-base tables
+template<class FP> struct field_is_montx { static constexpr bool value = false; };
+template<class P, int LB> struct field_is_montx<montx_dev<P, LB>> { static constexpr bool value = true; };
 
 // Points converted once per MSM into X | Y internal limbs (2*NL words, 16-byte aligned
 // stride); the infinity flag rides in bit 31 of X's top limb (a value < 2p leaves it free).

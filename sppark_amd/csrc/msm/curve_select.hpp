@@ -6,6 +6,7 @@
 #include "../ff/fp2_dev.hpp"
 #include "../ec/xyzz_dev.hpp"
 #include "../ec/xyzzx_dev.hpp"
+#include "../ec/xyzzx2_dev.hpp"
 
 namespace sppark_amd {
 #if defined(FEATURE_BLS12_381)
@@ -41,9 +42,16 @@ typedef xyzz_dev<fp_d> wire_bucket_d;       // XYZZ in the reference's wire form
 typedef wire_bucket_d::mem_t wire_bucket_m;
 typedef xyzz_dev<msm_fp_d> bucket_d;       // register type
 typedef bucket_d::mem_t bucket_m;           // memory image between the kernels
-// G2: same pipeline over the quadratic extension (ff/fp2_dev.hpp).  The kernel
-// translation units are compiled a second time with -DSPPARK_G2 to instantiate it.
-typedef fp2_dev<curve_p::fp> fp2_d;
+// G2: same pipeline over the quadratic extension.  The kernel translation units are compiled a second time with
+// -DSPPARK_G2 to instantiate it.  Round 3: over the loosely-reduced 28-bit-limb base field (ff/fp2x_dev.hpp,
+// ec/xyzzx2_dev.hpp) like G1; fp2_dev<> over the canonical 32-bit-limb class remains the wire-format type
+// (-DSPPARK_FP2_32LIMB: the old pipeline type, for A/B).
+typedef fp2_dev<curve_p::fp> fp2_wire_d;
+#if !defined(SPPARK_FP2_32LIMB)
+typedef fp2x_dev<curve_p::fp, 28> fp2_d;
+#else
+typedef fp2_wire_d fp2_d;
+#endif
 typedef xyzz_dev<fp2_d> bucket2_d;
 typedef bucket2_d::mem_t bucket2_m;
 #ifdef SPPARK_G2

@@ -149,6 +149,7 @@ public:
     static constexpr int STD_WORDS = sizeof(FH) / 4;        // 32-bit words of a coordinate in the reference's wire form
     static constexpr size_t FP_BYTES = sizeof(FH);
     static constexpr bool INTERNAL = field_is_internal<FD>::value;      // ff/montx_dev.hpp: own point/bucket records
+    static constexpr bool MONTX = field_is_montx<FD>::value;            // ... over the base field (G1): low-latency kernels, fixed-base tables
     typedef xyzz_mem<STD_WORDS> std_bucket_t;
     static_assert(INTERNAL || sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
@@ -402,7 +403,7 @@ public:
         if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
         pre_fb_wbits = pre_fb_nwins = 0;
         if (np == 0) return;
-        if (fixed_base && !INTERNAL) HIP_OK(hipErrorNotSupported);
+        if (fixed_base && !MONTX) HIP_OK(hipErrorNotSupported);
         // measured (profiles/r03_msm_fixed_base.log): the one-window MSM wins from 2^24 points on and loses below 2^23
         // (the tables are gathered from HBM without reuse; the plain path's points are shared by all its windows).  Below the
         // threshold the call is a plain preload unless a window width was forced (tests, measurements).
@@ -440,7 +441,7 @@ public:
                 }
                 HIP_OK(hipMalloc((void**)&pre_points, (size_t)fb_nw * np * conv_stride()));
                 launch_convert(pre_points, src, (unsigned)np, ffi_affine_sz);
-                if (fixed_base) {
+                if constexpr (MONTX) if (fixed_base) {
                     hipLaunchKernelGGL(k_fixed_base_table<fp_d>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream,
                                        pre_points, (unsigned)np, fb_nw, (unsigned)FRp::NBITS);
                     HIP_OK(hipGetLastError());
@@ -682,8 +683,8 @@ private:
             // the _lat kernels (no register cap, products in pairs); larger ones are work: two waves per SIMD
             const u32* offp = multi ? (const u32*)nullptr : (const u32*)(blob + l.off[0]);
             bool lat = false;
-            if constexpr (INTERNAL) lat = nthr <= LAT_LANES && tune.join != 3;
-            if constexpr (INTERNAL) {
+            if constexpr (MONTX) lat = nthr <= LAT_LANES && tune.join != 3;
+            if constexpr (MONTX) {
                 if (lat) hipLaunchKernelGGL(k_bucket_level1_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                                             A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
             }
@@ -711,8 +712,8 @@ private:
                 unsigned K = std::min(p.K, nitems);
                 nthr = (size_t)p.nwins * (nitems / K);
                 lat = false;
-                if constexpr (INTERNAL) lat = nthr <= LAT_LANES && tune.join != 3;
-                if constexpr (INTERNAL) {
+                if constexpr (MONTX) lat = nthr <= LAT_LANES && tune.join != 3;
+                if constexpr (MONTX) {
                     if (lat) hipLaunchKernelGGL(k_bucket_levelN_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                                                 oa, ow, ia, iw, nitems, K, lgG, p.nwins);
                 }

@@ -165,7 +165,7 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
     // with the compiler's allocation: 42 spilled registers without this prefetch, 93 with it, 29 with
     // single-chain products on top; 174 / 200 ms against 112 ms.  The prefetch itself is worth 1 %:
     // 113.4 vs 112.4 ms.  profiles/r02_msm_accumulate_waves_ab.log)
-    constexpr bool PREFETCH = field_is_internal<FP>::value;
+    constexpr bool PREFETCH = field_is_montx<FP>::value;
     u32 e_next = 0, e_next2 = 0;                    // the index list runs two entries ahead, so that the
     affine_dev<FP> pt_next = pt;                    // gather's address never waits for its own load
     if (PREFETCH && p + 1 < end) { e_next = src[p + 1]; pt_next = load_affine<FP, FLAGGED>(points, e_next & 0x7fffffffu, stride); }
@@ -201,7 +201,7 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
 // tools/gpu_r2_job23.sh).  The 14-limb fields stay at two waves: 230 registers, and every attempt at
 // 168 spilled enough to lose (profiles/r02_msm_accumulate_waves_ab.log).
 template<class FP, bool FLAGGED>
-__global__ __launch_bounds__(256, (field_is_internal<FP>::value && FP::N <= 10) ? 3 : 1)
+__global__ __launch_bounds__(256, (field_is_internal<FP>::value && FP::N <= 10) ? 3 : (field_is_internal<FP>::value && FP::N <= 20) ? 2 : 1)
 void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
                   u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict__ rec_pt,
                   const unsigned char* __restrict__ points, unsigned stride,
@@ -439,9 +439,9 @@ template<class FP> SPPARK_DEVFN void bucket_dbl(xyzz_dev<FP>& a)
 {   if constexpr (FP::N > 16) xyzz_dbl_outlined<FP>(a); else a.dbl();   }
 // the low-latency forms (products in interleaved pairs) where the field has them: the top of the bucket sums
 template<class FP> SPPARK_DEVFN void bucket_add_fast(xyzz_dev<FP>& a, const xyzz_dev<FP>& b)
-{   if constexpr (field_is_internal<FP>::value) a.add_pairs(b); else bucket_add<FP>(a, b);   }
+{   if constexpr (field_is_montx<FP>::value) a.add_pairs(b); else bucket_add<FP>(a, b);   }
 template<class FP> SPPARK_DEVFN void bucket_dbl_fast(xyzz_dev<FP>& a)
-{   if constexpr (field_is_internal<FP>::value) a.dbl_pairs(); else bucket_dbl<FP>(a);   }
+{   if constexpr (field_is_montx<FP>::value) a.dbl_pairs(); else bucket_dbl<FP>(a);   }
 
 // ---------------------------------------------------------------------------
 // |off| (nullable): the bucket offsets of the sort, off[w * (NB + 1) + b].  A bucket is written by exactly

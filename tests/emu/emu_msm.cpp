@@ -76,14 +76,14 @@ extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size
 template<class FPX> static int pairs_check(const unsigned char* points, size_t stride, size_t n)
 {
     int bad = 0;
-    if constexpr (field_is_internal<FPX>::value) {
+    if constexpr (field_is_montx<FPX>::value) {
         typedef FPX inst_fp;                                // (a dependent name: the branch is discarded for the other fields)
         typedef xyzz_dev<inst_fp> B;
         std::vector<uint4> conv((size_t)n * affine_loader<inst_fp>::STRIDE / 16 + 1);
         for (size_t i = 0; i < n; i++) affine_loader<inst_fp>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
         auto pt = [&](size_t i) { return load_affine<inst_fp, false>((const unsigned char*)conv.data(), i, 0); };
         auto same = [&](const B& a, const B& b) {
-            xyzz_mem<sizeof(mont_host<curve_p::fp>) / 4> sa, sb;
+            xyzz_mem<FPX::NW> sa, sb;
             a.store_std(&sa); b.store_std(&sb);
             // XYZZ representatives differ between formulas only by the common factor; both run the SAME formulas here
             return memcmp(&sa, &sb, sizeof(sa)) == 0;
@@ -325,7 +325,7 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
 template<class FPX> static int fixed_base_emu(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                                               const unsigned char* scalars, unsigned wbits)
 {
-    if constexpr (field_is_internal<FPX>::value) {
+    if constexpr (field_is_montx<FPX>::value) {
         typedef FPX F;
         typedef mont_host<curve_p::fp> fp_h;
         typedef jacobian_host<fp_h> point_t;

@@ -80,11 +80,12 @@ def test_msm_pipeline_on_host(oracle, curve):
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
 
 
-@pytest.mark.parametrize("curve", [2, 3])
+@pytest.mark.parametrize("curve", [2, 3, 5])
 def test_msm_g2_pipeline_on_host(oracle, curve):
-    """the same kernel bodies instantiated over Fp2 (fp2_dev.hpp): G2 MSM on the host"""
+    """the same kernel bodies instantiated over Fp2 (ff/fp2x_dev.hpp + ec/xyzzx2_dev.hpp: the loosely-reduced
+    28-bit-limb base field; u^2 = -1 for BLS12-381 / alt_bn128, u^2 = -5 for BLS12-377): G2 MSM on the host"""
     O = oracle
-    L = _emu("BLS12_381" if curve == 2 else "BN254", g2=True)
+    L = _emu({2: "BLS12_381", 3: "BN254", 5: "BLS12_377"}[curve], g2=True)
     fb = O.FP_BYTES[curve]
     for n, wb, LL, F, K, ns, flagged in ((1, 0, 0, 0, 0, 0, True), (33, 0, 0, 0, 0, 0, False), (600, 0, 0, 0, 0, 0, True),
                                          (500, 7, 4, 4, 2, 3, False), (300, 11, 16, 8, 4, 2, True)):

@@ -161,8 +161,12 @@ template<class P, int LB> struct montx_dev {
         montx_dev k;
         #pragma unroll
         for (int j = 0; j < NL; j++) k.l[j] = pow2_tab<0>::T.l[j];
-        montx_dev r = *this * k;                                    // < v*p/2^RBITS + p < 2p
-        // r - p if r >= p, limb-wise with borrow
+        (*this * k).cond_sub_p().to_words(w);                       // the product: < v*p/2^RBITS + p < 2p
+    }
+    // a normalised value < 2p -> its canonical representative: r - p if r >= p, limb-wise with borrow
+    SPPARK_DEVFN montx_dev cond_sub_p() const
+    {
+        montx_dev r = *this;
         u32 d[NL]; int bw = 0;
         #pragma unroll
         for (int j = 0; j < NL; j++) {
@@ -171,12 +175,25 @@ template<class P, int LB> struct montx_dev {
         }
         #pragma unroll
         for (int j = 0; j < NL; j++) r.l[j] = bw ? r.l[j] : d[j];
+        return r;
+    }
+    // the integer itself (no change of Montgomery domain): NW 32-bit words <-> NL limbs.  to_words: normalised limbs,
+    // value < 2^(32 NW)
+    SPPARK_DEVFN static montx_dev from_words(const u32* w)
+    {
+        montx_dev a;
+        #pragma unroll
+        for (int j = 0; j < NL; j++) a.l[j] = limb_of(w, j);
+        return a;
+    }
+    SPPARK_DEVFN void to_words(u32* w) const
+    {
         #pragma unroll
         for (int i = 0; i < NW; i++) {
             const int bit = 32 * i, j = bit / LB, sh = bit % LB;
-            u64 acc = (u64)r.l[j] >> sh;
-            if (j + 1 < NL) acc |= (u64)r.l[j + 1] << (LB - sh);
-            if (j + 2 < NL && 2 * LB - sh < 32) acc |= (u64)r.l[j + 2] << (2 * LB - sh);
+            u64 acc = (u64)l[j] >> sh;
+            if (j + 1 < NL) acc |= (u64)l[j + 1] << (LB - sh);
+            if (j + 2 < NL && 2 * LB - sh < 32) acc |= (u64)l[j + 2] << (2 * LB - sh);
             w[i] = (u32)acc;
         }
     }

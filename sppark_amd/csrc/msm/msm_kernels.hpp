@@ -200,8 +200,15 @@ SPPARK_DEVFN void accumulate_chunk(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_
 // per SIMD leave each: capped (4 spilled registers), alt_bn128 2^26: 68.4 -> 65.1 ms (A/B on one box,
 // tools/gpu_r2_job23.sh).  The 14-limb fields stay at two waves: 230 registers, and every attempt at
 // 168 spilled enough to lose (profiles/r02_msm_accumulate_waves_ab.log).
+#ifndef SPPARK_G2_TWO_WAVES_MAX_N
+// Fp2 over ten limbs (alt_bn128 G2): capped at 256 registers, 99 spilled, 184 B of scratch per lane, 26.0 -> 21.8 ms.
+// Over fourteen limbs (BLS12-381 / -377 G2, -DSPPARK_G2_TWO_WAVES_MAX_N=28) the cap spills 688 registers into 852 B of
+// scratch per lane: the 2^22 MSM gains (47.3 -> 42.1 ms) but 852 B x every resident lane is above the runtime's resident
+// scratch limit, scratch is then set up per dispatch and every small MSM pays milliseconds (the G2 test suite: 8 s -> 123 s).
+# define SPPARK_G2_TWO_WAVES_MAX_N 20
+#endif
 template<class FP, bool FLAGGED>
-__global__ __launch_bounds__(256, (field_is_internal<FP>::value && FP::N <= 10) ? 3 : (field_is_internal<FP>::value && FP::N <= 20) ? 2 : 1)
+__global__ __launch_bounds__(256, (field_is_internal<FP>::value && FP::N <= 10) ? 3 : (field_is_internal<FP>::value && FP::N <= SPPARK_G2_TWO_WAVES_MAX_N) ? 2 : 1)
 void k_accumulate(xyzz_mem<FP::N>* __restrict__ buckets,
                   u32* __restrict__ rec_key, xyzz_mem<FP::N>* __restrict__ rec_pt,
                   const unsigned char* __restrict__ points, unsigned stride,

@@ -392,6 +392,19 @@ public:
     // Keep a copy of |np| points in HBM for later invoke(out, nullptr, n <= np, scalars, ...)
     // calls: the reference's msm_t(points, np, ffi_affine_sz) + invoke(out, scalars)
     // (pippenger.cuh:351-385,604-605).  |points| may be a host or a device pointer; np == 0 drops the copy.
+    // window of the fixed-base tables: the c <= 26 with the least arithmetic -- W(c) * np mixed additions into the buckets
+    // + two full additions (~3 mixed ones) for each of the 2^(c-1) buckets of the ONE bucket set (2^26 points: c = 24,
+    // W = 11; c = 26, W = 10 costs the same and 4 x the buckets) -- or the forced width
+    unsigned fixed_base_width(size_t np) const
+    {
+        if (tune.wbits) return std::min(26u, std::max(8u, tune.wbits));
+        unsigned w = 0; double best = 0;
+        for (unsigned c = 8; c <= 26; c++) {
+            const double cost = (double)((FRp::NBITS - 1) / c + 1) * (double)np + 3.0 * (double)((size_t)1 << (c - 1));
+            if (w == 0 || cost < best) { best = cost; w = c; }
+        }
+        return w;
+    }
     // |fixed_base| (fields with their own records only): also keep the multiples 2^(off_j) * P_i of every point for
     // every window j (k_fixed_base_table), nwins x the memory; invoke(out, nullptr, np, ...) over exactly these np points
     // then runs as ONE window over nwins * np (digit, multiple) pairs -- fixed_plan() / invoke_fixed().
@@ -400,6 +413,11 @@ public:
         HIP_OK(hipSetDevice(gpu->hip_id));
         HIP_OK(hipStreamSynchronize(stream));
         join_default_stream();
+        // (arguments are checked before the previous set is dropped: a refused call leaves the context as it was)
+        if (np != 0 && (points == nullptr || ffi_affine_sz < 2 * FP_BYTES || np > (1u << 31))) HIP_OK(hipErrorInvalidValue);
+        if (np != 0 && fixed_base && !MONTX) HIP_OK(hipErrorNotSupported);
+        if (np != 0 && fixed_base && (tune.wbits || np >= FIXED_BASE_MIN)
+            && (size_t)((FRp::NBITS - 1) / fixed_base_width(np) + 1) * np >= ((size_t)1 << 31)) HIP_OK(hipErrorInvalidValue);
         if (pre_points) { HIP_OK(hipFree(pre_points)); pre_points = nullptr; pre_n = pre_stride = 0; }
         pre_fb_wbits = pre_fb_nwins = 0;
         if (np == 0) return;
@@ -410,17 +428,7 @@ public:
         if (fixed_base && !tune.wbits && np < FIXED_BASE_MIN) fixed_base = false;
         unsigned fb_w = 0, fb_nw = 1;
         if (fixed_base) {
-            // window: the c <= 26 with the least arithmetic -- W(c) * np mixed additions into the buckets + two full
-            // additions (~3 mixed ones) for each of the 2^(c-1) buckets of the ONE bucket set
-            // (2^26 points: c = 24, W = 11; c = 26, W = 10 costs the same and 4 x the buckets)
-            if (tune.wbits) fb_w = std::min(26u, std::max(8u, tune.wbits));
-            else {
-                double best = 0;
-                for (unsigned c = 8; c <= 26; c++) {
-                    const double cost = (double)((FRp::NBITS - 1) / c + 1) * (double)np + 3.0 * (double)((size_t)1 << (c - 1));
-                    if (fb_w == 0 || cost < best) { best = cost; fb_w = c; }
-                }
-            }
+            fb_w = fixed_base_width(np);
             fb_nw = (FRp::NBITS - 1) / fb_w + 1;
             fb_w = FRp::NBITS / fb_nw + (FRp::NBITS % fb_nw ? 1 : 0);
             if ((size_t)fb_nw * np >= ((size_t)1 << 31)) HIP_OK(hipErrorInvalidValue);

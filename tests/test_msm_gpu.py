@@ -391,6 +391,11 @@ def test_msm_fixed_base_tables(oracle, libs, name, curve):
             m = n // 3
             assert (sppark_amd.to_affine(ctx.invoke(None, d_sc[:m].contiguous(), npoints=m), name)
                     == O.msm_affine(curve, pts[:m], sc[:m], algo=0, param=8)).all(), (name, n, wb, "prefix")
+    # a refused call (stride below two coordinates) leaves the context as it was
+    with pytest.raises(ffi.SpparkError):
+        ctx.set_points(pts, ffi_affine_sz=8, fixed_base=True)
+    assert ctx.preloaded() == n
+    assert (sppark_amd.to_affine(ctx.invoke(None, sc), name) == exp).all()
     # plain preload afterwards drops the tables
     ctx.set_points(pts, ffi_affine_sz=pts.shape[1])
     assert ctx.fixed_base_windows() == 0

@@ -260,6 +260,9 @@ SppError sppark_lde_powers(size_t device_id, void *d_inout, uint32_t lg_domain_s
  * expansion is then done in place.  Any other overlap is an invalid-value error. */
 SppError sppark_lde_expand(size_t device_id, void *d_out, const void *d_in, uint32_t lg_domain_size,
                            uint32_t lg_blowup, void *stream);
+/* sppark_lde keeps its device scratch (the coefficient copy, the staging of host buffers) between calls -- at most
+ * two idle buffers per process; this frees them (the twiddle tables stay). */
+void     sppark_ntt_release_cached(void);
 
 /* ------------------------------------------------------------------------ */
 /* 3. Polynomial primitives over the library's NTT field (every library)      */

@@ -48,15 +48,13 @@ static void ntt_any(size_t device_id, void* inout, uint32_t lg, int order, int d
         return;
     }
     // host buffer: H2D, transform, D2H (NTT::Base, ntt/ntt.cuh:216-244)
-    fr_t* d = nullptr;
-    HIP_OK(hipMalloc((void**)&d, bytes));
-    try {
-        HIP_OK(hipMemcpyAsync(d, inout, bytes, hipMemcpyHostToDevice, stream));
-        ntt_engine<fr_t>::instance().run(gpu, d, lg, order, direction, type, stream);
-        HIP_OK(hipMemcpyAsync(inout, d, bytes, hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
-    } catch (...) { (void)hipFree(d); throw; }
-    HIP_OK(hipFree(d));
+    pooled_scratch buf(bytes);                  // (util/runtime.hpp: kept between calls)
+    fr_t* d = (fr_t*)buf.p;
+    HIP_OK(hipMemcpyAsync(d, inout, bytes, hipMemcpyHostToDevice, stream));
+    ntt_engine<fr_t>::instance().run(gpu, d, lg, order, direction, type, stream);
+    HIP_OK(hipMemcpyAsync(inout, d, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    buf.done();
 }
 
 SPPARK_FFI RustError compute_ntt(size_t device_id, void* inout, uint32_t lg_domain_size,
@@ -75,9 +73,9 @@ static void lde_any(size_t device_id, void* inout, uint32_t lg_domain, uint32_t 
     const bool dev = is_device_pointer(inout), aux_dev = aux_out && is_device_pointer(aux_out);
     // scratch: [tmp: dom][aux: dom, when it has to be staged][ext, when inout is a host buffer]
     const size_t need = dom + (aux_out && !aux_dev ? dom : 0) + (dev ? 0 : ext);
-    fr_t* scratch = nullptr;
-    HIP_OK(hipMalloc((void**)&scratch, need * sizeof(fr_t)));
-    try {
+    pooled_scratch buf(need * sizeof(fr_t));
+    fr_t* scratch = (fr_t*)buf.p;
+    {
         fr_t* d_tmp = scratch;
         fr_t* d_aux = aux_out ? (aux_dev ? (fr_t*)aux_out : scratch + dom) : nullptr;
         fr_t* d_ext = dev ? (fr_t*)inout : scratch + need - ext;
@@ -86,9 +84,10 @@ static void lde_any(size_t device_id, void* inout, uint32_t lg_domain, uint32_t 
         if (aux_out && !aux_dev) HIP_OK(hipMemcpyAsync(aux_out, d_aux, dom * sizeof(fr_t), hipMemcpyDeviceToHost, stream));
         if (!dev) HIP_OK(hipMemcpyAsync(inout, d_ext, ext * sizeof(fr_t), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
-    } catch (...) { (void)hipFree(scratch); throw; }
-    HIP_OK(hipFree(scratch));
+    }
+    buf.done();
 }
+SPPARK_FFI void sppark_ntt_release_cached(void) { dev_scratch_pool::instance().release(); }
 
 SPPARK_FFI RustError sppark_lde(size_t device_id, void* inout, uint32_t lg_domain_size, uint32_t lg_blowup,
                                 void* aux_out, void* stream)

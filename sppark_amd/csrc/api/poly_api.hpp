@@ -10,18 +10,20 @@
 namespace {
 // device view of a host-or-device buffer: copied in when it lives on the host, copied back on flush()
 struct dev_view {
-    fr_t* d = nullptr; void* host = nullptr; size_t bytes = 0; bool owned = false; hipStream_t stream;
+    fr_t* d = nullptr; void* host = nullptr; size_t bytes = 0, got = 0; bool owned = false, synced = false; int dev = 0; hipStream_t stream;
     dev_view(const void* p, size_t count, bool copy_in, hipStream_t s) : bytes(count * sizeof(fr_t)), stream(s)
     {
         if (count == 0) return;
         if (p == nullptr) HIP_OK(hipErrorInvalidValue);
         if (is_device_pointer(p)) { d = (fr_t*)p; return; }
         host = (void*)p; owned = true;
-        HIP_OK(hipMalloc((void**)&d, bytes));
+        HIP_OK(hipGetDevice(&dev));
+        d = (fr_t*)dev_scratch_pool::instance().take(dev, bytes, got);      // (util/runtime.hpp: kept between calls)
         if (copy_in) HIP_OK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, stream));
     }
-    void flush() { if (owned && bytes) { HIP_OK(hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, stream)); HIP_OK(hipStreamSynchronize(stream)); } }
-    ~dev_view() { if (owned && d) (void)hipFree(d); }
+    void flush() { if (owned && bytes) { HIP_OK(hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, stream)); HIP_OK(hipStreamSynchronize(stream)); synced = true; } }
+    void done() { synced = true; }             // the caller has synchronised the stream (an input-only view)
+    ~dev_view() { if (!(owned && d)) return; if (synced) dev_scratch_pool::instance().give(dev, d, got); else (void)hipFree(d); }
     dev_view(const dev_view&) = delete;
 };
 }
@@ -38,7 +40,8 @@ SPPARK_FFI RustError sppark_prefix_op(size_t device_id, void* out, const void* i
             vin.flush();
         } else {
             dev_view vout(out, len, false, s);
-            poly_engine<fr_t>::prefix_op(vout.d, vin.d, len, op, s);
+            poly_engine<fr_t>::prefix_op(vout.d, vin.d, len, op, s);     // (synchronises the stream)
+            vin.done();
             vout.flush();
         }
     });
@@ -52,7 +55,8 @@ SPPARK_FFI RustError sppark_poly_evaluate(size_t device_id, void* ret, const voi
         hipStream_t s = (hipStream_t)stream;
         if (n == 0) return;
         dev_view vx(x, n, true, s), vc(coeffs, len, true, s), vr(ret, n, false, s);
-        poly_engine<fr_t>::evaluate(vr.d, vx.d, n, vc.d, len, s);
+        poly_engine<fr_t>::evaluate(vr.d, vx.d, n, vc.d, len, s);       // (synchronises the stream)
+        vx.done(); vc.done();
         vr.flush();
     });
 }

@@ -1,6 +1,6 @@
 // Host driver of the polynomial primitives (polynomial/prefix_op.cuh:324-396,
 // polynomial/evaluate.cuh:307-412, polynomial/div_by_x_minus_z.cuh:447-486): three plain
-// launches per scan on one stream, scratch from the stream-ordered allocator.
+// launches per scan on one stream, scratch from the per-library pool (util/runtime.hpp).
 #pragma once
 #include "poly_kernels.hpp"
 #include "../util/runtime.hpp"
@@ -10,12 +10,7 @@ namespace sppark_amd {
 template<class F> struct poly_engine {
     static constexpr size_t TILE = (size_t)POLY_NT * poly_geom<F>::E;
 
-    struct scratch {            // freed on every exit path
-        void* p = nullptr;
-        explicit scratch(size_t bytes) { HIP_OK(hipMalloc(&p, bytes ? bytes : 16)); }
-        ~scratch() { if (p) (void)hipFree(p); }
-        scratch(const scratch&) = delete;
-    };
+    typedef pooled_scratch scratch;     // util/runtime.hpp: kept between calls; freed instead when the call ends in an exception
 
     template<class Op, bool SHIFT>
     static void scan(F* d_out, const F* d_inp, size_t len, const Op& op, hipStream_t stream)
@@ -34,7 +29,8 @@ template<class F> struct poly_engine {
             hipLaunchKernelGGL((k_poly_edges<F, Op::REVERSED>), dim3((unsigned)((ntiles + POLY_NT - 1) / POLY_NT)), dim3(POLY_NT), 0, stream,
                                d_out, (const F*)edge.p, ntiles, len);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipStreamSynchronize(stream));           // the scratch dies with this frame
+        HIP_OK(hipStreamSynchronize(stream));           // the scratch goes back to the pool with this frame
+        agg.done(); edge.done();
     }
 
     // out[i] = inp[0] (op) ... (op) inp[i];  op 0 = Add, 1 = Multiply; d_out may alias d_inp
@@ -57,6 +53,7 @@ template<class F> struct poly_engine {
         op_horner<F> op; op.zp = (const F*)zp.p;
         if (rotate) scan<op_horner<F>, true>(d_inout, d_inout, len, op, stream);
         else        scan<op_horner<F>, false>(d_inout, d_inout, len, op, stream);
+        zp.done();                                      // (scan() synchronised the stream)
     }
 
     // ret[j] = sum_i coeffs[i] * x[j]^i for j < n; all device pointers
@@ -70,6 +67,7 @@ template<class F> struct poly_engine {
         hipLaunchKernelGGL(k_poly_eval_sum<F>, dim3((unsigned)n), dim3(POLY_NT), 0, stream, d_ret, (const F*)part.p, (unsigned)n, ntiles);
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(stream));
+        part.done();
     }
 };
 

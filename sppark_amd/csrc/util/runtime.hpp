@@ -18,6 +18,7 @@
 #include <exception>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 
 namespace sppark_amd {
 
@@ -103,5 +104,62 @@ static inline bool is_device_pointer(const void* p)
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
+
+// Device scratch of the entry points that stage or need temporaries (compute_ntt / sppark_lde on host buffers, the
+// LDE's coefficient copy, the polynomial scans), kept between calls: a hipMalloc + hipFree pair per call -- the free
+// synchronises the whole device -- costs more than a 2^22 -> 2^24 Goldilocks extension itself (0.50 -> 0.33 ms with the
+// pool, profiles/r03_ntt_lde.log).  A buffer is taken for ONE call and goes back only after that call has synchronised
+// its stream (done()), so concurrent calls never share one; a call that ends in an exception frees its buffer instead.
+// At most four idle buffers per library are kept, the largest ones.
+struct dev_scratch_pool {
+    struct item { int dev; void* p; size_t bytes; };
+    std::mutex m;
+    std::vector<item> idle;
+    static dev_scratch_pool& instance() { static dev_scratch_pool pool; return pool; }
+    void* take(int dev, size_t bytes, size_t& got)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); i++)
+                if (idle[i].dev == dev && idle[i].bytes >= bytes && (best < 0 || idle[i].bytes < idle[best].bytes)) best = i;
+            if (best >= 0) { item it = idle[best]; idle.erase(idle.begin() + best); got = it.bytes; return it.p; }
+        }
+        void* p = nullptr;
+        HIP_OK(hipMalloc(&p, bytes ? bytes : 16));
+        got = bytes ? bytes : 16;
+        return p;
+    }
+    void give(int dev, void* p, size_t bytes)
+    {
+        item drop{dev, nullptr, 0};
+        {
+            std::lock_guard<std::mutex> lk(m);
+            idle.push_back(item{dev, p, bytes});
+            if (idle.size() > 4) {
+                int small = 0;
+                for (int i = 1; i < (int)idle.size(); i++) if (idle[i].bytes < idle[small].bytes) small = i;
+                drop = idle[small]; idle.erase(idle.begin() + small);
+            }
+        }
+        if (drop.p) { int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(drop.dev); (void)hipFree(drop.p); (void)hipSetDevice(cur); }
+    }
+    void release()
+    {
+        std::vector<item> all;
+        { std::lock_guard<std::mutex> lk(m); all.swap(idle); }
+        int cur = 0; (void)hipGetDevice(&cur);
+        for (auto& it : all) { (void)hipSetDevice(it.dev); (void)hipFree(it.p); }
+        (void)hipSetDevice(cur);
+    }
+};
+// one buffer of the pool on the CURRENT device for the duration of a call
+struct pooled_scratch {
+    void* p = nullptr; size_t bytes = 0; int dev = 0; bool ok = false;
+    explicit pooled_scratch(size_t want) { HIP_OK(hipGetDevice(&dev)); p = dev_scratch_pool::instance().take(dev, want, bytes); }
+    void done() { ok = true; }                  // the work that used the buffer has been synchronised
+    ~pooled_scratch() { if (!p) return; if (ok) dev_scratch_pool::instance().give(dev, p, bytes); else (void)hipFree(p); }
+    pooled_scratch(const pooled_scratch&) = delete;
+};
 
 } // namespace sppark_amd

@@ -144,6 +144,8 @@ def load(name):
         L.sppark_lde_powers.restype = _Error
         L.sppark_lde_expand.argtypes = [sz, vp, vp, u32, u32, vp]
         L.sppark_lde_expand.restype = _Error
+        L.sppark_ntt_release_cached.argtypes = []
+        L.sppark_ntt_release_cached.restype = None
 
     if name in NTT_FIELDS or name in CURVES or name in POLY_ONLY:
         L.sppark_prefix_op.argtypes = [sz, vp, vp, sz, ci, vp]

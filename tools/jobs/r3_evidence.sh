@@ -24,6 +24,7 @@ timeout 900 python bench.py > $R/gpurun_out/r3e_bench_final.json 2> $R/gpurun_ou
 timeout 300 env NTT_LGS=12,16,20,22,24,26 python tools/gpu_ntt_bench.py > $R/gpurun_out/r3e_ntt_bench.log 2>&1
 timeout 300 python tools/gpu_msm_tail.py ab 12 14 16 18 19 20 21 22 23 24 25 26 > $R/gpurun_out/r3e_msm_sizes.log 2>&1; grep -v amdgpu $R/gpurun_out/r3e_msm_sizes.log
 timeout 600 python tools/gpu_msm_fixed.py 22:20 23 24 25 26 > $R/gpurun_out/r3e_msm_fixed_base.log 2>&1; timeout 300 python tools/gpu_msm_fixed.py bn254 24 26 >> $R/gpurun_out/r3e_msm_fixed_base.log 2>&1; grep -v amdgpu $R/gpurun_out/r3e_msm_fixed_base.log
+for spec in "gl64 22 2" "gl64 20 3" "bb31 22 2" "bls12_381 20 2"; do timeout 120 python tools/gpu_lde_one.py $spec 2>&1 | grep LDE >> $R/gpurun_out/r3e_ntt_lde.log; done; timeout 120 python tools/gpu_poly_one.py 2>&1 | grep -v amdgpu >> $R/gpurun_out/r3e_ntt_lde.log; cat $R/gpurun_out/r3e_ntt_lde.log
 timeout 200 python tools/gpu_g2_bench.py 2>&1 | grep -v amdgpu > $R/gpurun_out/r3e_msm_g2.log; cat $R/gpurun_out/r3e_msm_g2.log
 timeout 200 python tools/gpu_msm_skew.py > $R/gpurun_out/r3e_msm_skew.log 2>&1; grep -v amdgpu $R/gpurun_out/r3e_msm_skew.log | tail -8
 rm -rf gpurun_out/prof_r3e gpurun_out/prof_r3e_fetch gpurun_out/prof_r3e_write gpurun_out/prof_tl

@@ -60,3 +60,22 @@ def test_point_arithmetic_kernels_are_one_wave_per_simd_groups(obj):
     for name, md in meta.items():
         if "max_flat_workgroup_size" in md:
             assert int(md["max_flat_workgroup_size"]) <= 256, (name[:70], md["max_flat_workgroup_size"])
+
+
+@pytest.mark.parametrize("obj,max_regs,max_scratch", [
+    ("bn254__msm_k_accumulate.hip__SPPARK_G2.o", 256, 256),          # Fp2 over ten limbs: two waves per SIMD, spills bounded
+    ("bls12_381__msm_k_accumulate.hip__SPPARK_G2.o", 512, 64),       # Fp2 over fourteen limbs: one wave, (almost) no scratch
+    ("bls12_377__msm_k_accumulate.hip__SPPARK_G2.o", 512, 64),
+])
+def test_g2_accumulate_scratch_stays_resident(obj, max_regs, max_scratch):
+    """The G2 accumulation over the 28-bit-limb field (ec/xyzzx2_dev.hpp).  Capping the fourteen-limb form at 256
+    registers spills 852 bytes per lane: times every resident lane that is above the runtime's resident scratch limit,
+    scratch is then set up per dispatch and small MSMs pay milliseconds each (measured: the G2 suite 8 s -> 123 s,
+    profiles/r03_msm_g2_montx.log).  The ten-limb form's 184 bytes stay resident."""
+    meta = _kernels(obj)
+    hit = {k: v for k, v in meta.items() if "k_accumulate" in k and "vgpr_count" in v}
+    assert hit, obj
+    for name, md in hit.items():
+        # (.vgpr_count of a kernel that uses accumulation registers is already the unified total)
+        assert int(md.get("vgpr_count") or 0) <= max_regs, (name[:60], md)
+        assert int(md.get("private_segment_fixed_size") or 0) <= max_scratch, (name[:60], "scratch", md)

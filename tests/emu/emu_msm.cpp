@@ -374,3 +374,37 @@ template<class FPX> static int fixed_base_emu(void* out_jac, const unsigned char
 extern "C" int emu_fixed_base(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                               const unsigned char* scalars, unsigned wbits)
 {   return fixed_base_emu<inst_fp>(out_jac, points, stride, npoints, scalars, wbits);   }
+
+// Fp2 over the loosely-reduced field (ff/fp2x_dev.hpp), operation by operation on INTERNAL limbs (2 * NL words per
+// element, as the caller built them -- including non-canonical representatives at the edge of the stated bounds):
+// op 0: mul<KA>(a, b)   op 1: a.sqr<KA>()   op 2: sub<KA, 1>(a, b).norm()   op 3: neg<KA, 1>(a).norm()
+// G2 builds only (returns 1 otherwise); KA in {3, 6, 10, 13}.
+template<class FPX, int KA> static void fp2x_ops(int op, u32* out, const u32* a, const u32* b, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        FPX x = FPX::from_wire(a + i * FPX::N), y = FPX::from_wire(b + i * FPX::N), r;
+        switch (op) {
+            case 0: r = FPX::template mul<KA>(x, y); break;
+            case 1: r = x.template sqr<KA>(); break;
+            case 2: r = FPX::template sub<KA>(x, y).norm(); break;
+            default: r = FPX::template neg<KA>(x).norm(); break;
+        }
+        r.to_wire(out + i * FPX::N);
+    }
+}
+extern "C" int emu_fp2x_op(int op, int ka, void* out, const void* a, const void* b, size_t n)
+{
+#ifdef SPPARK_G2
+    if constexpr (field_is_internal<inst_fp>::value && !field_is_montx<inst_fp>::value) {
+        switch (ka) {
+            case 3:  fp2x_ops<inst_fp, 3>(op, (u32*)out, (const u32*)a, (const u32*)b, n); return 0;
+            case 6:  fp2x_ops<inst_fp, 6>(op, (u32*)out, (const u32*)a, (const u32*)b, n); return 0;
+            case 10: fp2x_ops<inst_fp, 10>(op, (u32*)out, (const u32*)a, (const u32*)b, n); return 0;
+            case 13: fp2x_ops<inst_fp, 13>(op, (u32*)out, (const u32*)a, (const u32*)b, n); return 0;
+            default: return 2;
+        }
+    }
+#endif
+    (void)op; (void)ka; (void)out; (void)a; (void)b; (void)n;
+    return 1;
+}

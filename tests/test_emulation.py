@@ -36,6 +36,7 @@ def _emu(feature, g2=False):
     L.emu_msm.argtypes = [vp, vp, sz, sz, vp, ci, cu, cu, cu, cu, cu, ci, vp, cu]
     L.emu_pairs_check.argtypes = [vp, sz, sz]
     L.emu_fixed_base.argtypes = [vp, vp, sz, sz, vp, cu]
+    L.emu_fp2x_op.argtypes = [ci, ci, vp, vp, vp, sz]
     return L
 
 
@@ -193,3 +194,61 @@ def test_fixed_base_tables_on_host(oracle, curve, feature):
         out = np.zeros(3 * fb, dtype=np.uint8)
         assert L.emu_fixed_base(P(out), P(pts), pts.shape[1], n, P(sc), wb) == 0
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb)
+
+
+@pytest.mark.parametrize("curve,feature,nr", [(2, "BLS12_381", 1), (3, "BN254", 1), (5, "BLS12_377", 5)])
+def test_fp2_over_the_lazy_field_at_the_edge_of_its_bounds(oracle, curve, feature, nr):
+    """ff/fp2x_dev.hpp operation by operation on the host, on representatives AT THE EDGE of the stated contract: the
+    left operand of mul<KA> / the operand of sqr<KA> as x + (KA - 2) p (the largest normalised value below (KA - 1) p
+    that is congruent to x), the right operand up to 15 p; sub / neg with the subtrahend at its bound.  Checked against
+    Python integers: the result is congruent to the Montgomery product / difference, below 2 p for products (below
+    (bound_a + KA) p for differences), with normalised limbs."""
+    O = oracle
+    L = _emu(feature, g2=True)
+    p = O.FP_MODULUS[curve]
+    LB = 28
+    NL = (p.bit_length() + 8 + LB - 1) // LB
+    R = 1 << (LB * NL)
+
+    def limbs(v):                                   # normalised: limbs < 2^28, the top one takes what is left
+        out = [(v >> (LB * j)) & ((1 << LB) - 1) for j in range(NL - 1)] + [v >> (LB * (NL - 1))]
+        assert out[-1] < (1 << 31)
+        return out
+
+    def pack(els):                                  # list of (c0, c1) integers -> uint32 array of internal limbs
+        return np.array([w for c0, c1 in els for w in limbs(c0) + limbs(c1)], dtype=np.uint32)
+
+    def unpack(arr, n):
+        a = arr.reshape(n, 2, NL).astype(object)
+        val = lambda l: sum(int(l[j]) << (LB * j) for j in range(NL))
+        for e in a:
+            for c in e:
+                assert all(int(c[j]) < (1 << LB) for j in range(NL - 1)), "limbs not normalised"
+        return [(val(e[0]), val(e[1])) for e in a]
+
+    rng = np.random.default_rng(7 + curve)
+    rnd = lambda: int.from_bytes(rng.bytes(64), "little") % p
+    n = 24
+    for ka in (3, 6, 10, 13):
+        edge = (ka - 2) * p
+        xs = [(rnd() + edge, rnd() + edge) for _ in range(n)]
+        xs[0] = (edge, edge); xs[1] = (p - 1 + edge, p - 1 + edge); xs[2] = (edge, p - 1 + edge)       # 0, -1 at the bound
+        ys = [(rnd() + (k % 14) * p, rnd() + (13 - k % 14) * p) for k in range(n)]          # right operands up to 15 p
+        ys[0] = (15 * p - 1, 15 * p - 1); ys[1] = (0, 0)
+        A, B = pack(xs), pack(ys)
+        out = np.zeros_like(A)
+        assert L.emu_fp2x_op(0, ka, P(out), P(A), P(B), n) == 0
+        for (a0, a1), (b0, b1), (c0, c1) in zip(xs, ys, unpack(out, n)):
+            assert (c0 * R - (a0 * b0 - nr * a1 * b1)) % p == 0 and (c1 * R - (a0 * b1 + a1 * b0)) % p == 0, ("mul", ka)
+            assert c0 < 2 * p and c1 < 2 * p, ("mul bound", ka, c0 // p, c1 // p)
+        assert L.emu_fp2x_op(1, ka, P(out), P(A), P(A), n) == 0
+        for (a0, a1), (c0, c1) in zip(xs, unpack(out, n)):
+            assert (c0 * R - (a0 * a0 - nr * a1 * a1)) % p == 0 and (c1 * R - 2 * a0 * a1) % p == 0, ("sqr", ka)
+            assert c0 < 2 * p and c1 < 2 * p, ("sqr bound", ka)
+        # a - b with b at its bound (< (KA - 1) p), a anything normalised below 15 p
+        assert L.emu_fp2x_op(2, ka, P(out), P(B), P(A), n) == 0
+        for (b0, b1), (a0, a1), (c0, c1) in zip(ys, xs, unpack(out, n)):
+            assert (c0 - (b0 - a0)) % p == 0 and (c1 - (b1 - a1)) % p == 0 and c0 == b0 + ka * p - a0 and c1 == b1 + ka * p - a1, ("sub", ka)
+        assert L.emu_fp2x_op(3, ka, P(out), P(A), P(A), n) == 0
+        for (a0, a1), (c0, c1) in zip(xs, unpack(out, n)):
+            assert c0 == ka * p - a0 and c1 == ka * p - a1, ("neg", ka)

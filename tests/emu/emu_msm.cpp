@@ -408,3 +408,33 @@ extern "C" int emu_fp2x_op(int op, int ka, void* out, const void* a, const void*
     (void)op; (void)ka; (void)out; (void)a; (void)b; (void)n;
     return 1;
 }
+
+// The bucket invariant of ec/xyzzx2_dev.hpp under a chain of operations: after every step the accumulator's internal
+// image (X | Y | ZZZ | ZZ, 4 * N words) is appended to |out|.  Steps: set(p0); madd(p_i, i odd) for i < n; then
+// add(copy of the state after n/2 steps); dbl(); madd(p_0) again.  G2 builds only (returns the number of images, 0 otherwise).
+extern "C" int emu_g2_chain(void* out, const unsigned char* points, size_t stride, size_t n)
+{
+#ifdef SPPARK_G2
+    if constexpr (field_is_internal<inst_fp>::value && !field_is_montx<inst_fp>::value) {
+        typedef xyzz_dev<inst_fp> B;
+        std::vector<uint4> conv((size_t)n * affine_loader<inst_fp>::STRIDE / 16 + 1);
+        const bool flagged = stride > 2 * sizeof(fp2_host<curve_p::fp>);
+        for (size_t i = 0; i < n; i++) {
+            if (flagged) affine_loader<inst_fp>::template convert<true>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+            else         affine_loader<inst_fp>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+        }
+        auto pt = [&](size_t i) { return load_affine<inst_fp, false>((const unsigned char*)conv.data(), i, 0); };
+        B::mem_t* o = (B::mem_t*)out;
+        int k = 0;
+        B acc, half; acc.set(pt(0), false); acc.store(&o[k++]);
+        half = acc;
+        for (size_t i = 1; i < n; i++) { acc.madd(pt(i), i & 1); acc.store(&o[k++]); if (i == n / 2) half = acc; }
+        acc.add(half); acc.store(&o[k++]);
+        acc.dbl(); acc.store(&o[k++]);
+        acc.madd(pt(0), false); acc.store(&o[k++]);
+        return k;
+    }
+#endif
+    (void)out; (void)points; (void)stride; (void)n;
+    return 0;
+}

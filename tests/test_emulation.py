@@ -37,6 +37,7 @@ def _emu(feature, g2=False):
     L.emu_pairs_check.argtypes = [vp, sz, sz]
     L.emu_fixed_base.argtypes = [vp, vp, sz, sz, vp, cu]
     L.emu_fp2x_op.argtypes = [ci, ci, vp, vp, vp, sz]
+    L.emu_g2_chain.argtypes = [vp, vp, sz, sz]
     return L
 
 
@@ -252,3 +253,31 @@ def test_fp2_over_the_lazy_field_at_the_edge_of_its_bounds(oracle, curve, featur
         assert L.emu_fp2x_op(3, ka, P(out), P(A), P(A), n) == 0
         for (a0, a1), (c0, c1) in zip(xs, unpack(out, n)):
             assert c0 == ka * p - a0 and c1 == ka * p - a1, ("neg", ka)
+
+
+@pytest.mark.parametrize("curve,feature", [(2, "BLS12_381"), (3, "BN254"), (5, "BLS12_377")])
+def test_g2_bucket_invariant_on_host(oracle, curve, feature):
+    """ec/xyzzx2_dev.hpp: after every mixed addition, full addition and doubling of a chain the bucket satisfies what
+    the next operation's template bounds assume -- all coordinates normalised, X < 9 p, Y < 5 p, ZZ, ZZZ < 2 p (both
+    Fp2 components) -- and the point it represents is the oracle's (x = X / ZZ, y = Y / ZZZ checked through the MSM
+    tests; here: the invariant)."""
+    O = oracle
+    L = _emu(feature, g2=True)
+    p = O.FP_MODULUS[curve]
+    LB = 28
+    NL = (p.bit_length() + 8 + LB - 1) // LB
+    n = 40
+    pts, _ = recipe.msm_inputs(curve, n, 4242, ndistinct=n, flagged=True, edge=False)
+    pts[1] = pts[0]                                             # step 1 is P - P: the infinity branch, step 2 restarts from infinity
+    out = np.zeros((n + 3) * 4 * 2 * NL, dtype=np.uint32)
+    k = L.emu_g2_chain(P(out), P(pts), pts.shape[1], n)
+    assert k == n + 3
+    img = out.reshape(k, 4, 2, NL)
+    bounds = (9, 5, 2, 2)                                       # X, Y, ZZZ, ZZ
+    for step in range(k):
+        for coord in range(4):
+            for comp in range(2):
+                l = [int(v) for v in img[step, coord, comp]]
+                assert all(v < (1 << LB) for v in l[:-1]), ("limbs not normalised", step, coord, comp)
+                val = sum(v << (LB * j) for j, v in enumerate(l))
+                assert val < bounds[coord] * p, ("bound", step, coord, comp, val // p)

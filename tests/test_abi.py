@@ -102,3 +102,18 @@ def test_host_point_helpers(libs, oracle):
         assert O.jac_eq(curve, s, acc)
         assert (sppark_amd.to_affine(s, name) == O.jac_to_affine(curve, acc)).all()
         assert (sppark_amd.to_affine(np.zeros(3 * fb, dtype=np.uint8), name) == 0).all()
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/sppark_amd.h -- the drop-in boundary -- compiles as C99 and as C++ with warnings as errors: plain
+    pointers and sizes, no torch / HIP types in any signature (what a cgo / bindgen / ctypes binding consumes)."""
+    import shutil
+    import subprocess
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    body = '#include "sppark_amd.h"\nint main(void) { return sizeof(SppError) == 0; }\n'
+    for cc, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not available")
+        src = tmp_path / ("t." + ext)
+        src.write_text(body)
+        subprocess.check_call([cc, std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)])

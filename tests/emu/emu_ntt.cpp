@@ -158,18 +158,27 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
         emu_r64_passes<F>(d, lg, gs, inverse, T, nt, g_r64_direct);
         pl.npass = 0;
     }
+    // as ntt_engine::has_pass_table(): passes on sub-problems of <= 2^16 (256-bit fields: 2^24) elements read their
+    // inter-pass twiddles from a table; as ntt_engine::run(): the table of the smallest tabled pass carries 1/n
+    auto has_table = [](const ntt_pass& q) { return !(q.lg_cur > (ntt_gen_twiddles<F>::value ? 16u : 24u) || q.lg_cur <= q.S || q.S / 2 == 0); };
+    int scale_pass = -1;
+    if (inverse) {
+        unsigned best = ~0u;
+        for (unsigned i = 0; i < pl.npass; i++) {
+            const ntt_pass& q = pl.pass[gs ? i : pl.npass - 1 - i];
+            if (has_table(q) && q.lg_cur < best) { best = q.lg_cur; scale_pass = (int)i; }
+        }
+    }
     for (unsigned i = 0; i < pl.npass; i++) {
         ntt_pass P = pl.pass[gs ? i : pl.npass - 1 - i];
-        P.apply_scale = inverse && i == pl.npass - 1;
+        P.apply_scale = inverse && i == pl.npass - 1 && scale_pass < 0;
         size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
         std::vector<F> tile(ntt_lds_elems(P) + 1);
-        // as ntt_engine::pass_table(): passes on sub-problems of <= 2^16 elements read their inter-pass
-        // twiddles from a table instead of generating them
         std::vector<F> pass_tw;
         T.pass_tw = nullptr;
-        if (ntt_gen_twiddles<F>::value && P.lg_cur <= 16 && P.lg_cur > P.S && P.S / 2 != 0) {
+        if (has_table(P)) {
             pass_tw.resize((size_t)1 << P.lg_cur);
-            for (size_t k = 0; k < pass_tw.size(); k++) pass_table_item(pass_tw.data(), T, P.lg_cur, P.S, k);
+            for (size_t k = 0; k < pass_tw.size(); k++) pass_table_item(pass_tw.data(), T, P.lg_cur, P.S, k, inverse && scale_pass == (int)i);
             T.pass_tw = pass_tw.data();
         }
         for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {

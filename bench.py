@@ -55,6 +55,7 @@ MAD_PEAK_PER_S = MAD_RATE_PEAK * 1024 * 64 * 2.4e9
 # ff/montx_dev.hpp, ec/xyzzx_dev.hpp madd: 8 products (14x14) + 2 squares (105) + 9 Montgomery reductions
 # (14x14 each; Y3 is one reduced sum of two products)
 MADS_PER_MIXED_ADD = 8 * 196 + 2 * 105 + 9 * 196
+MADS_PER_MIXED_ADD_10 = 8 * 100 + 2 * 55 + 9 * 100    # alt_bn128 / Pasta: the same formulas on 10 limbs
 
 
 def cpu_model():
@@ -65,6 +66,50 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def host_ntt_time(field, host_in, expect, lg, reps=7):
+    """compute_ntt(device 0, HOST buffer, forward NR) in place: wall-clock ms (median, min) over |reps| calls
+    after one warm-up; the output of the last call asserted equal to |expect|."""
+    Ord = sppark_amd.NTTInputOutputOrder
+    buf = host_in.copy()
+    sppark_amd.NTT(0, buf, Ord.NR, field)
+    times = []
+    for _ in range(reps):
+        buf[:] = host_in
+        t1 = time.perf_counter()
+        sppark_amd.NTT(0, buf, Ord.NR, field)                   # stream=None: the reference's compute_ntt, synchronous
+        times.append((time.perf_counter() - t1) * 1e3)
+    ok = bool((buf == expect).all())
+    assert ok, "compute_ntt on a host buffer differs from the checked device path (%s)" % field
+    med = float(np.median(times))
+    nbytes = buf.nbytes
+    return {"entry_point": "compute_ntt(device_id=0, host inout, 2^%d, NR, forward, standard)" % lg, "bytes_each_way": nbytes,
+            "ms_median": med, "ms_min": float(min(times)), "elems_per_s": (1 << lg) / (med * 1e-3),
+            "copy_gb_per_s": 2 * nbytes / (med * 1e-3) / 1e9, "equals_checked_device_output": ok,
+            "note": "wall clock of the whole call: H2D + transform + D2H from pageable host memory (PCIe inclusive; never the headline value)"}
+
+
+def pcie_peaks(nbytes=1 << 30, reps=4):
+    """H2D / D2H rate of one pinned |nbytes| copy on this box (GB/s, best of |reps|): the denominator of the host-buffer paths"""
+    hbuf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = {"h2d": 0.0, "d2h": 0.0}
+    for _ in range(reps):
+        for key, dst, src in (("h2d", dbuf, hbuf), ("d2h", hbuf, dbuf)):
+            e0.record(); dst.copy_(src, non_blocking=True); e1.record(); torch.cuda.synchronize()
+            best[key] = max(best[key], nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    # pageable source (what mult_pippenger_inf / compute_ntt callers pass): the runtime stages it itself
+    pbuf = np.empty(nbytes, dtype=np.uint8); pbuf[::4096] = 1
+    pt = torch.from_numpy(pbuf)
+    pg = 0.0
+    for _ in range(2):
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        dbuf.copy_(pt); torch.cuda.synchronize()
+        pg = max(pg, nbytes / (time.perf_counter() - t1) / 1e9)
+    del hbuf, dbuf
+    return best["h2d"], best["d2h"], pg
 
 
 def main():
@@ -140,19 +185,21 @@ def main():
 
     for _ in range(args.warmup):
         result = step()
-    accum_ms, sort_ms, dev_ms = [], [], []
+    accum_ms, sort_ms, dev_ms, step_ms = [], [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        result = step()
+        ts = time.perf_counter()
+        result = step()                                         # synchronous: returns with the result on the host
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         accum_ms.append(ctx.kernel_ms(1)); sort_ms.append(ctx.kernel_ms(0)); dev_ms.append(ctx.kernel_ms(2))
     fence()
     elapsed = time.perf_counter() - t0
     acc_launches = int(ctx.kernel_ms(3))
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed] + step_ms, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                # every step: the slowest rank's time
+        elapsed = float(t[0].item()); step_ms = [float(v) for v in t[1:]]
 
     # ---- CHECKER (outside the timed region): the last timed result against the oracle ------------
     # class sums of this rank's scalars (exact integer arithmetic), gathered over the ranks; rank 0
@@ -220,9 +267,14 @@ def main():
         sppark_amd.iNTT(0, y, Ord.RN, "gl64", stream=stream); torch.cuda.synchronize()
         ntt_ok = ntt_ok and bool(torch.equal(y, ref))
         assert ntt_ok, "timed NTT differs from the oracle"
+        # SURVEY 8(d) timing protocol (ii), through-the-FFI: compute_ntt on a HOST buffer, what every caller of the
+        # reference hits (poc/ntt-cuda/src/lib.rs:7-118 -> ntt/ntt.cuh:215-244: H2D, transform, D2H); wall clock,
+        # pageable numpy memory as a Rust Vec / Go slice is; output asserted against the device path checked above
+        through_ffi = host_ntt_time("gl64", ref.cpu().numpy().view(np.uint64), y_host, lg)
         ntt = {"metric": "Goldilocks NTT 2^%d elements/s (forward NR / inverse RN, device-resident)" % lg,
                "timing": "HIP events around 20 back-to-back transforms, best of 3 batches",
                "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
+               "through_ffi": through_ffi,
                "forward_elems_per_s": (1 << lg) / (fwd * 1e-3), "inverse_elems_per_s": (1 << lg) / (inv * 1e-3),
                "pair_elems_per_s": (1 << lg) / ((fwd + inv) * 1e-3),
                "equals_oracle": ntt_ok, "output_sha256": hashlib.sha256(y_host.tobytes()).hexdigest(),
@@ -269,12 +321,25 @@ def main():
             extras["bls12_381_g1_msm_fixed_base"] = fb
         ctx.set_points(None)
         bctx = sppark_amd.MsmContext("bn254", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
+        bctx.enable_timing(True)
         bout = bctx.invoke(bpts, bsc)
         torch.cuda.synchronize(); t1 = time.perf_counter()
+        b_acc = []
         for _ in range(3):
             bout = bctx.invoke(bpts, bsc)
+            b_acc.append(bctx.kernel_ms(1))
         torch.cuda.synchronize()
         extras["alt_bn128_g1_msm_points_per_s"] = 3 * n / (time.perf_counter() - t1)
+        # configs[4]: the same two rooflines for the ten-limb pipeline (96 B per point: 64-byte affine point + 32-byte scalar)
+        b_ms, b_w = float(np.mean(b_acc)), bctx.plan(n)["windows"]
+        b_mads = float(b_w) * n * MADS_PER_MIXED_ADD_10
+        extras["alt_bn128_g1_msm_roofline"] = {
+            "kernel": "k_accumulate", "kernel_ms": b_ms, "windows": b_w,
+            "hbm": {"achieved": 96 * n / (b_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 96 * n / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "alu": {"bound": "v_mad_u64_u32 issue", "achieved": b_mads / (b_ms * 1e-3) / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
+                    "unit": "T mad/s", "frac": b_mads / (b_ms * 1e-3) / MAD_PEAK_PER_S,
+                    "note": "%d windows x points x %d multiply-adds (8 products + 2 squares + 9 reductions on 10 limbs of 28 bits); "
+                            "three waves per SIMD" % (b_w, MADS_PER_MIXED_ADD_10)}}
         bexp = O.msm_affine(O.BN254, bbase.cpu().numpy(), fold.fold_scalars(bsc, PERIOD, O.FR_MODULUS[O.BN254]), algo=0, param=8)
         extras["alt_bn128_g1_msm_equals_oracle"] = bool((sppark_amd.to_affine(bout, "bn254") == bexp).all())
         assert extras["alt_bn128_g1_msm_equals_oracle"]
@@ -283,8 +348,10 @@ def main():
         y0 = y.clone()
         stream = torch.cuda.current_stream().cuda_stream
         sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream); torch.cuda.synchronize()
-        extras["babybear_ntt_equals_oracle"] = bool((y.cpu().numpy().view(np.uint32) == O.ntt_bb31(y0.cpu().numpy().view(np.uint32), O.NR)).all())
+        bb_out = y.cpu().numpy().view(np.uint32)
+        extras["babybear_ntt_equals_oracle"] = bool((bb_out == O.ntt_bb31(y0.cpu().numpy().view(np.uint32), O.NR)).all())
         assert extras["babybear_ntt_equals_oracle"]
+        extras["babybear_ntt_through_ffi"] = host_ntt_time("bb31", y0.cpu().numpy().view(np.uint32), bb_out, args.ntt_lg)
         for _ in range(3):
             sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -335,6 +402,14 @@ def main():
         del ext
         # through-the-FFI path with HOST buffers (PCIe inclusive; never the headline value): what the
         # reference's Rust / Go callers use.  2^24 and the full 2^26, chunked copy under the arithmetic.
+        h2d, d2h, h2d_pageable = pcie_peaks()
+        extras["h2d_peak_gbs"], extras["d2h_peak_gbs"], extras["h2d_pageable_gbs"] = h2d, d2h, h2d_pageable
+        extras["pcie_note"] = ("one 1 GiB hipMemcpy each way between PINNED host memory and the device, HIP events, best of 4; "
+                               "h2d_pageable_gbs = the same copy from pageable memory (wall clock), which is what the host-buffer entry points receive")
+        for key in ("babybear_ntt_through_ffi",):
+            extras[key]["frac_of_h2d_peak"] = extras[key]["copy_gb_per_s"] / h2d
+        if ntt is not None:
+            ntt["through_ffi"]["frac_of_h2d_peak"] = ntt["through_ffi"]["copy_gb_per_s"] / h2d
         host = {}
         for lgh in sorted({min(args.lg, 24), args.lg}):
             m = 1 << lgh
@@ -348,7 +423,9 @@ def main():
             hexp = O.msm_affine(O.BLS12_381, base.cpu().numpy(), fold.fold_scalars(sc[:m], PERIOD, r_mod), algo=0, param=8)
             ok = bool((sppark_amd.to_affine(hout) == hexp).all())
             assert ok, "host-buffer MSM differs from the oracle"
-            host["2^%d" % lgh] = {"points": m, "seconds": dt, "points_per_s": m / dt, "equals_oracle": ok}
+            host["2^%d" % lgh] = {"points": m, "seconds": dt, "points_per_s": m / dt, "equals_oracle": ok,
+                                  "input_gb_per_s": m * (104 + 32) / dt / 1e9, "frac_of_h2d_peak": m * (104 + 32) / dt / 1e9 / h2d,
+                                  "frac_of_h2d_pageable": m * (104 + 32) / dt / 1e9 / h2d_pageable}
             del hp, hs
         extras["mult_pippenger_inf_host_buffers"] = host
         # the per-GPU shards of the headline MSM at N = 2 / 4 / 8 on THIS GPU (device-resident, same inputs): an upper
@@ -386,9 +463,11 @@ def main():
             cpu_msm = lambda p_, s_: O.msm_affine(O.BLS12_381, p_, s_, algo=0, param=cores)
         # size the sample for ~15 s of CPU work from a 2^16 probe (config 1 of BASELINE.json)
         hp = pts[:1 << 16].cpu().numpy(); hs = sc[:1 << 16].cpu().numpy()
-        t1 = time.perf_counter()
-        cpu_msm(hp, hs)
-        probe = time.perf_counter() - t1
+        probe = 1e30
+        for _ in range(2):                                      # (the first call also starts the thread pool)
+            t1 = time.perf_counter()
+            cpu_msm(hp, hs)
+            probe = min(probe, time.perf_counter() - t1)
         lgm = 16
         while lgm < min(args.lg, 24) and probe * (1 << (lgm + 1 - 16)) * 0.6 < 15.0:
             lgm += 1
@@ -399,6 +478,8 @@ def main():
         dt = time.perf_counter() - t1
         got = sppark_amd.to_affine(ctx.invoke(pts[:m], sc[:m]))
         cpu = {"value": m / dt, "unit": "points/s", "cores": cores, "cpu_model": cpu_model(),
+               "at_2^16": {"seconds": probe, "points_per_s": (1 << 16) / probe,
+                           "what": "BASELINE configs[0]: the first 2^16 points through the same CPU path, %d threads" % cores},
                "kind": "reference" if use_ref else "port",
                "sample": "first 2^%d points of the same workload, %s (portable C++ field, not blst asm), %d threads, %.2f s"
                          % (m.bit_length() - 1,
@@ -433,12 +514,13 @@ def main():
             "metric": "MSM points/sec (BLS12-381 G1, 2^%d points%s)" % (total.bit_length() - 1, " in total over %d GPUs" % world if world > 1 else ""),
             "value": total * args.steps / elapsed, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)), "ms_per_step_min": float(min(step_ms)),
+            "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "BLS12-381 G1 Pippenger MSM, 2^%d points in total, %d per GPU, device-resident inputs (%s)"
                                    % (total.bit_length() - 1, n,
                                       "BASELINE configs[2]" if world == 1 and total == 1 << 26 else
-                                      "BASELINE configs[3]" if total == 1 << 28 else
+                                      "BASELINE configs[3]: sharded x%d, %s all-gather of partial sums" % (world, xchg) if total == 1 << 28 else
                                       "BASELINE metric: the 2^26 MSM sharded x%d, %s all-gather of partial sums" % (world, xchg) if total == 1 << 26 else
                                       "sharded x%d, %s all-gather of partial sums" % (world, xchg)),
                        "backend": args.backend if use_dist else None,

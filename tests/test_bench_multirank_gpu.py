@@ -34,6 +34,7 @@ def _run(world, extra):
     (2, ["--total-lg", "21"], 1 << 21, 1 << 20, "strong"),                 # configs[3]'s mode
     (2, ["--scaling", "weak", "--lg", "19"], 1 << 20, 1 << 19, "weak"),    # 2^lg per rank
     (3, ["--lg", "18"], 1 << 18, 43 * 2048, "strong"),                     # uneven shards: 43 + 43 + 42 periods
+    (8, ["--total-lg", "24"], 1 << 24, 1 << 21, "strong"),                 # configs[3]'s rank count (its full size: tools/gpu_config3_rehearsal.py)
 ])
 def test_bench_multirank_dry_run(libs, world, extra, total, per_gpu, scaling):
     d = _run(world, extra)
@@ -43,3 +44,4 @@ def test_bench_multirank_dry_run(libs, world, extra, total, per_gpu, scaling):
     assert d["parity"]["timed_msm_equals_oracle"] is True
     assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["vs_baseline"] is None and d["unit"] == "points/s"
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step"] * 2

@@ -730,6 +730,36 @@ def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     ctx.close()
 
 
+def test_msm_above_2p28_vs_oracle(oracle, libs):
+    """BASELINE configs[3]'s TOTAL size on one device: 2^28 + 3 * 2048 points (not a power of two) through the plain
+    path in one piece (about 150 GB of inputs and scratch), against the oracle through the period fold.  Every
+    32-bit index of the driver and the kernels -- window * n offsets, 12 x 2^28 sort entries, 2^16-entry level-A
+    partitions beyond level B's register path -- runs four times above anything the other tests reach."""
+    import torch
+    import sppark_amd
+    from sppark_amd import synth
+    from oracle import fold
+    O = oracle
+    per = 2048
+    n = (1 << 28) + 3 * per
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 200 << 30:
+        pytest.skip("needs ~150 GB of device memory")
+    pts, base = synth.replicated_points(n, "bls12_381", per, 0x5eed5eed0001)
+    sc = torch.empty((n, 32), dtype=torch.uint8, device="cuda")
+    for k, lo in enumerate(range(0, n, 1 << 25)):                # pieces: bounded temporaries of the generator
+        m = min(1 << 25, n - lo)
+        sc[lo:lo + m] = synth.uniform_scalars(m, "bls12_381", 280 + k)
+    ctx = sppark_amd.MsmContext("bls12_381", stream=torch.cuda.current_stream().cuda_stream)
+    out = ctx.invoke(pts, sc)
+    assert ctx.last_chunks() == 1
+    exp = O.msm_affine(O.BLS12_381, base.cpu().numpy(), fold.fold_scalars(sc, per, O.FR_MODULUS[O.BLS12_381]), algo=0, param=8)
+    assert (sppark_amd.to_affine(out) == exp).all()
+    ctx.close()
+    del pts, sc
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("curve,name,lg", [(0, "bls12_381", 23), (1, "bn254", 24), (0, "bls12_381", 26)])
 def test_msm_fixed_base_full_size_vs_oracle(oracle, libs, curve, name, lg):
     """the fixed-base mode at the sizes it builds its tables by itself (>= 2^23 points: automatic window, 2^12

@@ -1,4 +1,4 @@
-"""Run the Goldilocks/BabyBear forward NR NTT a few times at 2^LG (for profiling)."""
+"""Run the Goldilocks/BabyBear forward NTT a few times at 2^LG (for profiling): FIELD LG REPS [NR|NN|RN|RR]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sppark_amd
@@ -9,6 +9,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dt = torch.int64 if field == "gl64" else torch.int32
 x = torch.randint(0, 2**30, (1 << lg,), dtype=dt, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
+order = getattr(Ord, sys.argv[4]) if len(sys.argv) > 4 else Ord.NR
 for _ in range(reps):
-    sppark_amd.NTT(0, x, Ord.NR, field, stream=s)
+    sppark_amd.NTT(0, x, order, field, stream=s)
 torch.cuda.synchronize()

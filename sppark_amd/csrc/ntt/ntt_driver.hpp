@@ -308,7 +308,14 @@ public:
         const size_t n = (size_t)1 << lg;
         if (lg >= 2 * TB + 1) {
             size_t lds = 2 * (((size_t)(1u << TB) + 1) << TB) * sizeof(F);
-            hipLaunchKernelGGL((k_bitrev_tiled<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
+            // 16-byte accesses for the single-word fields (any 16-byte aligned buffer; a view at an odd element offset
+            // takes the element-wise tiles)
+            bool vec = false;
+            if constexpr (sizeof(F) <= 8) vec = ((uintptr_t)d & 15) == 0;
+            if constexpr (sizeof(F) <= 8) {
+                if (vec) hipLaunchKernelGGL((k_bitrev_tiled_vec<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
+            }
+            if (!vec) hipLaunchKernelGGL((k_bitrev_tiled<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
         } else {
             hipLaunchKernelGGL(k_bitrev<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d, lg);
         }

@@ -384,6 +384,67 @@ __global__ __launch_bounds__(256) void k_bitrev_tiled(F* data, unsigned lg_n)
     __syncthreads();
     bitrev_tile_item<F, TB>(data, ldsA, ldsB, lg_n, blockIdx.x, threadIdx.x, blockDim.x, 1);
 }
+// The same with 16-byte global accesses, for elements of 4 and 8 bytes (round 4).  The kernel above moves one element
+// per lane and access and waits for each load before it issues the next: a 64 x 64 tile of 4-byte elements is 16
+// dependent rounds of 256-byte wave accesses per tile, and the BabyBear instance ran at 2.7 TB/s where the 8-byte one
+// (4 rounds, 512 bytes per wave access) reached 6.7 (profiles/r03_ntt_bench.log).  Here a lane owns V = 16 / sizeof(F)
+// CONSECUTIVE elements of a row: all its loads (both tiles of the pair) are issued before the first LDS write; in the
+// second phase it collects the V consecutive elements of a DESTINATION row from V source rows of the LDS image
+// (V 4-byte LDS reads) and stores them with one 16-byte access.  |data| must be 16-byte aligned.
+template<class F, unsigned TB>
+SPPARK_DEVFN void bitrev_tile_vec_item(F* data, F* ldsA, F* ldsB, unsigned lg_n, size_t mid, unsigned tid, int phase)
+{
+    constexpr unsigned V = 16 / sizeof(F), T = 1u << TB, NT = 256, ROW = T / V, PER = T * T / V / NT;
+    static_assert(V >= 2 && (T * T / V) % NT == 0 && T % V == 0, "vector slots must tile the work-group");
+    struct alignas(16) vec { F e[V]; };
+    const unsigned lg_mid = lg_n - 2 * TB;
+    const size_t rmid = bit_rev32((unsigned)mid, lg_mid);
+    if (mid > rmid) return;
+    const bool pair = mid != rmid;
+    if (phase == 0) {
+        vec a[PER], b[PER];
+        #pragma unroll
+        for (unsigned k = 0; k < PER; k++) {
+            const unsigned s = tid + k * NT, hi = s / ROW, lo = (s % ROW) * V;
+            a[k] = *reinterpret_cast<const vec*>(&data[((size_t)hi << (lg_n - TB)) | (mid << TB) | lo]);
+            if (pair) b[k] = *reinterpret_cast<const vec*>(&data[((size_t)hi << (lg_n - TB)) | (rmid << TB) | lo]);
+        }
+        #pragma unroll
+        for (unsigned k = 0; k < PER; k++) {
+            const unsigned s = tid + k * NT, hi = s / ROW, lo = (s % ROW) * V;
+            #pragma unroll
+            for (unsigned j = 0; j < V; j++) {
+                ldsA[bitrev_lds_index<TB>(hi, lo + j)] = a[k].e[j];
+                if (pair) ldsB[bitrev_lds_index<TB>(hi, lo + j)] = b[k].e[j];
+            }
+        }
+    } else {
+        #pragma unroll
+        for (unsigned k = 0; k < PER; k++) {
+            const unsigned s = tid + k * NT, r = s / ROW, q = (s % ROW) * V;             // destination row / first column
+            const unsigned lo = bit_rev32(r, TB);
+            vec a, b;
+            #pragma unroll
+            for (unsigned j = 0; j < V; j++) {
+                const unsigned hi = bit_rev32(q + j, TB);
+                a.e[j] = ldsA[bitrev_lds_index<TB>(hi, lo)];
+                if (pair) b.e[j] = ldsB[bitrev_lds_index<TB>(hi, lo)];
+            }
+            *reinterpret_cast<vec*>(&data[((size_t)r << (lg_n - TB)) | (rmid << TB) | q]) = a;
+            if (pair) *reinterpret_cast<vec*>(&data[((size_t)r << (lg_n - TB)) | (mid << TB) | q]) = b;
+        }
+    }
+}
+template<class F, unsigned TB>
+__global__ __launch_bounds__(256) void k_bitrev_tiled_vec(F* data, unsigned lg_n)
+{
+    extern __shared__ unsigned char bitrev_lds[];
+    F* ldsA = reinterpret_cast<F*>(bitrev_lds);
+    F* ldsB = ldsA + (((1u << TB) + 1) << TB);
+    bitrev_tile_vec_item<F, TB>(data, ldsA, ldsB, lg_n, blockIdx.x, threadIdx.x, 0);
+    __syncthreads();
+    bitrev_tile_vec_item<F, TB>(data, ldsA, ldsB, lg_n, blockIdx.x, threadIdx.x, 1);
+}
 // tile edge (bits): rows of >= 256 bytes, two tiles within 64 KB of LDS
 template<class F> struct bitrev_tile_bits { static constexpr unsigned value = sizeof(F) <= 4 ? 6 : sizeof(F) <= 8 ? 5 : 4; };
 

@@ -51,7 +51,13 @@ static void emu_bitrev(F* d, unsigned lg)
         F* A = lds.data(); F* B = A + (((1u << TB) + 1) << TB);
         for (size_t mid = 0; mid < (n >> (2 * TB)); mid++)
             for (int phase = 0; phase < 2; phase++)
-                for (unsigned tid = 0; tid < 256; tid++) bitrev_tile_item<F, TB>(d, A, B, lg, mid, tid, 256, phase);
+                for (unsigned tid = 0; tid < 256; tid++) {
+                    // as ntt_engine::bit_reverse: the 16-byte form for single-word fields in 16-byte aligned buffers
+                    if constexpr (sizeof(F) <= 8) {
+                        if (((uintptr_t)d & 15) == 0) { bitrev_tile_vec_item<F, TB>(d, A, B, lg, mid, tid, phase); continue; }
+                    }
+                    bitrev_tile_item<F, TB>(d, A, B, lg, mid, tid, 256, phase);
+                }
     } else {
         for (size_t i = 0; i < n; i++) bitrev_item(d, lg, i);
     }

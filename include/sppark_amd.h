@@ -96,7 +96,8 @@ SppError cuda_func(void *ptr);
  * reference's per-call msm_t does (msm/pippenger.cuh:730-747).  A context goes back to the pool
  * after the call and keeps its scratch only while that is below SPPARK_MSM_CACHE_BYTES
  * (environment, default 32 GiB); nothing is tied to the calling thread.  This call frees the
- * scratch of every idle pooled context (all devices).
+ * scratch of every idle pooled context (all devices) and the idle staging buffers of the library's
+ * NTT / LDE / polynomial entry points (sppark_ntt_release_cached's pool).
  *
  * Stream contract of the one-shot entry points: they are synchronous.  Host inputs are copied in
  * chunks that overlap the arithmetic.  When an input is a DEVICE pointer the call first waits for
@@ -260,9 +261,17 @@ SppError sppark_lde_powers(size_t device_id, void *d_inout, uint32_t lg_domain_s
  * expansion is then done in place.  Any other overlap is an invalid-value error. */
 SppError sppark_lde_expand(size_t device_id, void *d_out, const void *d_in, uint32_t lg_domain_size,
                            uint32_t lg_blowup, void *stream);
-/* sppark_lde keeps its device scratch (the coefficient copy, the staging of host buffers) between calls -- at most
- * two idle buffers per process; this frees them (the twiddle tables stay). */
+/* compute_ntt / sppark_lde on host buffers, the LDE's coefficient copy and the polynomial primitives keep their device
+ * scratch between calls: at most four idle buffers and at most SPPARK_SCRATCH_CACHE_BYTES (environment, default 1 GiB)
+ * of idle memory PER LIBRARY (every .so has its own pool); an allocation that fails frees the idle buffers and is tried
+ * once more before the call reports out-of-memory.  The twiddle tables are cached per (device, size, direction); the
+ * inter-pass tables of the 256-bit fields can be as large as the data (512 MB for a 2^24 transform) and are shared by
+ * all transform sizes.  This call frees the idle scratch buffers AND every cached twiddle table of this library (they
+ * are rebuilt on the next call); it must not run concurrently with a transform of the same library. */
 void     sppark_ntt_release_cached(void);
+/* diagnostics: idle bytes of the scratch pool / number of cached twiddle tables of this library */
+size_t   sppark_ntt_cached_scratch_bytes(void);
+size_t   sppark_ntt_cached_tables(void);
 
 /* ------------------------------------------------------------------------ */
 /* 3. Polynomial primitives over the library's NTT field (every library)      */

@@ -231,6 +231,7 @@ SPPARK_FFI void sppark_msm_release_cached(void)
 #ifndef SPPARK_NO_G2
     ctx_pool<msm2_impl>::get().release_idle();
 #endif
+    dev_scratch_pool::instance().release();     // the staging buffers of this library's NTT / LDE / polynomial entry points
 }
 
 // msm/batch_addition.cuh:25-132 (batch_addition / batch_diff, the bitmap variants; C++ templates in

@@ -87,7 +87,14 @@ static void lde_any(size_t device_id, void* inout, uint32_t lg_domain, uint32_t 
     }
     buf.done();
 }
-SPPARK_FFI void sppark_ntt_release_cached(void) { dev_scratch_pool::instance().release(); }
+SPPARK_FFI void sppark_ntt_release_cached(void)
+{
+    dev_scratch_pool::instance().release();
+    ntt_engine<fr_t>::instance().release_tables();
+}
+// diagnostics for the tests: idle scratch bytes of this library's pool, cached twiddle tables
+SPPARK_FFI size_t sppark_ntt_cached_scratch_bytes(void) { return dev_scratch_pool::instance().idle_bytes(); }
+SPPARK_FFI size_t sppark_ntt_cached_tables(void) { return ntt_engine<fr_t>::instance().cached_table_count(); }
 
 SPPARK_FFI RustError sppark_lde(size_t device_id, void* inout, uint32_t lg_domain_size, uint32_t lg_blowup,
                                 void* aux_out, void* stream)

@@ -141,14 +141,14 @@ private:
             if (aux) HIP_OK(hipStreamSynchronize(aux));
             HIP_OK(hipFree(blob)); blob = nullptr; blob_sz = 0;
         }
-        HIP_OK(hipMalloc((void**)&blob, sz));
+        HIP_OK(dev_scratch_pool::malloc_or_drain((void**)&blob, sz));      // (idle staging buffers of this library go first)
         blob_sz = sz;
     }
     void reserve_stage(size_t sz)
     {
         if (sz <= stage_sz) return;
         if (stage) { HIP_OK(hipDeviceSynchronize()); HIP_OK(hipFree(stage)); stage = nullptr; stage_sz = 0; }
-        HIP_OK(hipMalloc((void**)&stage, sz));
+        HIP_OK(dev_scratch_pool::malloc_or_drain((void**)&stage, sz));
         stage_sz = sz;
     }
     void reserve_sums(size_t count)
@@ -159,14 +159,14 @@ private:
         h_sums_cap = count;
     }
     void need_event(hipEvent_t& e) { if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
-    // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised at most once per (device, kernel, size step)
-    // in the process: the call costs a few microseconds of host time on every launch path otherwise
+    // hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised at most once per (context, kernel, size step):
+    // the call costs a few microseconds of host time on every launch path otherwise
+    // (the record lives in the CONTEXT: a process-wide one would be stale after a hipDeviceReset, and the next launch
+    // with more than 64 KB of dynamic LDS would fail; a context does not outlive its device)
+    std::map<const void*, size_t> lds_done;
     void lds_attr(const void* fn, size_t bytes)
     {
-        static std::mutex m;
-        static std::map<std::pair<int, const void*>, size_t> done;
-        std::lock_guard<std::mutex> lk(m);
-        size_t& have = done[std::make_pair(gpu->hip_id, fn)];
+        size_t& have = lds_done[fn];
         if (bytes <= have) return;
         HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         have = bytes;
@@ -351,7 +351,7 @@ public:
                     HIP_OK(hipMemcpyAsync(staging.p, points, np * ffi_affine_sz, hipMemcpyHostToDevice, stream));
                     src = staging.p;
                 }
-                HIP_OK(hipMalloc((void**)&pre_points, (size_t)fb_nw * np * conv_stride()));
+                HIP_OK(dev_scratch_pool::malloc_or_drain((void**)&pre_points, (size_t)fb_nw * np * conv_stride()));
                 launch_convert(pre_points, src, (unsigned)np, ffi_affine_sz);
                 if constexpr (MONTX) if (fixed_base) {
                     hipLaunchKernelGGL(k_fixed_base_table<fp_d>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream,
@@ -375,12 +375,13 @@ public:
     size_t preloaded() const { return pre_n; }
 
 private:
-    void launch_convert(unsigned char* dst, const unsigned char* src, unsigned n, size_t stride)
+    void launch_convert(unsigned char* dst, const unsigned char* src, unsigned n, size_t stride, hipStream_t on = nullptr)
     {
         if constexpr (INTERNAL) {
+            if (on == nullptr) on = stream;
             unsigned grid = (n + 255) / 256;
-            if (stride > 2 * FP_BYTES) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, stream, dst, src, n, (unsigned)stride);
-            else                       hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, stream, dst, src, n, (unsigned)stride);
+            if (stride > 2 * FP_BYTES) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, on, dst, src, n, (unsigned)stride);
+            else                       hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, on, dst, src, n, (unsigned)stride);
             HIP_OK(hipGetLastError());
         }
     }
@@ -504,8 +505,6 @@ private:
         bucket_t* buckets = (bucket_t*)(blob + l.buckets);
         u32* keyA = (u32*)(blob + l.keyA); bucket_t* ptA = (bucket_t*)(blob + l.ptA);
         u32* keyB = (u32*)(blob + l.keyB); bucket_t* ptB = (bucket_t*)(blob + l.ptB);
-        // (the bucket fill and the point conversion do not depend on the sort, but running them beside
-        // it on the second stream gains nothing: 157.0 -> 157.8 ms at 2^26, tools/gpu_r2_job11.sh)
         // With ONE window group the bucket offsets of every window are still there when the bucket sums run:
         // empty buckets are recognised from them and never read (k_bucket_level1), so no memset.  With several
         // groups the two offset sets are reused, and the buckets are cleared instead.
@@ -518,6 +517,9 @@ private:
             if (g == 0) {
                 // first group: on the main stream, at full width (stream order protects the set)
                 sort_group(stream, p, l, b, w0, wn, d_scalars, mont, fb_n, fb_nwins);
+                // (the conversion does not depend on the scalars, but running it on the second stream beside the digit /
+                // sort kernels gains nothing: all of them are memory-bound and share HBM -- 13.4 ms before the accumulation
+                // either way at 2^26, profiles/r04_msm_convert_beside_sort_negative.log; round 2 measured the same)
                 if (INTERNAL && !preconverted) {    // wire points -> the field's own records (2 products per point)
                     launch_convert(blob + l.conv, d_points, p.n, stride);
                     d_points = blob + l.conv;
@@ -668,6 +670,19 @@ private:
     msm_plan fixed_plan(size_t n) const
     {   return make_fixed_plan(n, pre_fb_wbits, pre_fb_nwins, SORTB_STAGE, tune);   }
 
+    // The one-window layout of the fixed-base mode needs ~16 B x windows x n of sort scratch in ONE piece (it cannot be
+    // chunked: the tables cover the whole vector).  When the device cannot hold it next to the tables, invoke() runs the
+    // ordinary chunked path on level 0 of the table instead of failing.
+    bool fixed_fits(size_t npoints, const void* scalars) const
+    {
+        const size_t need = make_layout(fixed_plan(npoints), false).total
+                          + (is_device_pointer(scalars) ? 0 : 2 * align_up(npoints * SCALAR_BYTES));
+        if (need <= blob_sz + stage_sz) return true;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
+        return need <= free_b - (free_b >> 5) + blob_sz + stage_sz;
+    }
+
     // out = sum s_i * P_i over the preloaded points through their fixed-base tables: device-resident scalars or host
     // scalars (copied in one piece), one pass, one window.
     void invoke_fixed(point_t& out, size_t npoints, const void* scalars, bool mont)
@@ -784,7 +799,7 @@ public:
         if (scalars == nullptr || ffi_affine_sz < 2 * FP_BYTES) HIP_OK(hipErrorInvalidValue);
         join_default_stream();
         // fixed-base tables cover exactly the preloaded vector: any other length runs the ordinary path on its first level
-        if (preconverted && pre_fb_nwins && npoints == pre_n && tune.chunk == 0 && tune.max_scratch == 0) {
+        if (preconverted && pre_fb_nwins && npoints == pre_n && tune.chunk == 0 && tune.max_scratch == 0 && fixed_fits(npoints, scalars)) {
             invoke_fixed(out, npoints, scalars, mont);
             return;
         }

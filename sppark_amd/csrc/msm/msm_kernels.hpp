@@ -410,7 +410,11 @@ void k_reduce_tail(xyzz_mem<FP::N>* __restrict__ buckets, u32* key0, xyzz_mem<FP
         const int last = nthreads == 1;
         reduce_runs_chunk<FP>(buckets, ok, op, ik, ip, nrec, F, nthreads, last, threadIdx.x);
         if (last) break;
-        __syncthreads();                                    // this level's records are written (same CU: visible)
+        // this level's records are read back by OTHER lanes of the work-group: make the global stores visible at
+        // work-group scope before the barrier (a barrier alone orders them only while all waves share one L1,
+        // i.e. not under the tgsplit / CU-split launch modes)
+        __threadfence_block();
+        __syncthreads();
         nrec = 2 * nthreads;
         u32* tk = ik; ik = ok; ok = tk;
         xyzz_mem<FP::N>* tp = ip; ip = op; op = tp;

@@ -69,11 +69,14 @@ template<class P> struct host_field<fr256_dev<P>> {
 
 template<class F>
 class ntt_engine {
-    struct table_set {
-        F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale;
-        std::map<std::tuple<unsigned, unsigned, int>, F*> pass_tw;  // (lg_cur, S, scaled) -> inter-pass twiddle table of that pass
-        std::map<std::tuple<unsigned, unsigned, int>, F*> r64_tw;   // (kind, lg_cur, scaled) -> table of the radix-64 plan
-    };
+    struct table_set { F *lo, *hi, *inner, *glo, *ghi; unsigned h; F scale; };
+    // Inter-pass twiddle tables.  W = w_n^(n / n_cur) is the primitive n_cur-th root whatever the transform size n, so an
+    // unscaled table is shared by every size and keyed (device, direction, family, a, b, 0): family 0 = k_pass_table
+    // (a = lg_cur, b = S), family 1 = k_r64_table (a = kind, b = lg_cur).  A table that also carries 1/n belongs to one
+    // size: its key ends in lg n.  (Round 3 kept one copy per (size, direction): a forward + inverse 2^24 transform of a
+    // 256-bit field pinned > 1.1 GB, and more for every further size.)
+    typedef std::tuple<int, int, int, unsigned, unsigned, unsigned> tw_key;
+    std::map<tw_key, F*> tw_cache;
     // the radix-64 plan (ntt_r64_kernels.hpp): single-word fields, transforms of >= 2^12 elements
     static constexpr bool R64 = sizeof(F) <= 8;
     static constexpr unsigned R64_DIRECT_MAX_LG = 20;          // one inter-pass table up to 2^20 entries, two small ones above
@@ -108,46 +111,51 @@ class ntt_engine {
     // (device, size, direction, pass shape); null when the pass generates its twiddles instead)
     static bool has_pass_table(unsigned lg_cur, unsigned S)
     {   return !(lg_cur > (ntt_gen_twiddles<F>::value ? PASS_TABLE_MAX_LG : wide_table_lg()) || lg_cur <= S || S / 2 == 0);   }
+    // Find or build one table.  The engine lock is NOT held while the table is allocated, generated and synchronised
+    // (another thread's transform of a cached size goes on meanwhile); two threads that miss the same key both build
+    // it and the loser frees its copy.  Returns nullptr when the device has no room for it -- the idle scratch buffers
+    // are given back first -- and the caller falls back to a plan without that table.
+    template<class Launch>
+    const F* cached_table(const tw_key& key, size_t count, hipStream_t stream, Launch&& launch)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            auto it = tw_cache.find(key);
+            if (it != tw_cache.end()) return it->second;
+        }
+        F* tw = nullptr;
+        hipError_t e = dev_scratch_pool::malloc_or_drain((void**)&tw, count * sizeof(F));
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return nullptr; }
+        HIP_OK(e);
+        launch(tw);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);      // visible to every later call on any stream
+        if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
+        std::lock_guard<std::mutex> lk(mtx);
+        auto ins = tw_cache.emplace(key, tw);
+        if (!ins.second) (void)hipFree(tw);                         // built twice: keep the first
+        return ins.first->second;
+    }
     const F* pass_table(int hip_dev, unsigned lg, int inverse, unsigned lg_cur, unsigned S, int scaled, const ntt_tables<F>& T, hipStream_t stream)
     {
         if (!has_pass_table(lg_cur, S)) return nullptr;
-        std::lock_guard<std::mutex> lk(mtx);
-        table_set& ts = cache.find(std::make_tuple(hip_dev, lg, inverse))->second;
-        auto key = std::make_tuple(lg_cur, S, scaled);
-        auto it = ts.pass_tw.find(key);
-        if (it != ts.pass_tw.end()) return it->second;
-        F* tw = nullptr;
         const size_t n = (size_t)1 << lg_cur;
-        HIP_OK(hipMalloc((void**)&tw, n * sizeof(F)));
-        hipLaunchKernelGGL(k_pass_table<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, T, lg_cur, S, scaled);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);      // visible to every later call on any stream
-        if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
-        ts.pass_tw.emplace(key, tw);
-        return tw;
+        return cached_table(tw_key(hip_dev, inverse, 0, lg_cur, S, scaled ? lg : 0u), n, stream, [&](F* tw) {
+            hipLaunchKernelGGL(k_pass_table<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tw, T, lg_cur, S, scaled);
+        });
     }
 
-    // a table of the radix-64 plan (r64_table_item), built once per (device, size, direction, kind, pass, scaled)
+    // a table of the radix-64 plan (r64_table_item)
     const F* r64_table(int hip_dev, unsigned lg, int inverse, unsigned kind, unsigned lg_cur, int scaled,
                        const ntt_tables<F>& T, hipStream_t stream)
     {
-        std::lock_guard<std::mutex> lk(mtx);
-        table_set& ts = cache.find(std::make_tuple(hip_dev, lg, inverse))->second;
-        auto key = std::make_tuple(kind, lg_cur, scaled);
-        auto it = ts.r64_tw.find(key);
-        if (it != ts.r64_tw.end()) return it->second;
         const size_t count = kind == 0 ? (size_t)1 << lg_cur : kind == 1 ? (size_t)1 << (lg_cur - 6) : 4096;
-        F* tw = nullptr;
-        HIP_OK(hipMalloc((void**)&tw, count * sizeof(F)));
-        hipLaunchKernelGGL(k_r64_table<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tw, T, kind, lg_cur, scaled);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { (void)hipFree(tw); HIP_OK(e); }
-        ts.r64_tw.emplace(key, tw);
-        return tw;
+        return cached_table(tw_key(hip_dev, inverse, 1, kind, lg_cur, scaled ? lg : 0u), count, stream, [&](F* tw) {
+            hipLaunchKernelGGL(k_r64_table<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tw, T, kind, lg_cur, scaled);
+        });
     }
 
-    const table_set& tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
+    table_set tables(int hip_dev, unsigned lg, int inverse, hipStream_t stream)
     {
         std::lock_guard<std::mutex> lk(mtx);
         auto key = std::make_tuple(hip_dev, lg, inverse);
@@ -157,7 +165,7 @@ class ntt_engine {
         table_set t;
         t.h = lg < 12 ? lg : 12;
         size_t nlo = (size_t)1 << t.h, nhi = (size_t)1 << (lg - t.h);
-        HIP_OK(hipMalloc((void**)&t.lo, (2 * (nlo + nhi) + 512) * sizeof(F)));
+        HIP_OK(dev_scratch_pool::malloc_or_drain((void**)&t.lo, (2 * (nlo + nhi) + 512) * sizeof(F)));
         t.hi = t.lo + nlo; t.glo = t.hi + nhi; t.ghi = t.glo + nlo; t.inner = t.ghi + nhi;
         auto w = H::top_root();
         for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = H::mul(w, w);
@@ -177,13 +185,26 @@ class ntt_engine {
 public:
     static ntt_engine& instance() { static ntt_engine e; return e; }
 
+    // Free every cached table of this library (sppark_ntt_release_cached); they are rebuilt on demand.  The caller
+    // guarantees that no transform of this library is in flight.
+    void release_tables()
+    {
+        std::lock_guard<std::mutex> lk(mtx);
+        int cur = 0; (void)hipGetDevice(&cur);
+        for (auto& kv : tw_cache) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second); }
+        for (auto& kv : cache) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second.lo); }
+        tw_cache.clear(); cache.clear();
+        (void)hipSetDevice(cur);
+    }
+    size_t cached_table_count() { std::lock_guard<std::mutex> lk(mtx); return tw_cache.size() + cache.size(); }
+
     // in-place transform of a DEVICE buffer of 2^lg elements on |stream|
     void run(const gpu_info& gpu, F* d, unsigned lg, int order, int direction, int type, hipStream_t stream)
     {
         if (lg == 0) return;                                        // ntt/ntt.cuh:220-221
         if (lg > F::TWO_ADICITY || order < 0 || order > 3) HIP_OK(hipErrorInvalidValue);
         const int inverse = direction == NTT_INVERSE;
-        const table_set& ts = tables(gpu.hip_id, lg, inverse, stream);
+        const table_set ts = tables(gpu.hip_id, lg, inverse, stream);
         ntt_tables<F> T{ts.lo, ts.hi, ts.inner, lg, ts.h, ts.scale, nullptr}, G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale, nullptr};
         const size_t n = (size_t)1 << lg;
         const unsigned egrid = (unsigned)((n + 255) / 256);
@@ -219,12 +240,26 @@ public:
         const unsigned smax = knobs.smax, lgc = knobs.lgc, lgt = knobs.lgt;
         ntt_plan pl;
         r64_plan rp; rp.nsteps = 0;
+        // the tables of the radix-64 plan, fetched (first call: built) BEFORE anything is launched: if the device has no
+        // room for one of them the transform runs the 8-stage plan, whose passes can generate their twiddles
+        const F* r64_tabs[8][2] = {};
         if (R64 && lg >= 12 && lg >= knobs.r64_min) {
             rp = make_r64_plan(lg);
-            pl.npass = rp.nsteps;
-        } else {
-            pl = make_ntt_plan(lg, lgc, lgt, smax);
+            bool ok = true;
+            for (unsigned i = 0; i < rp.nsteps && ok; i++) {
+                const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
+                if (st.kind == 0) continue;
+                const int scaled = inverse && i == rp.nsteps - 1;
+                if (st.kind == 2 || st.lg_cur <= knobs.r64_direct)
+                    ok = (r64_tabs[i][0] = r64_table(gpu.hip_id, lg, inverse, 0, st.lg_cur, scaled, T, stream)) != nullptr;
+                else
+                    ok = (r64_tabs[i][0] = r64_table(gpu.hip_id, lg, inverse, 1, st.lg_cur, scaled, T, stream)) != nullptr
+                      && (r64_tabs[i][1] = r64_table(gpu.hip_id, lg, inverse, 2, st.lg_cur, 0, T, stream)) != nullptr;
+            }
+            if (!ok) rp.nsteps = 0;
         }
+        if (rp.nsteps) pl.npass = rp.nsteps;
+        else           pl = make_ntt_plan(lg, lgc, lgt, smax);
         int scale_pass = -1;                        // (the radix-64 plan folds the scaling into its own last table)
         if (inverse && !rp.nsteps) {
             unsigned best = ~0u;
@@ -240,14 +275,9 @@ public:
                 const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
                 if constexpr (R64) {
                     if (st.kind != 0) {
-                        const int scaled = inverse && last;
                         ntt_r64_args<F> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur};
-                        if (st.kind == 2 || st.lg_cur <= knobs.r64_direct)
-                            A.tw = r64_table(gpu.hip_id, lg, inverse, 0, st.lg_cur, scaled, T, stream);
-                        else {
-                            A.t1 = r64_table(gpu.hip_id, lg, inverse, 1, st.lg_cur, scaled, T, stream);
-                            A.t2 = r64_table(gpu.hip_id, lg, inverse, 2, st.lg_cur, 0, T, stream);
-                        }
+                        if (st.kind == 2 || st.lg_cur <= knobs.r64_direct) A.tw = r64_tabs[i][0];
+                        else { A.t1 = r64_tabs[i][0]; A.t2 = r64_tabs[i][1]; }
                         const unsigned tiles = (unsigned)(n >> 12);
                         const size_t lds = sizeof(F) << 12;
 #define SPPARK_R64_LAUNCH(K)                                                                                   \
@@ -269,8 +299,12 @@ public:
             // 1/n of an inverse transform: carried by the table of the tabled pass on the smallest sub-problems when the
             // plan has one (a product per element saved), applied by the last pass otherwise
             const bool scale_here = inverse && scale_pass == (int)i;
-            P.apply_scale = inverse && last && scale_pass < 0;
             T.pass_tw = pass_table(gpu.hip_id, lg, inverse, P.lg_cur, P.S, scale_here ? 1 : 0, T, stream);
+            if (scale_here && T.pass_tw == nullptr) {           // no room for the scaled table: the shared unscaled one (or
+                scale_pass = -1;                                // none), and the last pass multiplies by 1/n itself
+                T.pass_tw = pass_table(gpu.hip_id, lg, inverse, P.lg_cur, P.S, 0, T, stream);
+            }
+            P.apply_scale = inverse && last && scale_pass < 0;
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);
             size_t lds = ntt_lds_elems(P) * sizeof(F);
@@ -313,6 +347,13 @@ public:
             bool vec = false;
             if constexpr (sizeof(F) <= 8) vec = ((uintptr_t)d & 15) == 0;
             if constexpr (sizeof(F) <= 8) {
+                // (experiment knob: SPPARK_NTT_BITREV_TB=5 -- 32 x 32 tiles for the 4-byte field too)
+                static const unsigned tbk = [] { const char* e = getenv("SPPARK_NTT_BITREV_TB"); return e ? (unsigned)atoi(e) : 0u; }();
+                if (vec && tbk == 5 && TB != 5) {
+                    const size_t lds5 = 2 * (((size_t)32 + 1) << 5) * sizeof(F);
+                    hipLaunchKernelGGL((k_bitrev_tiled_vec<F, 5>), dim3((unsigned)(n >> 10)), dim3(256), lds5, stream, d, lg);
+                    return;
+                }
                 if (vec) hipLaunchKernelGGL((k_bitrev_tiled_vec<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
             }
             if (!vec) hipLaunchKernelGGL((k_bitrev_tiled<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
@@ -325,7 +366,7 @@ public:
     void lde_powers(const gpu_info& gpu, F* d, unsigned lg, hipStream_t stream)
     {
         if (lg > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
-        const table_set& ts = tables(gpu.hip_id, lg, 0, stream);
+        const table_set ts = tables(gpu.hip_id, lg, 0, stream);
         ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg, ts.h, ts.scale, nullptr};
         const size_t n = (size_t)1 << lg;
         hipLaunchKernelGGL(k_coset<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d, G, 1);
@@ -348,7 +389,7 @@ public:
         const size_t dom = (size_t)1 << lg_domain, ext = dom << lg_blowup;
         const bool overlap = (d_in < d_out + ext) && (d_out < d_in + dom);
         if (overlap && (lg_blowup == 0 || d_in != d_out + (ext - dom))) HIP_OK(hipErrorInvalidValue);
-        const table_set& ts = tables(gpu.hip_id, lg_domain, 0, stream);
+        const table_set ts = tables(gpu.hip_id, lg_domain, 0, stream);
         ntt_tables<F> G{ts.glo, ts.ghi, nullptr, lg_domain, ts.h, ts.scale, nullptr};
         for (size_t lo = 0; lo < ext;) {
             const size_t hi = overlap ? ext - ((ext - lo) >> lg_blowup) : ext;

@@ -110,12 +110,32 @@ static inline bool is_device_pointer(const void* p)
 // synchronises the whole device -- costs more than a 2^22 -> 2^24 Goldilocks extension itself (0.50 -> 0.33 ms with the
 // pool, profiles/r03_ntt_lde.log).  A buffer is taken for ONE call and goes back only after that call has synchronised
 // its stream (done()), so concurrent calls never share one; a call that ends in an exception frees its buffer instead.
-// At most four idle buffers per library are kept, the largest ones.
+// Bounded: at most four idle buffers AND at most cache_limit() idle bytes per library (SPPARK_SCRATCH_CACHE_BYTES,
+// default 1 GiB; a buffer above the limit is freed when it comes back), and a failed allocation -- here or in the MSM
+// contexts of the same library -- frees every idle buffer and tries once more, so the cache can never be the reason a
+// call that fits the device runs out of memory.  Every .so has its own pool (one per field / curve).
 struct dev_scratch_pool {
     struct item { int dev; void* p; size_t bytes; };
     std::mutex m;
     std::vector<item> idle;
     static dev_scratch_pool& instance() { static dev_scratch_pool pool; return pool; }
+    static size_t cache_limit()
+    {
+        static const size_t lim = [] {
+            const char* e = getenv("SPPARK_SCRATCH_CACHE_BYTES");
+            return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)1 << 30;
+        }();
+        return lim;
+    }
+    // hipMalloc that gives the idle buffers back to the device before it reports out-of-memory
+    static hipError_t malloc_or_drain(void** p, size_t bytes)
+    {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();
+        instance().release();
+        return hipMalloc(p, bytes);
+    }
     void* take(int dev, size_t bytes, size_t& got)
     {
         {
@@ -126,28 +146,44 @@ struct dev_scratch_pool {
             if (best >= 0) { item it = idle[best]; idle.erase(idle.begin() + best); got = it.bytes; return it.p; }
         }
         void* p = nullptr;
-        HIP_OK(hipMalloc(&p, bytes ? bytes : 16));
+        HIP_OK(malloc_or_drain(&p, bytes ? bytes : 16));
         got = bytes ? bytes : 16;
         return p;
     }
     void give(int dev, void* p, size_t bytes)
     {
-        item drop{dev, nullptr, 0};
+        std::vector<item> drop;
         {
             std::lock_guard<std::mutex> lk(m);
             idle.push_back(item{dev, p, bytes});
-            if (idle.size() > 4) {
-                int small = 0;
-                for (int i = 1; i < (int)idle.size(); i++) if (idle[i].bytes < idle[small].bytes) small = i;
-                drop = idle[small]; idle.erase(idle.begin() + small);
+            // the smallest buffers go first: over the count, or while the idle bytes exceed the limit
+            for (;;) {
+                size_t total = 0;
+                for (auto& it : idle) total += it.bytes;
+                if (idle.size() <= 4 && total <= cache_limit()) break;
+                int victim = 0;
+                if (idle.size() <= 4) { for (int i = 1; i < (int)idle.size(); i++) if (idle[i].bytes > idle[victim].bytes) victim = i; }   // over the byte limit: the largest
+                else                  { for (int i = 1; i < (int)idle.size(); i++) if (idle[i].bytes < idle[victim].bytes) victim = i; }   // over the count: the smallest
+                drop.push_back(idle[victim]); idle.erase(idle.begin() + victim);
             }
         }
-        if (drop.p) { int cur = 0; (void)hipGetDevice(&cur); (void)hipSetDevice(drop.dev); (void)hipFree(drop.p); (void)hipSetDevice(cur); }
+        if (drop.empty()) return;
+        int cur = 0; (void)hipGetDevice(&cur);
+        for (auto& it : drop) { (void)hipSetDevice(it.dev); (void)hipFree(it.p); }
+        (void)hipSetDevice(cur);
+    }
+    size_t idle_bytes()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        size_t total = 0;
+        for (auto& it : idle) total += it.bytes;
+        return total;
     }
     void release()
     {
         std::vector<item> all;
         { std::lock_guard<std::mutex> lk(m); all.swap(idle); }
+        if (all.empty()) return;
         int cur = 0; (void)hipGetDevice(&cur);
         for (auto& it : all) { (void)hipSetDevice(it.dev); (void)hipFree(it.p); }
         (void)hipSetDevice(cur);

@@ -146,6 +146,10 @@ def load(name):
         L.sppark_lde_expand.restype = _Error
         L.sppark_ntt_release_cached.argtypes = []
         L.sppark_ntt_release_cached.restype = None
+        L.sppark_ntt_cached_scratch_bytes.argtypes = []
+        L.sppark_ntt_cached_scratch_bytes.restype = sz
+        L.sppark_ntt_cached_tables.argtypes = []
+        L.sppark_ntt_cached_tables.restype = sz
 
     if name in NTT_FIELDS or name in CURVES or name in POLY_ONLY:
         L.sppark_prefix_op.argtypes = [sz, vp, vp, sz, ci, vp]

@@ -26,6 +26,7 @@ def test_header_symbols_exported(libs):
               "sppark_gpu_ptr_alloc", "sppark_gpu_ptr_get"}
     msm_only = {s for s in syms if "msm" in s or "pippenger" in s or s.startswith("sppark_g1") or s.startswith("sppark_g2")} | {"sppark_ngpus", "sppark_batch_addition"}
     ntt_only = {"compute_ntt", "sppark_ntt", "sppark_lde", "sppark_lde_powers", "sppark_lde_expand", "sppark_ntt_release_cached",
+                "sppark_ntt_cached_scratch_bytes", "sppark_ntt_cached_tables",
                 "sppark_prefix_op", "sppark_poly_evaluate", "sppark_div_by_x_minus_z"}
     assert set(syms) == common | msm_only | ntt_only
     poly_only = {"sppark_prefix_op", "sppark_poly_evaluate", "sppark_div_by_x_minus_z"}

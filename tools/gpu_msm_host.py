@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, sppark_amd
 from sppark_amd import synth
-for lg in ([int(a) for a in sys.argv[1:]] or [24, 26]):
+for lg in ([int(a) for a in sys.argv[1:] if not a.startswith('-')] or [24, 26]):
     n = 1 << lg
     pts, _ = synth.replicated_points(n, "bls12_381", 2048, 1)
     hp = np.zeros((n, 104), dtype=np.uint8); hp[:, :96] = pts.cpu().numpy(); hp[3::2048, 96] = 1
@@ -16,9 +16,10 @@ for lg in ([int(a) for a in sys.argv[1:]] or [24, 26]):
     ref = None
     def sweep(tag, P, S):
         global ref
-        for chunk_lg in (0, 22, 23, 24):
+        for chunk_lg in (0, 22, 23, 24, -5, -6, -7):               # negative: n / k points per chunk (k chunks)
             if chunk_lg > lg: continue
-            ctx.tune_pipeline(groups=1, chunk_points=(1 << chunk_lg) if chunk_lg else 0)
+            cp = (1 << chunk_lg) if chunk_lg > 0 else (-(-n // -chunk_lg) if chunk_lg < 0 else 0)
+            ctx.tune_pipeline(groups=1, chunk_points=cp)
             ctx.invoke(P, S, ffi_affine_sz=104)
             best = 1e9
             for _ in range(3):
@@ -26,9 +27,11 @@ for lg in ([int(a) for a in sys.argv[1:]] or [24, 26]):
             a = sppark_amd.to_affine(out)
             ref = a if ref is None else ref
             print("2^%d %s, chunk %s: %d chunks, %.1f ms, %.3e points/s, %.1f GB/s of input %s"
-                  % (lg, tag, "auto" if not chunk_lg else "2^%d" % chunk_lg, ctx.last_chunks(), best * 1e3, n / best, gb / best,
+                  % (lg, tag, "auto" if not chunk_lg else "2^%d" % chunk_lg if chunk_lg > 0 else "n/%d" % -chunk_lg, ctx.last_chunks(), best * 1e3, n / best, gb / best,
                      "OK" if (a == ref).all() else "MISMATCH"), flush=True)
     sweep("pageable host buffers", hp, hs)
+    if "--registered" not in sys.argv:
+        ctx.close(); del hp, hs; continue
     # the caller's own buffers registered in place (what the library could do per call): cost of the registration
     rt = torch.cuda.cudart()
     for rep in range(2):

@@ -416,14 +416,21 @@ def main():
             hp = np.zeros((m, 104), dtype=np.uint8); hp[:, :96] = pts[:m].cpu().numpy()
             hp[3::PERIOD, 96] = 1                                # Affine_inf_t: the flag byte marks infinity
             hs = sc[:m].cpu().numpy()
-            sppark_amd.multi_scalar_mult_arkworks(hp[:1 << 21], hs[:1 << 21])
+            # first call at this size: the pooled context grows its scratch and staging buffers inside the call
+            # (hipFree + hipMalloc of GBs); the reported figure is the steady state a prover sees from its second
+            # proof on, the first call's time is kept beside it
             t1 = time.perf_counter()
-            hout = sppark_amd.multi_scalar_mult_arkworks(hp, hs)
-            dt = time.perf_counter() - t1
+            sppark_amd.multi_scalar_mult_arkworks(hp, hs)
+            dt_first = time.perf_counter() - t1
+            dt = 1e30
+            for _ in range(2):
+                t1 = time.perf_counter()
+                hout = sppark_amd.multi_scalar_mult_arkworks(hp, hs)
+                dt = min(dt, time.perf_counter() - t1)
             hexp = O.msm_affine(O.BLS12_381, base.cpu().numpy(), fold.fold_scalars(sc[:m], PERIOD, r_mod), algo=0, param=8)
             ok = bool((sppark_amd.to_affine(hout) == hexp).all())
             assert ok, "host-buffer MSM differs from the oracle"
-            host["2^%d" % lgh] = {"points": m, "seconds": dt, "points_per_s": m / dt, "equals_oracle": ok,
+            host["2^%d" % lgh] = {"points": m, "seconds": dt, "seconds_first_call": dt_first, "points_per_s": m / dt, "equals_oracle": ok,
                                   "input_gb_per_s": m * (104 + 32) / dt / 1e9, "frac_of_h2d_peak": m * (104 + 32) / dt / 1e9 / h2d,
                                   "frac_of_h2d_pageable": m * (104 + 32) / dt / 1e9 / h2d_pageable}
             del hp, hs

@@ -275,10 +275,11 @@ public:
     {
         HIP_OK(hipSetDevice(gpu->hip_id));
         size_t chunk = choose_chunk(npoints, (host_points ? ffi_affine_sz : 0) + (host_scalars ? SCALAR_BYTES : 0));
-        // as invoke(): one plan for the full chunks, one for the shorter last one, scratch for the larger
-        const size_t nchunks = (npoints + chunk - 1) / chunk;
-        msm_plan p = make_plan(chunk, FRp::NBITS, tune), p_last = make_plan(npoints - (nchunks - 1) * chunk, FRp::NBITS, tune);
-        reserve(std::max(make_layout(p, true).total, make_layout(p_last, true).total));
+        // as invoke(): one plan per chunk length, scratch for the largest layout
+        const std::vector<size_t> cb = chunk_bounds(npoints, chunk);
+        size_t need = 0;
+        for (size_t c = 0; c + 1 < cb.size(); c++) need = std::max(need, make_layout(make_plan(cb[c + 1] - cb[c], FRp::NBITS, tune), true).total);
+        reserve(need);
         if (host_points || host_scalars)
             reserve_stage(2 * (align_up(host_points ? chunk * ffi_affine_sz : 0) + align_up(host_scalars ? chunk * SCALAR_BYTES : 0)));
     }
@@ -416,6 +417,23 @@ private:
         }
         while (need(chunk) > limit && chunk > 4096) chunk = (chunk + 1) / 2;
         return chunk;
+    }
+
+    // Chunk boundaries [b_0 = 0, b_1, ..., b_k = n]: equal chunks, the last one shorter.
+    // (Round 4 measured the alternatives for host-resident inputs on a host whose pinned H2D rate is 57 GB/s,
+    // profiles/r04_msm_host_path.log: the pipeline behaves exactly like t = sum over chunks of max(copy, compute of the
+    // previous chunk) + the last computation, with the copies AT the link rate -- 2^26 points: 163 ms of copies + one
+    // exposed 2^24-point MSM = 201 ms.  Half-sized first / last chunks change nothing (the second-to-last computation is
+    // exposed instead: 202 ms); the points copy in 2 or 4 slices from as many host threads and streams changes nothing
+    // (201 ms: one pageable copy already saturates the link); eight 2^23-point chunks gain 5 % here (190 ms) and lost
+    // 8 % on the host of round 3 (266 vs 245 ms, profiles/r03_msm_host_path.log), where small pageable copies are
+    // slower per byte.  So: four chunks of at most 2^24 points, as the reference's 2^24-point strides.)
+    std::vector<size_t> chunk_bounds(size_t n, size_t chunk) const
+    {
+        std::vector<size_t> b{0};
+        for (size_t lo = chunk; lo < n; lo += chunk) b.push_back(lo);
+        b.push_back(n);
+        return b;
     }
 
     // ---- one complete MSM over device-resident data, asynchronously on stream (+ aux) ----------
@@ -807,24 +825,30 @@ public:
         const bool pts_dev = is_device_pointer(points), sc_dev = is_device_pointer(scalars);
         const bool host = !pts_dev || !sc_dev;
         const size_t chunk = choose_chunk(npoints, (pts_dev ? 0 : ffi_affine_sz) + (sc_dev ? 0 : SCALAR_BYTES));
-        const size_t nchunks = (npoints + chunk - 1) / chunk;
+        const std::vector<size_t> cb = chunk_bounds(npoints, chunk);
+        const size_t nchunks = cb.size() - 1;
         const size_t in_stride = preconverted ? conv_stride() : ffi_affine_sz;     // bytes between input records
         if (nchunks > 4096) HIP_OK(hipErrorOutOfMemory);
 
-        // one plan for the full chunks and one for the (shorter) last chunk; scratch for the larger
-        const msm_plan p_full = make_plan(chunk, FRp::NBITS, tune);
-        const msm_plan p_last = make_plan(npoints - (nchunks - 1) * chunk, FRp::NBITS, tune);
-        if (p_full.nwins > MAX_WINS || p_last.nwins > MAX_WINS) HIP_OK(hipErrorInvalidValue);
-        const layout l_full = make_layout(p_full, !preconverted), l_last = make_layout(p_last, !preconverted);
-        reserve(std::max(l_full.total, l_last.total));
+        // one plan (and layout) per chunk; scratch for the largest
+        std::vector<msm_plan> plans(nchunks);
+        std::vector<layout> layouts(nchunks);
+        size_t need = 0, longest = 0;
+        for (size_t c = 0; c < nchunks; c++) {
+            plans[c] = make_plan(cb[c + 1] - cb[c], FRp::NBITS, tune);
+            if (plans[c].nwins > MAX_WINS) HIP_OK(hipErrorInvalidValue);
+            layouts[c] = make_layout(plans[c], !preconverted);
+            need = std::max(need, layouts[c].total); longest = std::max(longest, cb[c + 1] - cb[c]);
+        }
+        reserve(need);
         reserve_sums(nchunks * MAX_WINS);
-        const size_t st_pts = align_up(pts_dev ? 0 : chunk * ffi_affine_sz), st_sc = align_up(sc_dev ? 0 : chunk * SCALAR_BYTES);
+        const size_t st_pts = align_up(pts_dev ? 0 : longest * ffi_affine_sz), st_sc = align_up(sc_dev ? 0 : longest * SCALAR_BYTES);
         if (host) { reserve_stage(2 * (st_pts + st_sc)); if (nchunks > 1) need_cpy(); }
 
         for (size_t c = 0; c < nchunks; c++) {
-            const size_t lo = c * chunk, cn = std::min(chunk, npoints - lo);
-            const msm_plan& p = c + 1 == nchunks ? p_last : p_full;
-            const layout& l = c + 1 == nchunks ? l_last : l_full;
+            const size_t lo = cb[c], cn = cb[c + 1] - lo;
+            const msm_plan& p = plans[c];
+            const layout& l = layouts[c];
             const unsigned sb = c & 1;
             const unsigned char* d_points = (const unsigned char*)points + lo * in_stride;
             const u32* d_scalars = (const u32*)((const unsigned char*)scalars + lo * SCALAR_BYTES);
@@ -849,7 +873,7 @@ public:
                     HIP_OK(hipStreamWaitEvent(stream, ev_copied[sb], 0));
                 }
             }
-            // (a shorter last chunk has a layout of its own: harmless, every sort set of an MSM is
+            // (chunks of different lengths have layouts of their own: harmless, every sort set of an MSM is
             // either written on the main stream or behind an event recorded on it after the previous MSM)
             enqueue(p, l, d_points, in_stride, preconverted, d_scalars, mont, h_sums + c * MAX_WINS, c == 0);
             if (host && nchunks > 1) HIP_OK(hipEventRecord(ev_chunkdone[sb], stream));
@@ -858,7 +882,7 @@ public:
         last_chunks = (unsigned)nchunks;
 
         if (timing) {
-            const msm_plan& p = nchunks == 1 ? p_last : p_full;
+            const msm_plan& p = plans[0];
             float acc = 0, t;
             for (unsigned g = 0; g < p.G; g++) { HIP_OK(hipEventElapsedTime(&t, tev[2 + 2 * g], tev[3 + 2 * g])); acc += t; }
             HIP_OK(hipEventElapsedTime(&last_ms[0], tev[0], tev[2]));
@@ -868,7 +892,7 @@ public:
         }
 
         for (size_t c = 0; c < nchunks; c++) {
-            point_t part = horner(h_sums + c * MAX_WINS, c + 1 == nchunks ? p_last : p_full);
+            point_t part = horner(h_sums + c * MAX_WINS, plans[c]);
             out.add(part);
         }
     }

@@ -347,13 +347,6 @@ public:
             bool vec = false;
             if constexpr (sizeof(F) <= 8) vec = ((uintptr_t)d & 15) == 0;
             if constexpr (sizeof(F) <= 8) {
-                // (experiment knob: SPPARK_NTT_BITREV_TB=5 -- 32 x 32 tiles for the 4-byte field too)
-                static const unsigned tbk = [] { const char* e = getenv("SPPARK_NTT_BITREV_TB"); return e ? (unsigned)atoi(e) : 0u; }();
-                if (vec && tbk == 5 && TB != 5) {
-                    const size_t lds5 = 2 * (((size_t)32 + 1) << 5) * sizeof(F);
-                    hipLaunchKernelGGL((k_bitrev_tiled_vec<F, 5>), dim3((unsigned)(n >> 10)), dim3(256), lds5, stream, d, lg);
-                    return;
-                }
                 if (vec) hipLaunchKernelGGL((k_bitrev_tiled_vec<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);
             }
             if (!vec) hipLaunchKernelGGL((k_bitrev_tiled<F, TB>), dim3((unsigned)(n >> (2 * TB))), dim3(256), lds, stream, d, lg);

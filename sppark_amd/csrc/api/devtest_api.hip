@@ -5,6 +5,7 @@
 // costs are measured on the box rather than assumed.  Not part of the
 // reference's surface.
 #include "../msm/curve_select.hpp"
+#include "../ec/xyzz_coop.hpp"
 #include "../util/runtime.hpp"
 #include <vector>
 
@@ -85,11 +86,11 @@ SPPARK_FFI RustError sppark_devtest_xyzz_op(int op, void* out, const void* a, co
 {
     return guarded([&] {
         (void)select_gpu(-1);
-        size_t ab = n * sizeof(wire_bucket_m), bb = n * (op == 0 ? sizeof(wire_bucket_m) : 8 * fp_d::N);
+        size_t ab = n * sizeof(wire_bucket_m), bb = n * (op == 0 || op == 4 ? sizeof(wire_bucket_m) : 8 * fp_d::N);
         wire_bucket_m *d_a, *d_o; unsigned char* d_b;
         HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_o, ab)); HIP_OK(hipMalloc((void**)&d_b, bb ? bb : 16));
         HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice));
-        if (op != 3) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
+        if (op != 3 && op != 5) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_xyzz_op, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpy(out, d_o, ab, hipMemcpyDeviceToHost));
@@ -155,6 +156,87 @@ __global__ void k_bucket_xyzz_op(wire_bucket_m* out, const wire_bucket_m* a, con
     }
 }
 
+// op 4: a += b (xyzz), op 5: a = 2a -- through the COOPERATIVE forms (ec/xyzz_coop.hpp): four waves per 64 operations
+template<class F>
+__global__ __launch_bounds__(256) void k_bucket_xyzz_coop(wire_bucket_m* out, const wire_bucket_m* a, const wire_bucket_m* b, unsigned n, int op)
+{
+    if constexpr (field_is_montx<F>::value) {
+        __shared__ coop_lds<F> ex;
+        constexpr int NW = fp_d::N;
+        const unsigned lane = threadIdx.x & 63, role = threadIdx.x >> 6, i = blockIdx.x * 64 + lane;
+        auto to_internal = [](const wire_bucket_m* src) {
+            xyzz_dev<F> r;
+            bool inf = true;
+            for (int k = 2 * NW; k < 4 * NW; k++) inf &= src->w[k] == 0;
+            if (inf) { r.set_inf(); return r; }
+            r.X = F::from_std(src->w); r.Y = F::from_std(src->w + NW);
+            r.ZZZ = F::from_std(src->w + 2 * NW); r.ZZ = F::from_std(src->w + 3 * NW);
+            return r;
+        };
+        xyzz_dev<F> p, q;
+        p.set_inf(); q.set_inf();
+        if (i < n) { p = to_internal(&a[i]); if (op == 4) q = to_internal(&b[i]); }
+        coop_ctx<F> c{&ex, role, lane, 0};
+        // two operations in a row, so that the hand-over of the exchange sets between operations is exercised too:
+        // op 4: (a + b) + b - checked against two serial additions; op 5: 2(2a)
+        if (op == 4) { coop_add<F>(p, q, c); coop_add<F>(p, q, c); }
+        else         { coop_dbl<F>(p, c); coop_dbl<F>(p, c); }
+        if (i < n && role == (i & 3)) p.store_std(&out[i]);     // every copy is the same: let the four waves take turns
+    }
+}
+
+// Latency micro-benchmark of a CHAIN of point operations, one work-group per CU (the regime of the MSM's tail):
+// mode 0: add_pairs by one wave, 1: coop_add by four waves, 2: dbl_pairs, 3: coop_dbl, 4: serial add (single chains)
+template<class F>
+__global__ __launch_bounds__(256) void k_chain_bench(wire_bucket_m* out, const wire_bucket_m* a, const wire_bucket_m* b, int mode, int reps)
+{
+    if constexpr (field_is_montx<F>::value) {
+        __shared__ coop_lds<F> ex;
+        constexpr int NW = fp_d::N;
+        const unsigned lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+        auto to_internal = [](const wire_bucket_m* src) {
+            xyzz_dev<F> r;
+            r.X = F::from_std(src->w); r.Y = F::from_std(src->w + NW);
+            r.ZZZ = F::from_std(src->w + 2 * NW); r.ZZ = F::from_std(src->w + 3 * NW);
+            return r;
+        };
+        xyzz_dev<F> p = to_internal(&a[lane]), q = to_internal(&b[lane]);
+        coop_ctx<F> c{&ex, role, lane, 0};
+        const bool coop = mode == 1 || mode == 3;
+        if (!coop && role != 0) return;
+        #pragma unroll 1
+        for (int r = 0; r < reps; r++) {
+            if (mode == 0) p.add_pairs(q);
+            else if (mode == 1) coop_add<F>(p, q, c);
+            else if (mode == 2) p.dbl_pairs();
+            else if (mode == 3) coop_dbl<F>(p, c);
+            else p.add(q);
+        }
+        if (role == 0 && blockIdx.x == 0) p.store_std(&out[lane]);
+    }
+}
+SPPARK_FFI RustError sppark_devtest_chain_bench(int mode, int reps, int nblocks, void* out, const void* a, const void* b, float* ms)
+{
+    return guarded([&] {
+        if (!field_is_montx<msm_fp_d>::value) HIP_OK(hipErrorNotSupported);
+        (void)select_gpu(-1);
+        const size_t ab = 64 * sizeof(wire_bucket_m);
+        wire_bucket_m *d_a, *d_b, *d_o;
+        HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_b, ab)); HIP_OK(hipMalloc((void**)&d_o, ab));
+        HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(d_b, b, ab, hipMemcpyHostToDevice));
+        hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        for (int it = 0; it < 2; it++) {
+            HIP_OK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_chain_bench<msm_fp_d>, dim3(nblocks), dim3(256), 0, 0, d_o, d_a, d_b, mode, reps);
+            HIP_OK(hipEventRecord(e1, 0));
+            HIP_OK(hipEventSynchronize(e1));
+        }
+        HIP_OK(hipEventElapsedTime(ms, e0, e1));
+        HIP_OK(hipMemcpy(out, d_o, ab, hipMemcpyDeviceToHost));
+        (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    });
+}
+
 // element size: NL words for ops on internal limbs (see k_bucket_field_op)
 SPPARK_FFI RustError sppark_devtest_bucket_field_op(int op, void* out, const void* a, const void* b, size_t n)
 {
@@ -180,12 +262,16 @@ SPPARK_FFI RustError sppark_devtest_bucket_xyzz_op(int op, void* out, const void
     return guarded([&] {
         if (!field_is_internal<msm_fp_d>::value) HIP_OK(hipErrorNotSupported);
         (void)select_gpu(-1);
-        size_t ab = n * sizeof(wire_bucket_m), bb = n * (op == 0 ? sizeof(wire_bucket_m) : 8 * fp_d::N);
+        size_t ab = n * sizeof(wire_bucket_m), bb = n * (op == 0 || op == 4 ? sizeof(wire_bucket_m) : 8 * fp_d::N);
         wire_bucket_m *d_a, *d_o; unsigned char* d_b;
         HIP_OK(hipMalloc((void**)&d_a, ab)); HIP_OK(hipMalloc((void**)&d_o, ab)); HIP_OK(hipMalloc((void**)&d_b, bb ? bb : 16));
         HIP_OK(hipMemcpy(d_a, a, ab, hipMemcpyHostToDevice));
-        if (op != 3) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_bucket_xyzz_op<msm_fp_d>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
+        if (op != 3 && op != 5) HIP_OK(hipMemcpy(d_b, b, bb, hipMemcpyHostToDevice));
+        if (op >= 4) {
+            if (!field_is_montx<msm_fp_d>::value) HIP_OK(hipErrorNotSupported);
+            hipLaunchKernelGGL(k_bucket_xyzz_coop<msm_fp_d>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, 0, d_o, d_a, (const wire_bucket_m*)d_b, (unsigned)n, op);
+        } else
+            hipLaunchKernelGGL(k_bucket_xyzz_op<msm_fp_d>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_o, d_a, d_b, (unsigned)n, op);
         HIP_OK(hipGetLastError());
         HIP_OK(hipMemcpy(out, d_o, ab, hipMemcpyDeviceToHost));
         (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_o);

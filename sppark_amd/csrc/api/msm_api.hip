@@ -4,6 +4,7 @@
 // (msm/pippenger.cuh:735-746).
 #include "../msm/curve_select.hpp"
 #include "../msm/msm_kernels.hpp"
+#include "../msm/msm_coop_kernels.hpp"
 #include "../msm/msm_sort_kernels.hpp"
 
 // the big kernels are instantiated in their own translation units
@@ -26,6 +27,14 @@ extern template __global__ void k_bucket_level1_lat<msm_fp_d>(bucket_m*, bucket_
 extern template __global__ void k_bucket_levelN_lat<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                           unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_bits<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_top_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
+extern template __global__ void k_bucket_top_sum_coop<msm_fp_d>(bucket_m*, const bucket_m*, unsigned);
+extern template __global__ void k_reduce_runs_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
+                                                         unsigned, unsigned, unsigned, int, const u32*);
+extern template __global__ void k_reduce_tail_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, u32*, bucket_m*, unsigned, unsigned, const u32*);
+extern template __global__ void k_bucket_level1_coop<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
+extern template __global__ void k_bucket_levelN_coop<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
+                                                           unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_sum<msm_fp_d>(bucket_m*, const bucket_m*, unsigned);
 // ... and once more over Fp2 for G2 (the same units compiled with -DSPPARK_G2)
 #ifndef SPPARK_NO_G2

@@ -1,0 +1,282 @@
+// The latency-bound end of the bucket sums with COOPERATIVE point operations (ec/xyzz_coop.hpp: four waves per 64
+// operations): the subset-sum top (k_bucket_top_bits / k_bucket_top_sum of msm_kernels.hpp) and the narrow end of the
+// record tree.  G1 bucket fields with their own records only.
+//
+// What the counters and timelines say about these kernels (profiles/r03_msm_timeline_2p*.txt, r04_msm_timeline_2p16_before.txt):
+// at every size from 2^18 points on, k_bucket_top_bits + k_bucket_top_sum are ~0.55 ms of chains -- per work-group a
+// gather of nitems/512 additions per lane, an 8-step tree over 256 lanes and b + lgG <= 16..20 doublings by ONE lane --
+// run by (m + 1) x windows ~ 200 work-groups, one per CU: three quarters of every SIMD's issue slots are empty.  The tree
+// and the doublings are where the cooperative forms apply directly: a tree level over s <= 64 pairs is one cooperative
+// addition, and the doubling chain of lane 0 is a chain of cooperative doublings -- ~2.7x fewer instructions on the
+// critical path each.
+#pragma once
+#include "msm_kernels.hpp"
+#include "../ec/xyzz_coop.hpp"
+
+namespace sppark_amd {
+
+static constexpr unsigned COOP_NT = 256;        // four waves
+
+// CAP points in LDS, word-major (lane-contiguous words: conflict-free 4-byte accesses)
+template<class FP, unsigned CAP> struct coop_img {
+    u32 w[4 * FP::N][CAP];
+    SPPARK_DEVFN xyzz_dev<FP> load(unsigned i) const
+    {
+        constexpr int N = FP::N;
+        xyzz_dev<FP> r;
+        #pragma unroll
+        for (int j = 0; j < N; j++) { r.X.l[j] = w[j][i]; r.Y.l[j] = w[N + j][i]; r.ZZZ.l[j] = w[2 * N + j][i]; r.ZZ.l[j] = w[3 * N + j][i]; }
+        return r;
+    }
+    SPPARK_DEVFN void store(unsigned i, const xyzz_dev<FP>& v)
+    {
+        constexpr int N = FP::N;
+        #pragma unroll
+        for (int j = 0; j < N; j++) { w[j][i] = v.X.l[j]; w[N + j][i] = v.Y.l[j]; w[2 * N + j][i] = v.ZZZ.l[j]; w[3 * N + j][i] = v.ZZ.l[j]; }
+    }
+    // the four waves hold the same value: wave |role| writes coordinate |role|
+    SPPARK_DEVFN void store_coord(unsigned i, unsigned role, const xyzz_dev<FP>& v)
+    {
+        constexpr int N = FP::N;
+        const FP& f = role == 0 ? v.X : role == 1 ? v.Y : role == 2 ? v.ZZZ : v.ZZ;
+        #pragma unroll
+        for (int j = 0; j < N; j++) w[role * N + j][i] = f.l[j];
+    }
+};
+
+// img[0] = sum of img[0 .. 2*s0): pairwise tree, one cooperative addition per 64 pairs and level.  All COOP_NT lanes call.
+template<class FP, unsigned CAP>
+SPPARK_DEVFN void coop_tree_sum(coop_img<FP, CAP>* img, unsigned s0, coop_ctx<FP>& c)
+{
+    for (unsigned s = s0; s >= 1; s >>= 1) {
+        for (unsigned base = 0; base < s; base += 64) {
+            const unsigned i = base + c.lane;
+            const bool on = i < s;
+            xyzz_dev<FP> x, y;
+            if (on) { x = img->load(i); y = img->load(i + s); } else { x.set_inf(); y.set_inf(); }
+            coop_add<FP>(x, y, c);                  // (barriers inside: every wave has loaded before any wave stores)
+            if (on) img->store_coord(i, c.role, x);
+        }
+        coop_barrier();
+    }
+}
+
+static inline size_t top_bits_coop_lds(size_t nl) { return 2 * 4 * nl * 64 * 4 + 4 * nl * COOP_NT * 4; }
+
+// k_bucket_top_bits with the tree and the doubling chain in cooperative form (same grid, same per-lane gather, same output)
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_bucket_top_bits_coop(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ A,
+                            const xyzz_mem<FP::N>* __restrict__ Wt, unsigned nitems, unsigned m, unsigned lgG)
+{
+    extern __shared__ unsigned char top_lds[];
+    coop_lds<FP>* ex = reinterpret_cast<coop_lds<FP>*>(top_lds);
+    coop_img<FP, COOP_NT>* img = reinterpret_cast<coop_img<FP, COOP_NT>*>(top_lds + sizeof(coop_lds<FP>));
+    const unsigned b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    {
+        const xyzz_dev<FP> acc = bucket_top_gather<FP>(A, Wt, nitems, m, b, w, tid, COOP_NT);
+        img->store(tid, acc);
+    }
+    coop_barrier();
+    coop_ctx<FP> c{ex, tid >> 6, tid & 63, 0};
+    // (with fewer items than lanes the upper lanes hold infinity: the tree starts where there is something to add)
+    coop_tree_sum<FP, COOP_NT>(img, nitems >= COOP_NT ? COOP_NT / 2 : nitems / 2, c);
+    xyzz_dev<FP> x;
+    if (c.lane == 0) x = img->load(0); else x.set_inf();
+    if (b < m) {
+        #pragma unroll 1
+        for (unsigned k = 0; k < b + lgG; k++) coop_dbl<FP>(x, c);
+    }
+    if (tid == 0) x.store(&parts[(size_t)w * (m + 1) + b]);
+}
+
+// k_bucket_top_sum: the m + 1 <= 32 parts of a window, one work-group of four waves per window
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned m)
+{
+    __shared__ coop_lds<FP> ex;
+    __shared__ coop_img<FP, 32> img;
+    const unsigned w = blockIdx.x, tid = threadIdx.x;
+    if (tid < 32) img.store(tid, bucket_top_sum_gather<FP>(parts, m, w, tid));
+    coop_barrier();
+    coop_ctx<FP> c{&ex, tid >> 6, tid & 63, 0};
+    unsigned s0 = 1;
+    while (2 * s0 < m + 1) s0 <<= 1;
+    coop_tree_sum<FP, 32>(&img, s0, c);
+    if (tid == 0) img.load(0).store(&out[w]);
+}
+
+} // namespace sppark_amd
+
+namespace sppark_amd {
+
+// ---------------------------------------------------------------------------
+// The record tree (msm_kernels.hpp reduce_runs_chunk) with its additions in cooperative form: a work-group is 64 work
+// items x four waves.  Below ~2^19 points the buckets are longer than k_join_runs' walk and the tree does the work: at
+// 2^16 points eight levels of ONE addition each (every level halves the list), 27-35 us per level with one wave per
+// addition (profiles/r04_msm_timeline_2p16_before.txt).  From the level with <= COOP_TREE_MAX work items on -- one
+// work-group per CU -- the cooperative addition (9 us against 16, profiles/r04_chain_bench.log) sets the pace.
+// Same record semantics as reduce_runs_chunk; the four copies of a work item take the same decisions, wave 0 stores.
+// The addition at step r is skipped by the whole work-group when no work item has one (__syncthreads_or): with the
+// [run, NONE, run, NONE] pattern k_accumulate leaves, every second step.
+// ---------------------------------------------------------------------------
+static constexpr unsigned COOP_TREE_MAX = 16384;
+
+template<class FP>
+SPPARK_DEVFN void reduce_runs_coop_item(xyzz_mem<FP::N>* buckets, u32* out_key, xyzz_mem<FP::N>* out_pt,
+                                        const u32* in_key, const xyzz_mem<FP::N>* in_pt,
+                                        unsigned nrec, unsigned F, unsigned nthreads, int last, unsigned t, coop_ctx<FP>& c)
+{
+    const bool live = t < nthreads, writer = c.role == 0;
+    const unsigned lo = t * F, hi = !live ? 0 : (nrec < lo + F ? nrec : lo + F);
+    const size_t rec0 = (size_t)t * 2;
+    xyzz_dev<FP> acc; acc.set_inf();
+    u32 cur = KEY_NONE, slot0_key = KEY_NONE;
+    bool first_run = true;
+    for (unsigned s = 0; s < F; s++) {                              // uniform trip count: barriers inside
+        const unsigned r = lo + s;
+        const u32 k = live && r < hi ? in_key[r] : KEY_NONE;
+        const bool add = k != KEY_NONE && k == cur;
+        if (k != KEY_NONE && !add) {                                // a new run: the finished one leaves
+            if (cur != KEY_NONE) {
+                if (writer) {
+                    if (first_run && !last) acc.store(&out_pt[rec0]);
+                    else                    acc.store(&buckets[cur]);
+                }
+                if (first_run && !last) slot0_key = cur;
+                first_run = false;
+            }
+            cur = k;
+            acc = xyzz_dev<FP>::load(&in_pt[r]);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool any = __syncthreads_or(add);
+#else
+        const bool any = add;
+#endif
+        if (any) {
+            xyzz_dev<FP> y;
+            if (add) y = xyzz_dev<FP>::load(&in_pt[r]); else y.set_inf();
+            coop_add<FP>(acc, y, c);                                // (an operand at infinity leaves acc as it is)
+        }
+    }
+    if (!live || !writer) return;
+    if (last) {
+        if (cur != KEY_NONE) acc.store(&buckets[cur]);
+        return;
+    }
+    if (cur == KEY_NONE)      { out_key[rec0] = KEY_NONE; out_key[rec0 + 1] = KEY_NONE; }
+    else if (first_run)       { acc.store(&out_pt[rec0]); out_key[rec0] = cur; out_key[rec0 + 1] = KEY_NONE; }
+    else                      { acc.store(&out_pt[rec0 + 1]); out_key[rec0] = slot0_key; out_key[rec0 + 1] = cur; }
+}
+
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_reduce_runs_coop(xyzz_mem<FP::N>* __restrict__ buckets,
+                        u32* __restrict__ out_key, xyzz_mem<FP::N>* __restrict__ out_pt,
+                        const u32* __restrict__ in_key, const xyzz_mem<FP::N>* __restrict__ in_pt,
+                        unsigned nrec, unsigned F, unsigned nthreads, int last, const u32* __restrict__ skip)
+{
+    if (skip != nullptr && *skip == 0) return;
+    __shared__ coop_lds<FP> ex;
+    coop_ctx<FP> c{&ex, threadIdx.x >> 6, threadIdx.x & 63, 0};
+    reduce_runs_coop_item<FP>(buckets, out_key, out_pt, in_key, in_pt, nrec, F, nthreads, last, blockIdx.x * 64 + c.lane, c);
+}
+
+// the narrow end (<= 64 work items): every remaining level in one launch, as k_reduce_tail
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_reduce_tail_coop(xyzz_mem<FP::N>* __restrict__ buckets, u32* key0, xyzz_mem<FP::N>* pt0, u32* key1, xyzz_mem<FP::N>* pt1,
+                        unsigned nrec, unsigned F, const u32* __restrict__ skip)
+{
+    if (skip != nullptr && *skip == 0) return;
+    __shared__ coop_lds<FP> ex;
+    coop_ctx<FP> c{&ex, threadIdx.x >> 6, threadIdx.x & 63, 0};
+    u32 *ik = key0, *ok = key1; xyzz_mem<FP::N> *ip = pt0, *op = pt1;
+    for (;;) {
+        const unsigned nthreads = (nrec + F - 1) / F;               // <= 64
+        const int last = nthreads == 1;
+        reduce_runs_coop_item<FP>(buckets, ok, op, ik, ip, nrec, F, nthreads, last, c.lane, c);
+        if (last) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __threadfence_block();                                      // (see k_reduce_tail)
+#endif
+        coop_barrier();
+        nrec = 2 * nthreads;
+        u32* tk = ik; ik = ok; ok = tk;
+        xyzz_mem<FP::N>* tp = ip; ip = op; op = tp;
+    }
+}
+
+} // namespace sppark_amd
+
+namespace sppark_amd {
+
+// ---------------------------------------------------------------------------
+// The chunked bucket-sum levels (msm_kernels.hpp bucket_level1_item / bucket_levelN_item) for grids of at most one
+// work-group of four waves per CU (<= COOP_LEVEL_MAX work items: MSMs of <= 2^16 points, and the last chunked level of
+// larger ones): the same running sums, every addition and doubling by four waves.  64 work items per work-group.
+// ---------------------------------------------------------------------------
+static constexpr unsigned COOP_LEVEL_MAX = 16384;
+
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_bucket_level1_coop(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __restrict__ Wt,
+                          const xyzz_mem<FP::N>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins,
+                          const u32* __restrict__ off)
+{
+    __shared__ coop_lds<FP> ex;
+    coop_ctx<FP> c{&ex, threadIdx.x >> 6, threadIdx.x & 63, 0};
+    const unsigned nchunks = NB / K;
+    const size_t id = (size_t)blockIdx.x * 64 + c.lane;
+    const bool live = id < (size_t)nwins * nchunks;
+    const unsigned w = live ? (unsigned)(id / nchunks) : 0, u = live ? (unsigned)(id % nchunks) : 0;
+    const xyzz_mem<FP::N>* row = buckets + (size_t)w * NB + (size_t)u * K;
+    const u32* o = off ? off + (size_t)w * (NB + 1) + (size_t)u * K : nullptr;
+    xyzz_dev<FP> acc, ret;
+    if (live) acc = bucket_load<FP>(row, o, K - 1); else acc.set_inf();
+    ret = acc;
+    #pragma unroll 1
+    for (unsigned j = K - 1; j--;) {
+        xyzz_dev<FP> y;
+        if (live) y = bucket_load<FP>(row, o, j); else y.set_inf();
+        coop_add<FP>(acc, y, c);
+        coop_add<FP>(ret, acc, c);
+    }
+    if (live && c.role == 0) { acc.store(&A[id]); ret.store(&Wt[id]); }
+}
+
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_bucket_levelN_coop(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restrict__ Wt2,
+                          const xyzz_mem<FP::N>* __restrict__ A1, const xyzz_mem<FP::N>* __restrict__ Wt1,
+                          unsigned nitems, unsigned K, unsigned lgG, unsigned nwins)
+{
+    __shared__ coop_lds<FP> ex;
+    coop_ctx<FP> c{&ex, threadIdx.x >> 6, threadIdx.x & 63, 0};
+    const unsigned nchunks = nitems / K;
+    const size_t id = (size_t)blockIdx.x * 64 + c.lane;
+    const bool live = id < (size_t)nwins * nchunks;
+    const unsigned w = live ? (unsigned)(id / nchunks) : 0, u = live ? (unsigned)(id % nchunks) : 0;
+    const size_t base = (size_t)w * nitems + (size_t)u * K;
+    xyzz_dev<FP> acc, r, sw, y;
+    acc.set_inf(); r.set_inf();
+    if (live) sw = xyzz_dev<FP>::load(&Wt1[base]); else sw.set_inf();
+    #pragma unroll 1
+    for (unsigned j = K - 1; j >= 1; j--) {
+        if (live) y = xyzz_dev<FP>::load(&A1[base + j]); else y.set_inf();
+        coop_add<FP>(acc, y, c);
+        coop_add<FP>(r, acc, c);
+        if (live) y = xyzz_dev<FP>::load(&Wt1[base + j]); else y.set_inf();
+        coop_add<FP>(sw, y, c);
+    }
+    if (live) y = xyzz_dev<FP>::load(&A1[base]); else y.set_inf();
+    coop_add<FP>(acc, y, c);
+    #pragma unroll 1
+    for (unsigned k = 0; k < lgG; k++) coop_dbl<FP>(r, c);
+    coop_add<FP>(sw, r, c);
+    if (live && c.role == 0) { acc.store(&A2[id]); sw.store(&Wt2[id]); }
+}
+
+} // namespace sppark_amd

@@ -30,6 +30,7 @@
 // and the preloaded-points constructor :351-388).
 #pragma once
 #include "msm_kernels.hpp"
+#include "msm_coop_kernels.hpp"
 #include "msm_plan.hpp"
 #include "../ec/jacobian_host.hpp"
 #include "../util/runtime.hpp"
@@ -586,8 +587,27 @@ private:
                 HIP_OK(hipGetLastError());
                 ik = keyC; skip = flag;
             }
+            bool coop_tree = false;
+            if constexpr (MONTX) coop_tree = tune.join != 4 && tune.join != 2;
             for (;;) {
                 unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);
+                if constexpr (MONTX) {
+                    // from one work-group per CU on: four waves per addition (msm_coop_kernels.hpp)
+                    if (coop_tree && nthreads <= 64) {
+                        hipLaunchKernelGGL(k_reduce_tail_coop<fp_d>, dim3(1), dim3(COOP_NT), 0, stream,
+                                           buckets, ik, ip, ok, op, (unsigned)nrec, p.F, skip);
+                        HIP_OK(hipGetLastError());
+                        break;
+                    }
+                    if (coop_tree && nthreads <= COOP_TREE_MAX) {
+                        hipLaunchKernelGGL(k_reduce_runs_coop<fp_d>, dim3((nthreads + 63) / 64), dim3(COOP_NT), 0, stream,
+                                           buckets, ok, op, ik, ip, (unsigned)nrec, p.F, nthreads, 0, skip);
+                        HIP_OK(hipGetLastError());
+                        nrec = (size_t)2 * nthreads;
+                        std::swap(ik, ok); std::swap(ip, op);
+                        continue;
+                    }
+                }
                 if (nthreads <= REDUCE_TAIL_NT && tune.join != 2) {     // the narrow end: every remaining level in one launch
                     // (the level kernels write into the OTHER buffer pair; here the pairs alternate from |ik| on)
                     hipLaunchKernelGGL(k_reduce_tail<fp_d>, dim3(1), dim3(REDUCE_TAIL_NT), 0, stream,
@@ -617,8 +637,12 @@ private:
             bool lat = false;
             if constexpr (MONTX) lat = nthr <= LAT_LANES && tune.join != 3;
             if constexpr (MONTX) {
-                if (lat) hipLaunchKernelGGL(k_bucket_level1_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                                            A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
+                // (at most one work-group of four waves per CU: four waves per operation, msm_coop_kernels.hpp)
+                if (lat && nthr <= COOP_LEVEL_MAX && tune.join != 4)
+                    hipLaunchKernelGGL(k_bucket_level1_coop<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(COOP_NT), 0, stream,
+                                       A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
+                else if (lat) hipLaunchKernelGGL(k_bucket_level1_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                                 A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
             }
             if (!lat) hipLaunchKernelGGL(k_bucket_level1<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                                          A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
@@ -630,14 +654,30 @@ private:
                 if (nitems <= (tune.top ? tune.top : BUCKET_TOP_MAX) && nitems >= 32 && (nitems & (nitems - 1)) == 0
                     && (size_t)p.NB / p.K1 >= 32) {
                     const unsigned m = lg2_floor(nitems);
-                    const size_t img = (size_t)BUCKET_TOP_NT * sizeof(bucket_t);
-                    if (img > 65536)
-                        lds_attr((const void*)k_bucket_top_bits<fp_d>, img);
-                    hipLaunchKernelGGL(k_bucket_top_bits<fp_d>, dim3(m + 1, p.nwins), dim3(BUCKET_TOP_NT), img, stream,
-                                       oa, ia, iw, nitems, m, lgG);
-                    HIP_OK(hipGetLastError());
-                    hipLaunchKernelGGL(k_bucket_top_sum<fp_d>, dim3(p.nwins), dim3(32), 32 * sizeof(bucket_t), stream, ow, oa, m);
-                    HIP_OK(hipGetLastError());
+                    bool coop = false;
+                    if constexpr (MONTX) coop = tune.join != 4;     // (4: the one-wave-per-operation kernels, A/B switch)
+                    if constexpr (MONTX) {
+                        if (coop) {
+                            // the tree and the doubling chains by four waves per operation (msm_coop_kernels.hpp)
+                            const size_t lds = top_bits_coop_lds(fp_d::N);
+                            if (lds > 65536) lds_attr((const void*)k_bucket_top_bits_coop<fp_d>, lds);
+                            hipLaunchKernelGGL(k_bucket_top_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), lds, stream,
+                                               oa, ia, iw, nitems, m, lgG);
+                            HIP_OK(hipGetLastError());
+                            hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m);
+                            HIP_OK(hipGetLastError());
+                        }
+                    }
+                    if (!coop) {
+                        const size_t img = (size_t)BUCKET_TOP_NT * sizeof(bucket_t);
+                        if (img > 65536)
+                            lds_attr((const void*)k_bucket_top_bits<fp_d>, img);
+                        hipLaunchKernelGGL(k_bucket_top_bits<fp_d>, dim3(m + 1, p.nwins), dim3(BUCKET_TOP_NT), img, stream,
+                                           oa, ia, iw, nitems, m, lgG);
+                        HIP_OK(hipGetLastError());
+                        hipLaunchKernelGGL(k_bucket_top_sum<fp_d>, dim3(p.nwins), dim3(32), 32 * sizeof(bucket_t), stream, ow, oa, m);
+                        HIP_OK(hipGetLastError());
+                    }
                     std::swap(iw, ow);
                     break;
                 }
@@ -646,8 +686,11 @@ private:
                 lat = false;
                 if constexpr (MONTX) lat = nthr <= LAT_LANES && tune.join != 3;
                 if constexpr (MONTX) {
-                    if (lat) hipLaunchKernelGGL(k_bucket_levelN_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
-                                                oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                    if (lat && nthr <= COOP_LEVEL_MAX && tune.join != 4)
+                        hipLaunchKernelGGL(k_bucket_levelN_coop<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(COOP_NT), 0, stream,
+                                           oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                    else if (lat) hipLaunchKernelGGL(k_bucket_levelN_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                                     oa, ow, ia, iw, nitems, K, lgG, p.nwins);
                 }
                 if (!lat) hipLaunchKernelGGL(k_bucket_levelN<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                                              oa, ow, ia, iw, nitems, K, lgG, p.nwins);

@@ -25,7 +25,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
     unsigned groups = 0;                // window groups (1 = everything on one stream)
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
-    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels (A/B switches)
+    unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)

@@ -189,6 +189,16 @@ def test_bucket_point_ops_bit_exact_with_wire_class(oracle, libs):
         ffi.check(L, L.sppark_devtest_xyzz_op(op, P(ref), P(xa), ptr, n))
         ffi.check(L, L.sppark_devtest_bucket_xyzz_op(op, P(got), P(xa), ptr, n))
         assert (got == ref).all(), op
+    # the cooperative forms (ec/xyzz_coop.hpp: four waves per 64 operations), two operations in a row:
+    # (a + b) + b against two serial additions, 2(2a) against two serial doublings; n is not a multiple of 64
+    xb[5] = 0                                                # an operand at infinity on the right as well
+    r1 = np.zeros_like(xa); r2 = np.zeros_like(xa); got = np.zeros_like(xa)
+    ffi.check(L, L.sppark_devtest_xyzz_op(0, P(r1), P(xa), P(xb), n)); ffi.check(L, L.sppark_devtest_xyzz_op(0, P(r2), P(r1), P(xb), n))
+    ffi.check(L, L.sppark_devtest_bucket_xyzz_op(4, P(got), P(xa), P(xb), n))
+    assert (got == r2).all()
+    ffi.check(L, L.sppark_devtest_xyzz_op(3, P(r1), P(xa), 0, n)); ffi.check(L, L.sppark_devtest_xyzz_op(3, P(r2), P(r1), 0, n))
+    ffi.check(L, L.sppark_devtest_bucket_xyzz_op(5, P(got), P(xa), 0, n))
+    assert (got == r2).all()
 
 
 @pytest.mark.parametrize("curve,name", CURVES)

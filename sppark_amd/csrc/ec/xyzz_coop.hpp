@@ -29,10 +29,28 @@ namespace sppark_amd {
 // level's reads) of four slots of NL x 64 words
 template<class F> struct coop_lds { u32 w[2][4][F::NL][64]; };
 
+// Work-group barrier / barrier with an OR-vote.  Host emulation (tests/emu/emu_coop.cpp) runs a work-group as 256 host
+// threads and supplies the two hooks.
+#if defined(SPPARK_HOST_EMULATION)
+extern "C" void sppark_emu_barrier();
+extern "C" int sppark_emu_barrier_or(int);
+#endif
 SPPARK_DEVFN void coop_barrier()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __syncthreads();
+#elif defined(SPPARK_HOST_EMULATION)
+    sppark_emu_barrier();
+#endif
+}
+SPPARK_DEVFN bool coop_any(bool p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __syncthreads_or(p) != 0;
+#elif defined(SPPARK_HOST_EMULATION)
+    return sppark_emu_barrier_or(p) != 0;
+#else
+    return p;
 #endif
 }
 

@@ -150,12 +150,7 @@ SPPARK_DEVFN void reduce_runs_coop_item(xyzz_mem<FP::N>* buckets, u32* out_key, 
             cur = k;
             acc = xyzz_dev<FP>::load(&in_pt[r]);
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        const bool any = __syncthreads_or(add);
-#else
-        const bool any = add;
-#endif
-        if (any) {
+        if (coop_any(add)) {
             xyzz_dev<FP> y;
             if (add) y = xyzz_dev<FP>::load(&in_pt[r]); else y.set_inf();
             coop_add<FP>(acc, y, c);                                // (an operand at infinity leaves acc as it is)

@@ -281,3 +281,95 @@ def test_g2_bucket_invariant_on_host(oracle, curve, feature):
                 assert all(v < (1 << LB) for v in l[:-1]), ("limbs not normalised", step, coord, comp)
                 val = sum(v << (LB * j) for j, v in enumerate(l))
                 assert val < bounds[coord] * p, ("bound", step, coord, comp, val // p)
+
+
+def _emu_coop(feature):
+    so = os.path.join(EMU, "libemu_coop_%s.so" % feature)
+    src = os.path.join(EMU, "emu_coop.cpp")
+    csrc = os.path.join(os.path.dirname(HERE), "sppark_amd", "csrc")
+    newest = max(os.stat(os.path.join(r, f)).st_mtime for r, _, fs in os.walk(csrc) for f in fs)
+    newest = max(newest, os.stat(src).st_mtime)
+    if not os.path.exists(so) or os.stat(so).st_mtime < newest:
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                               "-DFEATURE_" + feature, "-o", so, src])
+    L = ctypes.CDLL(so)
+    vp, sz, ci, cu = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint
+    L.emu_coop_ops.argtypes = [ci, vp, vp, vp, sz]
+    L.emu_coop_tree.argtypes = [vp, vp, cu]
+    L.emu_coop_reduce.argtypes = [vp, vp, cu, cu, ci, cu, vp, vp, vp, vp, vp, vp]
+    L.emu_coop_from_std.argtypes = [vp, vp, sz]
+    L.emu_coop_to_std.argtypes = [vp, vp, sz]
+    L.emu_coop_record_words.restype = cu
+    L.emu_coop_points_differ.argtypes = [vp, vp, sz]
+    return L
+
+
+@pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])
+def test_cooperative_point_ops_on_host(oracle, curve, feature):
+    """ec/xyzz_coop.hpp and the cooperative record walk / tree of msm/msm_coop_kernels.hpp with a work-group emulated by
+    256 host threads (tests/emu/emu_coop.cpp): two cooperative additions / doublings in a row against the serial
+    formulas AND against the 32-bit-limb wire class, operands at infinity, equal operands (the doubling inside an
+    addition), a count that is not a multiple of 64; the pairwise tree; one level of the record tree against the
+    one-thread-per-item walk on records with runs, gaps and a run that crosses work items."""
+    O = oracle
+    L = _emu_coop(feature); W = _emu(feature)
+    fb, n = O.FP_BYTES[curve], 96
+    ofield = O.FIELD_BLS_FP if curve == 0 else O.FIELD_BN_FP
+    one = O.field_op(ofield, 4, O.int_to_limbs(1, fb)).view(np.uint8)
+    A = O.g1_gen_points(curve, n, 21)
+    xa = np.zeros((n, 4 * fb), dtype=np.uint8); xa[:, :2 * fb] = A; xa[:, 2 * fb:3 * fb] = one; xa[:, 3 * fb:] = one
+    tmp = np.zeros_like(xa); xb = np.zeros_like(xa)
+    W.emu_xyzz_op(1, P(tmp), P(xa), P(O.g1_gen_points(curve, n, 22)), n); xa = tmp.copy()     # ZZ, ZZZ != 1
+    W.emu_xyzz_op(1, P(xb), P(xa), P(O.g1_gen_points(curve, n, 23)), n)
+    xb[0] = xa[0]; xa[3] = 0; xb[5] = 0; xa[7] = 0; xb[7] = 0
+    words = int(L.emu_coop_record_words())
+    ia = np.zeros((n, words), dtype=np.uint32); ib = np.zeros_like(ia)
+    L.emu_coop_from_std(P(ia), P(xa), n); L.emu_coop_from_std(P(ib), P(xb), n)
+
+    def std(rec):
+        out = np.zeros((rec.shape[0], 4 * fb), dtype=np.uint8)
+        L.emu_coop_to_std(P(out), P(np.ascontiguousarray(rec)), rec.shape[0])
+        return out
+    r1 = np.zeros_like(xa); r2 = np.zeros_like(xa)
+    for coop_op, serial_op, wire_op, operand in ((0, 2, 0, xb), (1, 3, 3, None)):
+        got = np.zeros_like(ia); ser = np.zeros_like(ia)
+        L.emu_coop_ops(coop_op, P(got), P(ia), P(ib), n); L.emu_coop_ops(serial_op, P(ser), P(ia), P(ib), n)
+        W.emu_xyzz_op(wire_op, P(r1), P(xa), P(operand) if operand is not None else None, n)
+        W.emu_xyzz_op(wire_op, P(r2), P(r1), P(operand) if operand is not None else None, n)
+        assert (std(got) == std(ser)).all() and (std(got) == r2).all(), coop_op
+    # the tree: a power-of-two count of points, some at infinity
+    pts = np.concatenate([ia, ib])[:256] if 2 * n >= 256 else None
+    if pts is None:
+        pts = np.concatenate([ia, ib, ia])[:256]
+    pts = np.ascontiguousarray(pts)
+    for count in (2, 64, 256):
+        out = np.zeros((2, words), dtype=np.uint32)
+        L.emu_coop_tree(P(out), P(pts), count)
+        assert L.emu_coop_points_differ(P(out[:1].copy()), P(out[1:].copy()), 1) == 0, count    # (projective: another order of summation)
+    # one level of the record tree: runs of 1..9 records with one key, NONE gaps, fan-in 4 and 8, last level too
+    NONE = 0xffffffff
+    rng = np.random.default_rng(5)
+    keys = []
+    k = 0
+    while len(keys) < 700:
+        run = int(rng.integers(1, 10))
+        keys += [k] * run
+        if rng.random() < 0.4:
+            keys += [NONE] * int(rng.integers(1, 3))
+        k += 1
+    keys = np.array(keys[:700], dtype=np.uint32)
+    nb = int(keys[keys != NONE].max()) + 1
+    recs = np.ascontiguousarray(np.concatenate([ia, ib] * 4)[:700])
+    for fan, nrec, last in ((4, 700, 0), (8, 700, 0), (4, 4, 1), (8, 7, 1)):
+        nthreads = (nrec + fan - 1) // fan
+        res = []
+        for _ in range(2):
+            res.append([np.zeros((nb, words), dtype=np.uint32), np.full(2 * nthreads, 0xabcdef01, dtype=np.uint32), np.zeros((2 * nthreads, words), dtype=np.uint32)])
+        L.emu_coop_reduce(P(keys), P(recs), nrec, fan, last, nb, P(res[0][0]), P(res[0][1]), P(res[0][2]), P(res[1][0]), P(res[1][1]), P(res[1][2]))
+        assert (res[0][1] == res[1][1]).all(), (fan, nrec, "keys")
+        # (same order of additions in both walks: the records agree coordinate by coordinate)
+        assert (std(res[0][0]) == std(res[1][0])).all(), (fan, nrec, "buckets")
+        live = res[0][1] != NONE if not last else np.zeros(2 * nthreads, dtype=bool)
+        assert (std(res[0][2][live]) == std(res[1][2][live])).all(), (fan, nrec, "records")

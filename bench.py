@@ -502,9 +502,9 @@ def main():
         nwins = plan["windows"]
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the timed run, so the
         # value is a CONSTANT read from the committed rocprofv3 --pmc passes of this same workload
-        # (profiles/r03_pmc_traffic.json, else r02 / r01), not an in-run measurement; null for any other workload.
+        # (profiles/r04_pmc_traffic.json, else r03 / r02 / r01), not an in-run measurement; null for any other workload.
         traffic, traffic_note = None, ""
-        for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     pmc = json.load(f)

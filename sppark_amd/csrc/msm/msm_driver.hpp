@@ -59,14 +59,10 @@ public:
     static_assert(INTERNAL || sizeof(FH) == 4 * FD::N, "host and device coordinate fields must share the wire image");
     static constexpr size_t SCALAR_BYTES = sizeof(fr_d);
     static constexpr unsigned MAX_WINS = 128;
-    static constexpr size_t LAT_LANES_DEFAULT = 65536;      // one wave per SIMD on 256 CUs
-    // (SPPARK_MSM_LAT_LANES: experiment knob -- the bucket-sum levels up to this many work items run the one-wave-per-SIMD,
-    // paired-product kernels)
-    static size_t lat_lanes()
-    {
-        static const size_t v = [] { const char* e = getenv("SPPARK_MSM_LAT_LANES"); return e ? (size_t)strtoull(e, nullptr, 0) : LAT_LANES_DEFAULT; }();
-        return v;
-    }
+    // one wave per SIMD on 256 CUs: bucket-sum grids up to this size run the paired-product one-wave kernels.  (Larger,
+    // work-bound grids are faster with the two-wave kernels: forcing the one-wave ones everywhere costs the tail of a
+    // 2^26-point MSM 2.0 ms and 0.5 ms at 2^24, profiles/r04_msm_lat_lanes_negative.log.)
+    static constexpr size_t LAT_LANES = 65536;
     static constexpr size_t FIXED_BASE_MIN = (size_t)1 << 23;      // points from which set_points_fixed_base builds tables by itself
 
 private:
@@ -642,7 +638,7 @@ private:
             // the _lat kernels (no register cap, products in pairs); larger ones are work: two waves per SIMD
             const u32* offp = multi ? (const u32*)nullptr : (const u32*)(blob + l.off[0]);
             bool lat = false;
-            if constexpr (MONTX) lat = nthr <= lat_lanes() && tune.join != 3;
+            if constexpr (MONTX) lat = nthr <= LAT_LANES && tune.join != 3;
             if constexpr (MONTX) {
                 // (at most one work-group of four waves per CU: four waves per operation, msm_coop_kernels.hpp)
                 if (lat && nthr <= COOP_LEVEL_MAX && tune.join != 4)
@@ -691,7 +687,7 @@ private:
                 unsigned K = std::min(p.K, nitems);
                 nthr = (size_t)p.nwins * (nitems / K);
                 lat = false;
-                if constexpr (MONTX) lat = nthr <= lat_lanes() && tune.join != 3;
+                if constexpr (MONTX) lat = nthr <= LAT_LANES && tune.join != 3;
                 if constexpr (MONTX) {
                     if (lat && nthr <= COOP_LEVEL_MAX && tune.join != 4)
                         hipLaunchKernelGGL(k_bucket_levelN_coop<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(COOP_NT), 0, stream,

@@ -87,7 +87,11 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // fan-in of the record tree (< 3 would never shrink the list): 4 up to 2^20 points, where the buckets are longer
     // than the join's walk and the tree does the work -- one addition per work item and level instead of three
     // (above 2^18 the join leaves the tree nothing to do and every level is an empty launch of ~6 us: fewer, wider ones)
-    p.F = std::max(4u, t.F ? t.F : (lg <= 18 ? 4u : 8u));
+    // (round 4: 16 wherever k_join_runs runs first -- the driver's condition n / NB <= 4 L -- : the tree then sees only the
+    // records of long segments, with uniform scalars none at all, and every level it does not have is an empty launch of
+    // ~6 us saved: ten levels become four at 2^18 points)
+    const bool joined = t.join != 1 && (size_t)p.n / p.NB <= (size_t)4 * p.L;
+    p.F = std::max(4u, t.F ? t.F : (joined ? 16u : 4u));
     p.K = t.K ? t.K : (lg <= 22 ? 4 : 8);
     p.K = std::min(p.K, p.NB);
     // first level: 16 buckets per work item once a window has >= 2^21 of them (2^26 points: tail 11.35 -> 11.03 ms)

@@ -1,7 +1,7 @@
 """profiles/rNN_pmc_traffic.json from the two rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1
 --no-cpu-baseline --no-ntt --no-extras`: FETCH_SIZE / WRITE_SIZE of k_accumulate per launch, with the in-run
 calibration of the counters on kernels with known byte counts (MI355X_MICROARCH.md, HBM section).
-    python tools/make_pmc_traffic.py <fetch.db> <write.db> <lg> > profiles/r03_pmc_traffic.json"""
+    python tools/make_pmc_traffic.py <fetch.db> <write.db> <lg> > profiles/r04_pmc_traffic.json"""
 import json
 import sqlite3
 import sys
@@ -37,7 +37,7 @@ out = {
     "fetch_correction": 2.0, "write_correction": 1.0,
     "fetch_bytes": f_kib * 1024 * 2.0, "write_bytes": w_kib * 1024, "raw_fetch_bytes": f_kib * 1024,
     "avg_kernel_us_under_pmc": f_us, "dispatches_averaged": calls,
-    "collection": "rocprofv3 --pmc FETCH_SIZE and rocprofv3 --pmc WRITE_SIZE in separate passes, no trace domains (tools/jobs/r3_evidence.sh)",
+    "collection": "rocprofv3 --pmc FETCH_SIZE and rocprofv3 --pmc WRITE_SIZE in separate passes, no trace domains (tools/jobs/r4_evidence.sh)",
     "calibration_in_the_same_passes": {
         "k_breakdown": {"reads_KiB": n * 32 / 1024, "FETCH_SIZE_KiB": bd_f, "ratio": bd_f / (n * 32 / 1024) if bd_f else None,
                         "writes_KiB": (nwins or 0) * n * 4 / 1024, "WRITE_SIZE_KiB": bd_w},

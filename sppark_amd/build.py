@@ -130,9 +130,9 @@ def build(only=None, force=False, verbose=True, jobs=None):
         links[n] = objs
     # longest translation units first (measured seconds, BLS12-381 / alt_bn128 roughly 2:1):
     # with 8 cores the makespan is then bounded by total work, not by a late long job
-    cost = {"msm/k_bucketN.hip": 85, "msm/k_bucket_lat.hip": 60, "msm/k_bucketN.hip:SPPARK_G2": 75, "msm/k_accumulate.hip:SPPARK_G2": 70,
+    cost = {"msm/k_bucketN.hip": 85, "msm/k_bucket_lat.hip": 95, "msm/k_bucketN.hip:SPPARK_G2": 75, "msm/k_accumulate.hip:SPPARK_G2": 70,
             "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=0": 68, "ntt/k_ntt_pass.hip:SPPARK_NTT_DIF=1": 57,
-            "msm/k_reduce.hip:SPPARK_G2": 54, "msm/k_bucket1.hip:SPPARK_G2": 53, "api/devtest_api.hip": 45,
+            "msm/k_reduce.hip:SPPARK_G2": 54, "msm/k_bucket1.hip:SPPARK_G2": 53, "api/devtest_api.hip": 100,
             "msm/k_bucket1.hip": 35, "api/msm_api.hip": 28, "msm/k_accumulate.hip": 25, "msm/k_reduce.hip": 24}
     todo.sort(key=lambda job: -cost.get(job[0], 5) * (2 if "BLS12" in job[2] else 1))
     if todo:

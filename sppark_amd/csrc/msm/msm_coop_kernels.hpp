@@ -213,6 +213,7 @@ namespace sppark_amd {
 // work-group of four waves per CU (<= COOP_LEVEL_MAX work items: MSMs of <= 2^16 points, and the last chunked level of
 // larger ones): the same running sums, every addition and doubling by four waves.  64 work items per work-group.
 // ---------------------------------------------------------------------------
+// (24576 or 32768 -- 1.5 or 2 rounds of work-groups -- change nothing measurable: profiles/r04_msm_coop_level_max.log)
 static constexpr unsigned COOP_LEVEL_MAX = 16384;
 
 template<class FP>

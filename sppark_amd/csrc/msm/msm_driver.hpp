@@ -214,6 +214,14 @@ public:
     explicit msm_t(int device_id = -1, hipStream_t s = nullptr)
         : gpu(&select_gpu(device_id)), stream(s), own_stream(false)
     {
+        {
+            // lanes of k_accumulate the device runs at once -- at most two waves per SIMD (two 256-lane work-groups per CU):
+            // a third resident wave adds no throughput -- : the plan fits the accumulation's grid to whole rounds of them
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_accumulate<fp_d, false>, 256, 0) == hipSuccess && nb > 0)
+                tune.resident_lanes = (size_t)std::min(nb, 2) * 256 * (size_t)gpu->prop.multiProcessorCount;
+            else (void)hipGetLastError();
+        }
         if (stream == nullptr) {
             // a non-blocking private stream (a blocking one pays an implicit legacy-stream check on
             // every launch: +36 ms on a 2^26 MSM); join_default_stream() orders each call after the

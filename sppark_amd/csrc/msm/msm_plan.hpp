@@ -27,6 +27,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
+    size_t resident_lanes = 0;          // lanes of k_accumulate the device holds at once (set by the driver from the occupancy query; 0 = unknown)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
 };
@@ -45,8 +46,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // much smaller windows (more, shorter windows in parallel) win
     // (round 3, with the sort split following the size and the cheaper tail: 2^17..2^19 moved from 8 / 8 / 11 to
     // 14 / 15 / 16 bits -- 2^18: 2.15 -> 1.82 ms, 2^19: 3.10 -> 2.42 ms, profiles/r03_msm_small_grid2.log)
+    // (round 4, with the cooperative tail: 8 bits at 2^15 too -- 0.85 -> 0.73 ms, profiles/r04_msm_small_grid.log)
     unsigned autow = lg >= 22 ? std::min(22u, lg - 4) : lg >= 19 ? 16u : lg == 18 ? 15u : lg == 17 ? 14u
-                   : lg == 16 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
+                   : lg >= 15 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
     p.wbits = t.wbits ? t.wbits : autow;
     p.wbits = std::min(24u, std::max(2u, p.wbits));
     p.nwins = (scalar_bits - 1) / p.wbits + 1;      // as pippenger.cuh:365
@@ -78,6 +80,36 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // Below 2^22 points: 8..64 entries, twice what round 2 used (2^14..2^18: -5..-9 %, profiles/r03_msm_small_grid.log)
     unsigned L = t.L ? t.L : lg >= 22 ? (lg >= 25 ? 256u : 128u)
                            : 1u << lg2_floor(std::min<size_t>(64, std::max<size_t>(8, entries / 131072)));
+    // Round 4: FIT THE GRID TO THE DEVICE.  k_accumulate's lanes all run the same L additions, so its time is
+    // (rounds of resident waves) x L: 17 windows x 2^18 points / 32 = 139 264 lanes are 1.06 x the 131 072 that two waves
+    // per SIMD hold -- two rounds, the second one for 6 % of the work (0.96 ms where 16 windows take 0.70,
+    // profiles/r04_msm_small_grid.log).  With R = resident_lanes known, a grid that needs MORE than one round gets the
+    // smallest run length that fits k rounds exactly, k = the rounds of the power-of-two choice above or one less
+    // (fewer, longer runs also leave fewer records) -- if that saves at least 3 % of rounds x L; a grid that fills its
+    // rounds already (2^16, 2^19, 2^20, 2^23 ... 2^26 points) keeps its power of two.  2^17: 19 x 8192 lanes at L = 16
+    // (1.19 rounds) -> L = 20, one round: 1.41 -> 1.24 ms; 2^18: L = 32 -> 35: 1.95 -> 1.70 ms; 2^22: 128 -> 161 (three
+    // rounds instead of 3.75): 12.1 -> 11.7 ms (profiles/r04_msm_fit_rounds.log).  Not applied to a grid below one round
+    // (shorter runs there only add records), and R counts at most two waves per SIMD: a third one (ten-limb fields)
+    // adds no throughput (alt_bn128 at 2^20: 1.33 rounds of three waves at L = 64 run faster than one round at L = 86).
+    // (In WORK-GROUPS: the grid is ceil(chunks / 256) groups of 256 lanes per window, and the groups, not the lanes, are
+    // what must fit -- 300 000 points at L = 39 are 130 781 lanes but 17 x 31 = 527 groups for 512 places: 1.17 ms
+    // instead of 0.97 at L = 32; at L = 40 they are 510.)
+    if (!t.L && t.resident_lanes >= 256 && p.n >= 4096) {
+        const size_t R = t.resident_lanes / 256, T0 = (size_t)p.nwins * (((p.n + L - 1) / L + 255) / 256);
+        const size_t k_hi = (T0 + R - 1) / R, k_lo = k_hi > 1 ? k_hi - 1 : 1;
+        if (k_hi >= 2 && k_hi <= 64) {
+            size_t best_cost = 0; unsigned best_L = L;
+            for (size_t k = k_lo; k <= k_hi; k++) {
+                const size_t q = (k * R / p.nwins) * 256;           // chunks per window whose work-groups fit k rounds
+                if (q == 0) continue;
+                const size_t Lk = (p.n + q - 1) / q;
+                if (Lk < 4 || Lk > 1024) continue;
+                const size_t cost = k * Lk * 100 + (k - k_lo) * 3 * Lk;      // prefer the longer runs unless the shorter ones save > 3 %
+                if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_L = (unsigned)Lk; }
+            }
+            if (best_cost && best_cost <= k_hi * (size_t)L * 97) L = best_L;
+        }
+    }
     p.L = L;
     p.chunks_per_win = (p.n + L - 1) / L;
     // point slabs of the level-A histogram / scatter: >= 8 from 2^14 points on (2^18: digits + sort 0.31 -> 0.17 ms with 8)

@@ -18,6 +18,13 @@ extern "C" void emu_make_plan(size_t npoints, unsigned scalar_bits, unsigned wbi
     t.wbits = wbits; t.L = L; t.F = F; t.K = K; t.nslabs = nslabs; t.LB = LB; t.groups = groups; t.K1 = K1;
     put(make_plan(npoints, scalar_bits, t), out);
 }
+// the automatic plan as the driver asks for it: with the device's resident k_accumulate lanes known
+extern "C" void emu_make_plan_resident(size_t npoints, unsigned scalar_bits, size_t resident_lanes, unsigned out[18])
+{
+    msm_tunables t;
+    t.resident_lanes = resident_lanes;
+    put(make_plan(npoints, scalar_bits, t), out);
+}
 extern "C" void emu_make_fixed_plan(size_t npoints, unsigned fb_wbits, unsigned fb_nwins, unsigned register_stage, unsigned out[18])
 {
     msm_tunables t;

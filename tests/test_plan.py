@@ -20,6 +20,7 @@ def plan_lib():
     L = ctypes.CDLL(so)
     L.emu_make_plan.argtypes = [ctypes.c_size_t] + [ctypes.c_uint] * 9 + [ctypes.POINTER(ctypes.c_uint)]
     L.emu_make_fixed_plan.argtypes = [ctypes.c_size_t] + [ctypes.c_uint] * 3 + [ctypes.POINTER(ctypes.c_uint)]
+    L.emu_make_plan_resident.argtypes = [ctypes.c_size_t, ctypes.c_uint, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint)]
     return L
 
 
@@ -58,6 +59,35 @@ def test_automatic_plans_over_every_size(plan_lib):
                 assert p["NA"] <= 4096, (n, p)
                 if (1 << 15) <= n <= (1 << 26):                                       # (above 2^26 points the 2^12 partitions outgrow
                     assert n // p["NA"] <= 18432, (n, p)                              # level B's register form: its two-pass form sorts them)
+
+
+def test_run_length_fits_whole_rounds_of_resident_waves(plan_lib):
+    """With the device's resident k_accumulate lanes R known (the driver's occupancy query: 131072 for the 14-limb fields,
+    196608 for the 10-limb ones), the automatic run length makes windows x ceil(n / L) lanes fit k rounds of R exactly:
+    never more rounds x run length than the power-of-two choice, every invariant intact, and the cases that prompted it."""
+    for R in (65536, 131072, 196608):
+        for bits in (255, 254):
+            for lg in range(12, 29):
+                for n in {1 << lg, (1 << lg) + 1, (1 << lg) * 3 // 2 + 7, (1 << lg) - 1, (1 << lg) * 5 // 4}:
+                    out = (ctypes.c_uint * 18)()
+                    plan_lib.emu_make_plan_resident(n, bits, R, out)
+                    p = dict(zip(KEYS, out))
+                    _check(p, n, bits)
+                    q = _plan(plan_lib, n, bits)                                      # without the fit: the power-of-two run length
+                    assert (p["wbits"], p["nwins"], p["NA"], p["K"], p["K1"]) == (q["wbits"], q["nwins"], q["NA"], q["K"], q["K1"])
+                    groups = lambda pl: pl["nwins"] * -(-pl["chunks_per_win"] // 256)  # the launch: ceil(chunks / 256) groups of 256 lanes per window
+                    rounds = lambda pl: -(-groups(pl) // (R // 256))
+                    assert rounds(p) * p["L"] <= rounds(q) * q["L"], (n, R, p, q)
+                    assert 4 <= p["L"] <= 1024
+                    if p["L"] != q["L"]:
+                        assert 2 <= rounds(q) <= 64 and rounds(p) * p["L"] * 100 <= rounds(q) * q["L"] * 97, (n, R, p, q)
+                        assert groups(p) <= rounds(p) * (R // 256), (n, R, p)
+                        if p["L"] > 4:                                                # ... tightly: one entry less per run would not fit
+                            assert p["nwins"] * -(-(-(-n // (p["L"] - 1))) // 256) > rounds(p) * (R // 256), (n, R, p)
+    out = (ctypes.c_uint * 18)()
+    for n, L in ((1 << 17, 20), (1 << 18, 35), (300000, 40), (1 << 22, 161), (1 << 13, 8), (1 << 16, 16), (1 << 20, 64), (1 << 26, 256)):
+        plan_lib.emu_make_plan_resident(n, 255, 131072, out)
+        assert dict(zip(KEYS, out))["L"] == L, (n, dict(zip(KEYS, out)))
 
 
 def test_tuned_plans(plan_lib):

@@ -500,10 +500,15 @@ private:
         HIP_OK(hipGetLastError());
         const unsigned big = tune.big ? tune.big : p.big ? p.big : (1u << 18);
         u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
-        HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
+        // (a window of n entries cannot hold a partition above |big| when n <= big: the list of oversized partitions and its
+        // three kernels -- which would find nothing and return, ~5 us of launch each -- are not even queued: 25 us of every
+        // MSM up to 2^18 points)
+        const bool may_be_big = p.n > big;
+        if (may_be_big) HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
         hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
                            sorted, off, partA, offA, p.n, p.NA, p.LB, sf, big);
         HIP_OK(hipGetLastError());
+        if (!may_be_big) return;
         // oversized partitions (skewed scalars); empty list and immediate return otherwise
         hipLaunchKernelGGL(k_big_find, dim3((p.NA * wn + 255) / 256), dim3(256), 0, ss,
                            nbig, blist, off, offA, p.NA, p.LB, sf, wn, big);

@@ -85,10 +85,10 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // per SIMD hold -- two rounds, the second one for 6 % of the work (0.96 ms where 16 windows take 0.70,
     // profiles/r04_msm_small_grid.log).  With R = resident_lanes known, a grid that needs MORE than one round gets the
     // smallest run length that fits k rounds exactly, k = the rounds of the power-of-two choice above or one less
-    // (fewer, longer runs also leave fewer records) -- if that saves at least 3 % of rounds x L; a grid that fills its
+    // (fewer, longer runs also leave fewer records) -- if that saves at least 8 % of rounds x L; a grid that fills its
     // rounds already (2^16, 2^19, 2^20, 2^23 ... 2^26 points) keeps its power of two.  2^17: 19 x 8192 lanes at L = 16
-    // (1.19 rounds) -> L = 20, one round: 1.41 -> 1.24 ms; 2^18: L = 32 -> 35: 1.95 -> 1.70 ms; 2^22: 128 -> 161 (three
-    // rounds instead of 3.75): 12.1 -> 11.7 ms (profiles/r04_msm_fit_rounds.log).  Not applied to a grid below one round
+    // (1.19 rounds) -> L = 20, one round: 1.41 -> 1.24 ms; 2^18: L = 32 -> 35: 1.95 -> 1.65 ms; 300 000 points: L = 32 -> 40:
+    // 2.02 -> 1.84 ms (profiles/r04_msm_fit_rounds.log).  Not applied to a grid below one round
     // (shorter runs there only add records), and R counts at most two waves per SIMD: a third one (ten-limb fields)
     // adds no throughput (alt_bn128 at 2^20: 1.33 rounds of three waves at L = 64 run faster than one round at L = 86).
     // (In WORK-GROUPS: the grid is ceil(chunks / 256) groups of 256 lanes per window, and the groups, not the lanes, are
@@ -107,7 +107,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
                 const size_t cost = k * Lk * 100 + (k - k_lo) * 3 * Lk;      // prefer the longer runs unless the shorter ones save > 3 %
                 if (best_cost == 0 || cost < best_cost) { best_cost = cost; best_L = (unsigned)Lk; }
             }
-            if (best_cost && best_cost <= k_hi * (size_t)L * 97) L = best_L;
+            // (>= 8 %: the fit assumes full lists -- uniform scalars; with half of the digits zero a fitted L = 161 at 2^22
+            // made the accumulation 13 % SLOWER than L = 128 for a 3 % gain on uniform ones, profiles/r04_msm_skew.log)
+            if (best_cost && best_cost <= k_hi * (size_t)L * 92) L = best_L;
         }
     }
     p.L = L;

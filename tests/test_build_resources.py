@@ -50,7 +50,8 @@ def test_register_budget(obj, needle, max_regs):
 
 @pytest.mark.parametrize("obj", ["bls12_381__msm_k_reduce.hip.o", "bls12_381__msm_k_reduce.hip__SPPARK_G2.o",
                                  "bls12_381__msm_k_bucketN.hip.o", "bls12_381__msm_k_bucketN.hip__SPPARK_G2.o",
-                                 "bls12_381__msm_k_bucket1.hip.o", "bls12_381__msm_k_accumulate.hip.o"])
+                                 "bls12_381__msm_k_bucket1.hip.o", "bls12_381__msm_k_accumulate.hip.o",
+                                 "bls12_381__msm_k_bucket_lat.hip.o", "bn254__msm_k_bucket_lat.hip.o"])      # incl. the cooperative kernels
 def test_point_arithmetic_kernels_are_one_wave_per_simd_groups(obj):
     """The kernels that do point arithmetic are built for work-groups of <= 256 lanes (one wave per SIMD, up to 512
     registers).  A larger `__launch_bounds__` caps the kernel's registers (1024 lanes: 128) -- the 14-limb addition then
@@ -79,3 +80,21 @@ def test_g2_accumulate_scratch_stays_resident(obj, max_regs, max_scratch):
         # (.vgpr_count of a kernel that uses accumulation registers is already the unified total)
         assert int(md.get("vgpr_count") or 0) <= max_regs, (name[:60], md)
         assert int(md.get("private_segment_fixed_size") or 0) <= max_scratch, (name[:60], "scratch", md)
+
+
+def test_cooperative_kernels_fit_one_work_group_per_cu():
+    """The cooperative kernels (msm_coop_kernels.hpp) are work-groups of exactly four waves, one per SIMD: <= 512 registers
+    per lane, and LDS (static + the dynamic image of the top) within the CU's 160 KB.  Their scratch is the frame of the
+    out-of-line serial addition of the exceptional lanes only -- when that call took the operands by reference they lived
+    in scratch on the hot path and every kernel was 25 % slower (profiles/r04_msm_coop_ab.log): bounded here."""
+    meta = _kernels("bls12_381__msm_k_bucket_lat.hip.o")
+    hit = {k: v for k, v in meta.items() if "coop" in k and "vgpr_count" in v}
+    assert len(hit) >= 6, sorted(hit)
+    for name, md in hit.items():
+        assert int(md.get("max_flat_workgroup_size") or 0) == 256, (name[:60], md)
+        # (.vgpr_count of a kernel that uses accumulation registers is already the unified total)
+        assert int(md.get("vgpr_count") or 0) <= 512, (name[:60], md)
+        # static LDS: the exchange area (+ the image of a tree / a level); the top's image of 2^nl points is dynamic and
+        # sized by the driver (top_bits_coop_lds) under the 160 KB of a CU
+        assert int(md.get("group_segment_fixed_size") or 0) <= 40 * 1024, (name[:60], md)
+        assert int(md.get("private_segment_fixed_size") or 0) <= 1280, (name[:60], "scratch", md)

@@ -127,7 +127,7 @@ size_t sppark_ngpus(void);
  * exchange step of 144 bytes per device.  points / scalars: HOST pointers, same formats as
  * mult_pippenger_inf (mont != 0: scalars in Montgomery form); ndev == 0: all devices.
  * The multi-PROCESS variant (one rank per GPU, RCCL all-gather of the partial sums) is
- * sppark_amd/multi_gpu.py. */
+ * sppark_msm_rccl below (native callers) and sppark_amd/multi_gpu.py (torch.distributed). */
 SppError sppark_msm_multi(void *out, const void *points, size_t npoints, const void *scalars,
                           int mont, size_t ffi_affine_sz, unsigned ndev);
 /* General form: nshards independent (points[i], npoints[i], scalars[i]) triples; shard i runs on
@@ -144,6 +144,24 @@ SppError sppark_msm_multi_ms(void *out, const void *points, size_t npoints, cons
 SppError sppark_msm_multi_shards_ms(void *out, const void *const *points, const size_t *npoints,
                                     const void *const *scalars, int mont, size_t ffi_affine_sz,
                                     unsigned nshards, const int *device_ids, float *out_ms);
+
+/* One PROCESS per GPU (north star: "sharded across the GPUs of one node, RCCL partial-sum exchange"): the exchange
+ * step over the CALLER's communicator.  nccl_comm: an ncclComm_t the caller made with ncclCommInitRank (one rank per
+ * process, its device current); stream: a hipStream_t of that device (NULL: the null stream).  Every rank passes its
+ * Jacobian partial sum (host memory; the `out` of any MSM entry point above: 3 field elements, g2 != 0: 3 Fp2
+ * elements); ONE ncclAllGather of that many bytes per rank, then every rank adds the nranks points on its host --
+ * elliptic-curve addition is not an RCCL reduction operator, and N host additions are microseconds.  All ranks
+ * return the same point.  The library does not link RCCL: ncclAllGather / ncclCommCount are looked up in
+ * $SPPARK_RCCL_LIB when set, else in the copy the process already holds (the one that made the communicator), else in
+ * librccl.so.1;
+ * code ENOSYS when there is none.  The reference has no counterpart (one gpu_t per msm_t, msm/pippenger.cuh:328-353). */
+SppError sppark_msm_rccl_sum(void *out, const void *partial, int g2, void *nccl_comm, void *stream);
+/* A rank's whole share: the local G1 MSM over its shard on the calling thread's current device (arguments of
+ * mult_pippenger_inf, plus mont), then the exchange above.  Collective: every rank calls it (npoints == 0 allowed);
+ * a rank whose local MSM fails still contributes the point at infinity so that the others do not hang, and reports
+ * its own error. */
+SppError sppark_msm_rccl(void *out, const void *points, size_t npoints, const void *scalars,
+                         int mont, size_t ffi_affine_sz, void *nccl_comm, void *stream);
 
 typedef struct sppark_msm_ctx sppark_msm_ctx;
 

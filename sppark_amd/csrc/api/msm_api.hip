@@ -57,6 +57,7 @@ extern template __global__ void k_bucket_top_sum<fp2_d>(bucket2_m*, const bucket
 #include "../ff/fp2_host.hpp"
 #include "../msm/msm_driver.hpp"
 #include "common_api.hpp"
+#include "../util/rccl_dyn.hpp"
 #include <chrono>
 #include <map>
 #include <memory>
@@ -207,6 +208,19 @@ static void msm_shards(point_t& out, const void* const* points, const size_t* np
     for (unsigned i = 0; i < nshards; i++) out.add(part[i]);
 }
 
+// the exchange step of the one-process-per-GPU entry points (sppark_msm_rccl_sum below)
+template<class Pt> static void rccl_sum(void* out, const void* partial, void* comm, void* stream)
+{
+    if (!comm || !partial) throw hip_error(EINVAL, "sppark_msm_rccl_sum: null communicator or partial sum");
+    const std::vector<unsigned char> all = rccl_all_gather_host(partial, sizeof(Pt), (ncclComm_t)comm, (hipStream_t)stream);
+    Pt acc; acc.set_inf();
+    for (size_t i = 0; i < all.size() / sizeof(Pt); i++) {
+        Pt p; memcpy(&p, all.data() + i * sizeof(Pt), sizeof(p));
+        acc.add(p);
+    }
+    memcpy(out, &acc, sizeof(acc));
+}
+
 extern "C" {
 
 SPPARK_FFI RustError mult_pippenger_inf(void* out, const void* points, size_t npoints,
@@ -328,6 +342,39 @@ SPPARK_FFI RustError sppark_msm_multi_shards_ms(void* out, const void* const* po
                                                 const void* const* scalars, int mont, size_t ffi_affine_sz,
                                                 unsigned nshards, const int* device_ids, float* out_ms)
 {   return msm_multi_shards_impl(out, points, npoints, scalars, mont, ffi_affine_sz, nshards, device_ids, out_ms);   }
+
+// ---- one PROCESS per GPU: the exchange step over the caller's RCCL communicator ------------------------------
+// (north star: "RCCL exchange"; the reference has no multi-GPU MSM -- one gpu_t per msm_t, msm/pippenger.cuh:328-353.)
+// Elliptic-curve addition is not an RCCL reduction operator, so the exchange is ONE ncclAllGather of the ranks'
+// Jacobian partial sums (144 bytes each for BLS12-381 G1) and every rank adds the nranks points on its host:
+// all ranks return the same point.  RCCL is bound at run time (util/rccl_dyn.hpp).
+SPPARK_FFI RustError sppark_msm_rccl_sum(void* out, const void* partial, int g2, void* nccl_comm, void* stream)
+{
+#ifndef SPPARK_NO_G2
+    memset(out, 0, g2 ? sizeof(point2_t) : sizeof(point_t));
+    return guarded([&] { if (g2) rccl_sum<point2_t>(out, partial, nccl_comm, stream); else rccl_sum<point_t>(out, partial, nccl_comm, stream); });
+#else
+    store_inf(out);
+    return guarded([&] {
+        if (g2) throw hip_error(ENOTSUP, "this curve has no G2");
+        rccl_sum<point_t>(out, partial, nccl_comm, stream);
+    });
+#endif
+}
+// A rank's whole share of a sharded G1 MSM: the local MSM over its shard (the arguments of mult_pippenger_inf, plus
+// |mont|) on the calling thread's current device, then the exchange.  Collective: every rank of |nccl_comm| calls it
+// (a rank without points passes npoints == 0).
+SPPARK_FFI RustError sppark_msm_rccl(void* out, const void* points, size_t npoints, const void* scalars,
+                                     int mont, size_t ffi_affine_sz, void* nccl_comm, void* stream)
+{
+    unsigned char part[sizeof(point_t)];
+    RustError e = one_shot(part, points, npoints, scalars, mont != 0, ffi_affine_sz);
+    // (a rank that failed locally still takes part in the collective with the point at infinity one_shot() left: the
+    // others must not hang in it; this rank reports its own error)
+    RustError x = sppark_msm_rccl_sum(out, part, 0, nccl_comm, stream);
+    if (e.code) { free(x.message); store_inf(out); return e; }
+    return x;
+}
 
 SPPARK_FFI RustError sppark_msm_create(sppark_msm_ctx** ctx, int device_id, void* stream)
 {

@@ -1,0 +1,80 @@
+// RCCL for the one-process-per-GPU exchange step, bound at run time.
+//
+// The product libraries do not LINK librccl: a prover that drives the node from one process (sppark_msm_multi*) never
+// needs it, and a process that already holds a copy -- PyTorch ships its own beside the one under /opt/rocm -- must go
+// on using that one, because a communicator is only valid inside the library instance that made it.  So the caller
+// creates the communicator (ncclCommInitRank in ITS copy), and the three entry points used here are looked up in the
+// library SPPARK_RCCL_LIB names when set, else in the copy that is already mapped (RTLD_NOLOAD), else in librccl.so.1.
+// Types and enum values come from <rccl/rccl.h>; nothing of it is called directly.
+#pragma once
+#include "runtime.hpp"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <cerrno>
+
+namespace sppark_amd {
+
+struct rccl_dyn {
+    decltype(&ncclAllGather)      all_gather = nullptr;
+    decltype(&ncclCommCount)      comm_count = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string origin;
+
+    static const rccl_dyn& get()
+    {
+        static const rccl_dyn api;
+        if (!api.all_gather)
+            throw hip_error(ENOSYS, "RCCL is not available to this process: " + api.origin);
+        return api;
+    }
+    static void ok(ncclResult_t r, const char* what)
+    {
+        if (r != ncclSuccess)
+            throw hip_error(EIO, std::string(what) + " failed: " + get().error_string(r));
+    }
+private:
+    rccl_dyn()
+    {
+        // an explicit choice wins; else a copy that is already in the process; else the system's
+        const char* env = getenv("SPPARK_RCCL_LIB");
+        const char* names[2] = {"librccl.so.1", "librccl.so"};
+        void* h = nullptr;
+        if (env && *env) { h = dlopen(env, RTLD_NOW | RTLD_LOCAL); origin = env; }
+        else
+            for (int pass = 0; pass < 2 && !h; pass++)
+                for (const char* n : names) {
+                    h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                    if (h) { origin = n; break; }
+                }
+        if (!h) { const char* e = dlerror(); origin = e ? e : "librccl.so.1 not found"; return; }
+        all_gather   = reinterpret_cast<decltype(all_gather)>(dlsym(h, "ncclAllGather"));
+        comm_count   = reinterpret_cast<decltype(comm_count)>(dlsym(h, "ncclCommCount"));
+        error_string = reinterpret_cast<decltype(error_string)>(dlsym(h, "ncclGetErrorString"));
+        if (!all_gather || !comm_count || !error_string) { all_gather = nullptr; origin += ": ncclAllGather / ncclCommCount / ncclGetErrorString missing"; }
+    }
+};
+
+// all ranks of |comm| contribute |bytes| of host memory; returns the nranks * bytes of all of them in rank order.
+// ONE collective on |stream|; the device staging comes from the scratch pool.
+inline std::vector<unsigned char> rccl_all_gather_host(const void* mine, size_t bytes, ncclComm_t comm, hipStream_t stream)
+{
+    const rccl_dyn& api = rccl_dyn::get();
+    int nranks = 0;
+    rccl_dyn::ok(api.comm_count(comm, &nranks), "ncclCommCount");
+    if (nranks < 1) throw hip_error(EINVAL, "communicator without ranks");
+    const size_t slot = (bytes + 15) & ~(size_t)15;
+    pooled_scratch buf(slot * (1 + (size_t)nranks));
+    unsigned char* d_mine = (unsigned char*)buf.p, *d_all = d_mine + slot;
+    std::vector<unsigned char> padded(slot, 0), all(slot * nranks);
+    memcpy(padded.data(), mine, bytes);
+    HIP_OK(hipMemcpyAsync(d_mine, padded.data(), slot, hipMemcpyHostToDevice, stream));
+    rccl_dyn::ok(api.all_gather(d_mine, d_all, slot, ncclUint8, comm, stream), "ncclAllGather");
+    HIP_OK(hipMemcpyAsync(all.data(), d_all, slot * nranks, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    buf.done();
+    std::vector<unsigned char> out(bytes * nranks);
+    for (int r = 0; r < nranks; r++) memcpy(out.data() + (size_t)r * bytes, all.data() + (size_t)r * slot, bytes);
+    return out;
+}
+
+} // namespace sppark_amd

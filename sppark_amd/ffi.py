@@ -109,6 +109,10 @@ def load(name):
         L.sppark_msm_multi_shards_ms.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ci, sz, cu,
                                                  ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float)]
         L.sppark_msm_multi_shards_ms.restype = _Error
+        L.sppark_msm_rccl_sum.argtypes = [vp, vp, ci, vp, vp]
+        L.sppark_msm_rccl_sum.restype = _Error
+        L.sppark_msm_rccl.argtypes = [vp, vp, sz, vp, ci, sz, vp, vp]
+        L.sppark_msm_rccl.restype = _Error
         L.sppark_msm_reserve.argtypes = [vp, sz, sz, ci, ci]
         L.sppark_msm_reserve.restype = _Error
         L.sppark_msm_invoke.argtypes = [vp, vp, vp, sz, vp, ci, sz]

@@ -83,6 +83,30 @@ def test_error_out_is_infinity_and_message_owned(libs):
     L.drop_error_message(err.message)
 
 
+def test_rccl_exchange_rejects_a_missing_communicator(libs):
+    """sppark_msm_rccl_sum / sppark_msm_rccl (the one-process-per-GPU exchange): without a communicator the call is an
+    error (EINVAL) with `out` at infinity and an owned message -- it never touches RCCL, which the libraries do not link
+    (bound at run time, csrc/util/rccl_dyn.hpp)."""
+    import errno
+    import subprocess
+    from sppark_amd import ffi
+    for name in ("bls12_381", "pallas"):
+        L = ffi.load(name)
+        fb = 48 if name == "bls12_381" else 32
+        part = np.zeros(3 * fb, dtype=np.uint8)
+        out = np.full(3 * fb, 0xff, dtype=np.uint8)
+        err = L.sppark_msm_rccl_sum(out.ctypes.data, part.ctypes.data, 0, None, None)
+        assert err.code == errno.EINVAL and (out == 0).all() and b"communicator" in ctypes.string_at(err.message)
+        L.drop_error_message(err.message)
+        needed = subprocess.run(["readelf", "-d", libs[name]], capture_output=True, text=True).stdout
+        assert "rccl" not in needed.lower()
+    L = ffi.load("pallas")                                     # a curve without G2
+    out = np.full(96, 0xff, dtype=np.uint8)
+    err = L.sppark_msm_rccl_sum(out.ctypes.data, out.ctypes.data, 1, None, None)
+    assert err.code != 0 and (out == 0).all()
+    L.drop_error_message(err.message)
+
+
 def test_host_point_helpers(libs, oracle):
     """sppark_g1_jacobian_sum / sppark_g1_to_affine are host arithmetic (the
     multi-GPU combine step) and must agree with the oracle."""

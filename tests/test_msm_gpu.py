@@ -938,6 +938,82 @@ def test_msm_multi_device_entry_points(oracle, libs):
     assert (sppark_amd.to_affine(out) == exp).all() and len(ms) == 1 and ms[0] > 0
 
 
+def test_msm_rccl_exchange_single_rank(oracle, libs):
+    """sppark_msm_rccl / sppark_msm_rccl_sum: the native one-process-per-GPU exchange over an RCCL communicator made
+    without torch (ncclGetUniqueId + ncclCommInitRank through ctypes, as a Rust / Go caller would).  One GPU in the pool:
+    a communicator of ONE rank -- the all-gather, the staging and the host sum run, the collective has no peer.
+    G1 from host and device buffers, an empty shard, a G2 partial sum, the error path with the communicator intact."""
+    import torch
+    import sppark_amd
+    from sppark_amd import multi_gpu
+    O = oracle
+    comm = multi_gpu.RcclComm(1, 0, multi_gpu.RcclComm.unique_id())
+    try:
+        n = 7001
+        pts, sc = recipe.msm_inputs(O.BLS12_381, n, 2718, ndistinct=300, flagged=True)
+        exp = O.msm_affine(O.BLS12_381, pts, sc, algo=0, param=8)
+        assert (sppark_amd.to_affine(multi_gpu.msm_rccl(pts, sc, comm, ffi_affine_sz=pts.shape[1])) == exp).all()
+        d_pts, d_sc = torch.from_numpy(pts).cuda(), torch.from_numpy(sc).cuda()
+        torch.cuda.synchronize()
+        assert (sppark_amd.to_affine(multi_gpu.msm_rccl(d_pts, d_sc, comm, ffi_affine_sz=pts.shape[1])) == exp).all()
+        assert (multi_gpu.msm_rccl(pts[:0], sc[:0], comm, ffi_affine_sz=pts.shape[1]) == 0).all()      # a rank without points
+        part = sppark_amd.multi_scalar_mult_arkworks(pts, sc)
+        assert (multi_gpu.rccl_sum(part, comm) == part).all()
+        name2, curve2 = G2[0]
+        p2, s2 = recipe.msm_inputs(curve2, 65, 99, ndistinct=16, flagged=True)
+        part2 = sppark_amd.multi_scalar_mult_fp2_arkworks(p2, s2, name2)
+        assert (sppark_amd.to_affine_g2(multi_gpu.rccl_sum(part2, comm, name2, g2=True), name2) == sppark_amd.to_affine_g2(part2, name2)).all()
+        # a local failure (a stride below two field elements) is reported with `out` at infinity; the collective still ran
+        from sppark_amd import ffi
+        L = ffi.load("bls12_381")
+        out = np.full(144, 0xff, dtype=np.uint8)
+        err = L.sppark_msm_rccl(out.ctypes.data, pts.ctypes.data, n, sc.ctypes.data, 0, 8, comm.handle, None)
+        assert err.code != 0 and (out == 0).all()
+        L.drop_error_message(err.message)
+        assert (sppark_amd.to_affine(multi_gpu.msm_rccl(pts, sc, comm, ffi_affine_sz=pts.shape[1])) == exp).all()
+    finally:
+        comm.destroy()
+
+
+def test_msm_rccl_exchange_many_ranks_with_a_test_double(oracle, libs, tmp_path):
+    """The N > 1 shape of sppark_msm_rccl on one GPU: RCCL refuses two ranks on one device, so the three entry points
+    the library binds are supplied by a TEST DOUBLE (tests/emu/fake_rccl.cpp, via SPPARK_RCCL_LIB) whose ranks are
+    threads of one process and whose all-gather is N device-to-device copies behind a barrier.  Four ranks with uneven
+    shards, an empty one included: every rank returns the whole MSM; then rank 2 fails locally (bad stride): it reports
+    its error with `out` at infinity, the others do not hang and return the sum of the remaining shards."""
+    import json
+    import subprocess
+    import sys
+    O = oracle
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = str(tmp_path / "libfake_rccl.so")
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib,
+                    os.path.join(here, "emu", "fake_rccl.cpp")], check=True, capture_output=True)
+    n = 7001
+    pts, sc = recipe.msm_inputs(O.BLS12_381, n, 161803, ndistinct=300, flagged=True)
+    np.savez(tmp_path / "in.npz", pts=pts, sc=sc)
+    cuts = [0, 1000, 1000, 4567, n]
+    env = dict(os.environ, SPPARK_RCCL_LIB=lib)
+    for bad in (-1, 2):
+        r = subprocess.run([sys.executable, os.path.join(here, "rccl_ranks_worker.py"), str(tmp_path / "in.npz"), json.dumps(cuts), str(bad)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+        assert not any(res["hung"])
+        keep = np.ones(n, dtype=bool)
+        if bad >= 0:
+            keep[cuts[bad]:cuts[bad + 1]] = False
+        zsc = sc.copy(); zsc[~keep] = 0
+        exp = O.msm_affine(O.BLS12_381, pts, zsc, algo=0, param=8)
+        for rank, (code, out) in enumerate(zip(res["codes"], res["outs"])):
+            out = np.frombuffer(bytes.fromhex(out), dtype=np.uint8)
+            if rank == bad:
+                assert code != 0 and (out == 0).all()
+            else:
+                import sppark_amd
+                assert code == 0 and (sppark_amd.to_affine(out) == exp).all(), (bad, rank)
+
+
 def test_one_shot_pool_is_not_tied_to_threads(oracle, libs):
     """The one-shot entry points borrow contexts from a process-wide pool: calls from short-lived
     threads reuse them (no scratch stranded per dead thread), concurrent calls get distinct ones."""

@@ -231,7 +231,13 @@ def main():
         lg = args.ntt_lg
         g = torch.Generator(device="cuda"); g.manual_seed(2)
         x = (torch.randint(0, 2**62, (1 << lg,), dtype=torch.int64, device="cuda", generator=g))   # < p
-        stream = torch.cuda.current_stream().cuda_stream
+        # A NON-NULL stream for the device-resident timings: on the NULL stream sppark_ntt is synchronous (it mirrors the
+        # reference's compute_ntt), so every timed transform would carry a launch + host synchronisation round trip
+        # (~12 us of a 0.1-0.2 ms transform, profiles/r04_ntt_host_overhead.log) that is not kernel time.  torch's
+        # events below record on the current stream = this one.
+        ntt_stream = torch.cuda.Stream()
+        torch.cuda.synchronize(); torch.cuda.set_stream(ntt_stream)
+        stream = ntt_stream.cuda_stream
         Ord = sppark_amd.NTTInputOutputOrder
         ref = x.clone()
         for _ in range(3):
@@ -270,11 +276,31 @@ def main():
         # SURVEY 8(d) timing protocol (ii), through-the-FFI: compute_ntt on a HOST buffer, what every caller of the
         # reference hits (poc/ntt-cuda/src/lib.rs:7-118 -> ntt/ntt.cuh:215-244: H2D, transform, D2H); wall clock,
         # pageable numpy memory as a Rust Vec / Go slice is; output asserted against the device path checked above
+        torch.cuda.synchronize(); torch.cuda.set_stream(torch.cuda.default_stream())
         through_ffi = host_ntt_time("gl64", ref.cpu().numpy().view(np.uint64), y_host, lg)
+        # BASELINE beside it: the reference's OWN NTT (its HIP path, built for gfx950 from /root/reference into
+        # oracle/_ref/libref_ntt_gl64.so by `make -C oracle ref_ntt`; test infrastructure, prebuilt, not the product) on
+        # the same device-resident array: NTT::Base_dev_ptr (ntt/ntt.cuh:344-350), events on ITS stream around the same
+        # number of back-to-back transforms, best of 3 batches; its output on the timed input == ours, bit for bit
+        ref_build = None
+        if O.ref_ntt_available("gl64"):
+            xr = ref.clone(); torch.cuda.synchronize()
+            O.ref_ntt_dev("gl64", xr.data_ptr(), lg, 1, 0, 0); torch.cuda.synchronize()
+            same = bool((xr.cpu().numpy().view(np.uint64) == y_host).all())
+            assert same, "the reference's own NTT and sppark_amd's differ on the timed input"
+            r_fwd, r_inv, r_nn = (min(O.ref_ntt_dev_ms("gl64", xr.data_ptr(), lg, o, d_, 0, reps) for _ in range(3))
+                                  for o, d_ in ((1, 0), (2, 1), (0, 0)))
+            ref_build = {"what": "supranational/sppark's own NTT through its HIP path (hipcc -include util/cuda2hip.hpp, gfx950), "
+                                 "same box, same device-resident array, NTT::Base_dev_ptr",
+                         "forward_ms": r_fwd, "inverse_ms": r_inv, "forward_nn_ms": r_nn,
+                         "output_equals_ours": same,
+                         "speedup_forward": r_fwd / fwd, "speedup_inverse": r_inv / inv, "speedup_forward_nn": r_nn / fwd_nn}
+            del xr
         ntt = {"metric": "Goldilocks NTT 2^%d elements/s (forward NR / inverse RN, device-resident)" % lg,
-               "timing": "HIP events around 20 back-to-back transforms, best of 3 batches",
+               "timing": "HIP events around 20 back-to-back transforms on a non-null stream, best of 3 batches",
                "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
                "through_ffi": through_ffi,
+               "reference_hip_build": ref_build,
                "forward_elems_per_s": (1 << lg) / (fwd * 1e-3), "inverse_elems_per_s": (1 << lg) / (inv * 1e-3),
                "pair_elems_per_s": (1 << lg) / ((fwd + inv) * 1e-3),
                "equals_oracle": ntt_ok, "output_sha256": hashlib.sha256(y_host.tobytes()).hexdigest(),
@@ -346,7 +372,9 @@ def main():
         bctx.close(); del bpts, bsc
         y = torch.randint(0, 0x78000000, (1 << args.ntt_lg,), dtype=torch.int32, device="cuda")
         y0 = y.clone()
-        stream = torch.cuda.current_stream().cuda_stream
+        ntt_stream = torch.cuda.Stream()                        # (non-null, as for the Goldilocks timings above)
+        torch.cuda.synchronize(); torch.cuda.set_stream(ntt_stream)
+        stream = ntt_stream.cuda_stream
         sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream); torch.cuda.synchronize()
         bb_out = y.cpu().numpy().view(np.uint32)
         extras["babybear_ntt_equals_oracle"] = bool((bb_out == O.ntt_bb31(y0.cpu().numpy().view(np.uint32), O.NR)).all())
@@ -360,6 +388,18 @@ def main():
             sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NR, "bb31", stream=stream)
         e1.record(); torch.cuda.synchronize()
         extras["babybear_ntt_elems_per_s"] = 20 * (1 << args.ntt_lg) / (e0.elapsed_time(e1) * 1e-3)
+        e0.record()
+        for _ in range(20):
+            sppark_amd.NTT(0, y, sppark_amd.NTTInputOutputOrder.NN, "bb31", stream=stream)
+        e1.record(); torch.cuda.synchronize()
+        extras["babybear_ntt_forward_nr_ms"] = (1 << args.ntt_lg) / extras["babybear_ntt_elems_per_s"] * 1e3
+        extras["babybear_ntt_forward_nn_ms"] = e0.elapsed_time(e1) / 20
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        if O.ref_ntt_available("bb31"):                         # the reference's own build beside it, as for Goldilocks
+            torch.cuda.synchronize()
+            extras["babybear_ntt_reference_hip_build"] = {
+                "forward_nr_ms": min(O.ref_ntt_dev_ms("bb31", y.data_ptr(), args.ntt_lg, 1, 0, 0, 20) for _ in range(3)),
+                "forward_nn_ms": min(O.ref_ntt_dev_ms("bb31", y.data_ptr(), args.ntt_lg, 0, 0, 0, 20) for _ in range(3))}
         # the "next" rows of SURVEY 8(f): G2 MSM, 256-bit-field NTT, low-degree extension
         try:
             # input points: the 33 G2 points of a committed golden case (data fixture), replicated
@@ -378,7 +418,8 @@ def main():
             del g2pts, g2sc
         except Exception as ex:                                 # noqa: BLE001  (extras never fail the bench)
             extras["bls12_381_g2_msm_error"] = repr(ex)[:200]
-        stream = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize(); torch.cuda.set_stream(ntt_stream)
+        stream = ntt_stream.cuda_stream
         wlg = min(args.ntt_lg, 22)
         wx = torch.randint(0, 2**62, ((1 << wlg) * 4,), dtype=torch.int64, device="cuda"); wx[3::4] &= 0x0fffffffffffffff
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -400,6 +441,7 @@ def main():
         e1.record(); torch.cuda.synchronize()
         extras["goldilocks_lde_2^%d_to_2^%d_ms" % (llg, llg + 2)] = e0.elapsed_time(e1) / 5
         del ext
+        torch.cuda.set_stream(torch.cuda.default_stream())
         # through-the-FFI path with HOST buffers (PCIe inclusive; never the headline value): what the
         # reference's Rust / Go callers use.  2^24 and the full 2^26, chunked copy under the arithmetic.
         h2d, d2h, h2d_pageable = pcie_peaks()

@@ -373,3 +373,75 @@ def ref_msm_affine(curve, points, scalars, nthreads=0, mont=False):
                                  _ptr(scalars), int(mont), nthreads)
     assert rc == 0
     return out
+
+
+# ------------------- the reference's own NTT, built for gfx950 by its HIP path (_ref/libref_ntt_*.so) -
+# oracle/Makefile: ref_ntt; oracle/ref_ntt_shim.cu.  GPU box only (the libraries hold device code); used by the `-m gpu`
+# tests and by bench.py's reference leg, never by the product.
+_REF_NTT = {}
+REF_NTT_FIELDS = ("gl64", "gl64_plonky2", "bb31", "bb31_canonical", "bls12_381", "bn254", "bls12_377", "pallas", "vesta")
+
+
+class _RefError(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_int), ("message", ctypes.c_char_p)]      # RustError::by_value (util/rusterror.h:18-36)
+
+
+def ref_ntt_available(field):
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_ntt_%s.so" % field))
+
+
+def ref_ntt_lib(field):
+    if field not in _REF_NTT:
+        L = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_ntt_%s.so" % field), mode=ctypes.RTLD_LOCAL)
+        vp, u32, ci = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
+        L.compute_ntt.argtypes = [ctypes.c_size_t, vp, u32, ci, ci, ci]
+        L.compute_ntt.restype = _RefError
+        L.ref_ntt_dev.argtypes = [vp, u32, ci, ci, ci]
+        L.ref_ntt_dev_timed.argtypes = [vp, u32, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
+        L.ref_lde.argtypes = [vp, u32, u32]
+        L.ref_lde_aux.argtypes = [vp, u32, u32, vp]
+        L.ref_ntt_elem_bytes.restype = ctypes.c_size_t
+        _REF_NTT[field] = L
+    return _REF_NTT[field]
+
+
+def ref_compute_ntt(field, x, order, direction, typ):
+    """the reference's compute_ntt (poc/ntt-cuda/cuda/ntt_api.cu:25-36) on a copy of the host array |x|"""
+    L = ref_ntt_lib(field)
+    y = np.ascontiguousarray(x).copy()
+    n = y.nbytes // L.ref_ntt_elem_bytes()
+    assert n and not n & (n - 1)
+    err = L.compute_ntt(0, _ptr(y), n.bit_length() - 1, int(order), int(direction), int(typ))
+    assert err.code == 0, (err.code, err.message)
+    return y
+
+
+def ref_ntt_dev(field, dev_ptr, lg, order, direction, typ):
+    """NTT::Base_dev_ptr (ntt/ntt.cuh:344-350) on caller-owned device memory, synchronous"""
+    rc = ref_ntt_lib(field).ref_ntt_dev(dev_ptr, lg, int(order), int(direction), int(typ))
+    assert rc == 0, rc
+
+
+def ref_ntt_dev_ms(field, dev_ptr, lg, order, direction, typ, iters):
+    """average milliseconds of one of |iters| back-to-back reference transforms of a device buffer (event-timed)"""
+    ms = ctypes.c_float(0)
+    rc = ref_ntt_lib(field).ref_ntt_dev_timed(dev_ptr, lg, int(order), int(direction), int(typ), iters, ctypes.byref(ms))
+    assert rc == 0, rc
+    return float(ms.value)
+
+
+def ref_lde(field, x, lg_blowup, want_aux=False):
+    """NTT::LDE / LDE_aux (ntt/ntt.cuh:280-342) of the host array |x| (2^lg elements)"""
+    L = ref_ntt_lib(field)
+    x = np.ascontiguousarray(x)
+    eb = L.ref_ntt_elem_bytes()
+    n = x.nbytes // eb
+    lg = n.bit_length() - 1
+    buf = np.zeros((n << lg_blowup) * eb, dtype=np.uint8)
+    buf[:n * eb] = x.view(np.uint8).reshape(-1)
+    if want_aux:
+        aux = np.zeros(n * eb, dtype=np.uint8)
+        assert L.ref_lde_aux(_ptr(buf), lg, lg_blowup, _ptr(aux)) == 0
+        return buf.view(x.dtype), aux.view(x.dtype)
+    assert L.ref_lde(_ptr(buf), lg, lg_blowup) == 0
+    return buf.view(x.dtype)

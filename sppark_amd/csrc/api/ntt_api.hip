@@ -8,6 +8,10 @@ namespace sppark_amd {
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, false)
 #if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, false)
+#else
+#define SPPARK_NTT_LAT_EXTERN(DIF, INV) \
+    extern template __global__ void k_ntt_pass_lat<ntt_fr_t, DIF, INV>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+SPPARK_NTT_LAT_EXTERN(true, false) SPPARK_NTT_LAT_EXTERN(true, true) SPPARK_NTT_LAT_EXTERN(false, false) SPPARK_NTT_LAT_EXTERN(false, true)
 #endif
 }
 #if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // the radix-64 plan: ntt/k_ntt_r64.hip

@@ -8,7 +8,10 @@ namespace sppark_amd {
 #define SPPARK_NTT_DEFINE(DIF, INV, R1, R2) \
     template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
-#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // wide fields stop at 4 stages per pass
+#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // wide fields stop at 4 stages per pass in registers ...
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
+#else                                                              // ... and run up to 8 with one stage per round
+template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), false>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), true>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 #endif
 }

@@ -96,6 +96,10 @@ class ntt_engine {
     // with S = 6 against 2.54 with S = 4 on the same box, S = 5 2.81 -- a third fewer instructions and two passes less
     // buy nothing at two waves per SIMD (LDS: 256 B per lane).  Not instantiated.  profiles/r03_ntt_wide_stages.log
     static constexpr unsigned S_MAX = sizeof(F) > 8 ? 4 : 8;
+    // Round 4: the 256-bit fields run passes of up to 8 stages with ONE butterfly per lane and stage and the tile in LDS
+    // throughout (k_ntt_pass_lat, ntt_kernels.hpp): S/2 + 1 products per element for S stages instead of 3.75 for 4, half
+    // the passes -- and half the dependent chain on the small, latency-bound sizes.  0 = the register passes above.
+    static constexpr unsigned LAT_SMAX = sizeof(F) > 8 ? 8 : 0;
 
     // 256-bit elements: tables up to 2^24 entries (512 MB; every sub-problem of the pass reads its table once, the small
     // ones from L2 / the Infinity Cache).  The per-element alternative is a lo x hi product per twiddle: one of the ~3.5
@@ -222,9 +226,14 @@ public:
 
         // tuning knobs (tools/gpu_ntt_sweep.py), read once per process; the LDS tile is clamped to what
         // the element size allows (160 KB per work-group: 2^14 eight-byte elements, 2^12 32-byte ones)
-        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct; };
+        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; };
         static const knobs_t knobs = [] {
-            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG};
+            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1};
+            // 256-bit fields: stages per one-stage-per-round pass (0: the register passes), columns per tile row and tile
+            // elements (log2; default: by size, lat_shape())
+            if (const char* e = getenv("SPPARK_NTT_LAT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v <= 8) k.lat_smax = R64 ? 0 : v; }
+            if (const char* e = getenv("SPPARK_NTT_LAT_LGC")) { int v = atoi(e); if (v >= 0 && v <= 4) k.lat_lgc = v; }
+            if (const char* e = getenv("SPPARK_NTT_LAT_LGTILE")) { int v = atoi(e); if (v >= 6 && v <= 11) k.lat_lgt = v; }
             if (const char* e = getenv("SPPARK_NTT_R64_MIN")) k.r64_min = (unsigned)atoi(e);          // 99: the 8-stage plan only
             if (const char* e = getenv("SPPARK_NTT_R64_DIRECT")) k.r64_direct = (unsigned)atoi(e);    // largest single inter-pass table (log2)
             if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= S_MAX) k.smax = v; }
@@ -258,7 +267,9 @@ public:
             }
             if (!ok) rp.nsteps = 0;
         }
+        const bool lat = !R64 && knobs.lat_smax != 0;
         if (rp.nsteps) pl.npass = rp.nsteps;
+        else if (lat)  pl = make_ntt_lat_plan(lg, knobs.lat_smax, knobs.lat_lgc, knobs.lat_lgt);
         else           pl = make_ntt_plan(lg, lgc, lgt, smax);
         int scale_pass = -1;                        // (the radix-64 plan folds the scaling into its own last table)
         if (inverse && !rp.nsteps) {
@@ -307,6 +318,17 @@ public:
             P.apply_scale = inverse && last && scale_pass < 0;
             size_t tile_elems = (size_t)1 << (P.lgG + P.S + P.lgC);
             unsigned tiles = (unsigned)(n / tile_elems);
+            if constexpr (!R64) {
+                if (lat) {                                      // one butterfly per lane and stage, the tile in LDS throughout
+                    const unsigned lanes = (unsigned)std::min<size_t>(std::max<size_t>(tile_elems / 2, 64), 1024);
+                    const size_t lat_lds = tile_elems * sizeof(F);
+                    if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, true, true>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);
+                              else         hipLaunchKernelGGL((k_ntt_pass_lat<F, true, false>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); }
+                    else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, false, true>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);
+                              else         hipLaunchKernelGGL((k_ntt_pass_lat<F, false, false>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); }
+                    continue;
+                }
+            }
             size_t lds = ntt_lds_elems(P) * sizeof(F);
             // one lane per register sub-transform: a tile has 2^(lgG + R1 + lgC) of them in its
             // larger round (small tiles of wide elements would leave most of 256 lanes idle)

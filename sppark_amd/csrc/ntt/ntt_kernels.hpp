@@ -302,6 +302,121 @@ void k_ntt_pass(F* data, ntt_tables<F> T, ntt_pass P)
     }
 }
 
+// ---- the same pass, ONE STAGE PER ROUND: 256-bit fields (round 4) ------------------------------------------------------
+// A pass of the 256-bit fields in registers is radix-4 x radix-4 (S = 4: sixteen 8-word elements per lane is where the
+// registers end), i.e. six passes at 2^24 and FOUR at 2^16, and every pass costs each element one inter-pass and most
+// elements one w_{2^S} twiddle product on top of its S/2 butterfly products: 3.75 products per element for 4 stages.
+// Here the tile stays in LDS for all S <= 8 stages of a pass, a lane does ONE butterfly per stage (two elements: 16
+// data registers, any occupancy), and a barrier separates the stages: S/2 + 1 = 5 products per element for 8 stages,
+// half the passes, half the HBM traffic -- and on small transforms, which are latency-bound (a 2^16 transform is 256
+// waves on 1024 SIMDs), half the dependent chain per element and twice the lanes.  LDS moves 128 bytes per lane and
+// stage against >= 300 instructions of one 256-bit product: not a limit.  Same function of (data, T, P) as
+// k_ntt_pass<R1, R2> with R1 + R2 = P.S (the reference splits its steps the same way, 8 stages per launch with
+// 1 butterfly per thread and stage: ntt/kernels/gs_mixed_radix_wide.cu:9-119; measured beside this one in
+// profiles/r04_ntt_vs_reference_timing.log).
+// LDS image of a tile of 32-byte elements: 16-byte CHUNK k of element e lives in plane k, at chunk index
+// k * elems + e.  A ds_read_b128 serves 16 lanes per LDS cycle and wants their sixteen 16-byte slots distinct modulo
+// 256 bytes; with whole elements side by side the two halves of an element are two separate reads that each touch only
+// every other slot -- at least 2-way conflicts in every stage, 4- to 16-way in the last ones (counters of the first
+// version: SQ_LDS_BANK_CONFLICT = 80 % of SQ_LDS_IDX_ACTIVE, the pass LDS-bound at 1.0 ms; profiles/r04_ntt_wide_pmc.txt).
+// In planes, consecutive elements are consecutive slots: the strided stages are conflict-free down to half = 4 rows.
+typedef uint4 __attribute__((may_alias)) ntt_lat_chunk;
+template<class F> SPPARK_DEVFN F ntt_lat_get(const F* tile, unsigned e, unsigned elems)
+{
+    if constexpr (sizeof(F) % 16 == 0 && sizeof(F) > 16) {
+        F r;
+        #pragma unroll
+        for (unsigned k = 0; k < sizeof(F) / 16; k++)
+            reinterpret_cast<ntt_lat_chunk*>(&r)[k] = reinterpret_cast<const ntt_lat_chunk*>(tile)[k * elems + e];
+        return r;
+    } else return tile[e];
+}
+template<class F> SPPARK_DEVFN void ntt_lat_put(F* tile, unsigned e, unsigned elems, const F& x)
+{
+    if constexpr (sizeof(F) % 16 == 0 && sizeof(F) > 16) {
+        #pragma unroll
+        for (unsigned k = 0; k < sizeof(F) / 16; k++)
+            reinterpret_cast<ntt_lat_chunk*>(tile)[k * elems + e] = reinterpret_cast<const ntt_lat_chunk*>(&x)[k];
+    } else tile[e] = x;
+}
+template<class F>
+SPPARK_DEVFN F ntt_lat_twiddle(const ntt_tables<F>& T, const ntt_pass& P, const ntt_tile_geom& geo, unsigned mid, unsigned c)
+{
+    if (T.pass_tw != nullptr) return T.pass_tw[((size_t)mid << geo.lgQ) + geo.c0 + c];
+    const size_t ex = (size_t)(geo.c0 + c) * bit_rev32(mid, P.S);
+    return ntt_twiddle(T, ex << (T.lg_n - P.lg_cur));
+}
+// HBM -> (CT/DIT: * w_{n_cur}^(col * rev_S(mid))) -> LDS; tile element e = row gm * C + column c
+template<class F, bool DIF>
+SPPARK_DEVFN void ntt_lat_load(const F* data, F* tile, const ntt_tables<F>& T, const ntt_pass& P, size_t tile_id, unsigned tid, unsigned nt)
+{
+    const ntt_tile_geom geo = ntt_geom(P, tile_id);
+    const unsigned elems = 1u << (P.lgG + P.S + P.lgC), C = 1u << P.lgC;
+    for (unsigned e = tid; e < elems; e += nt) {
+        const unsigned c = e & (C - 1), gm = e >> P.lgC;
+        F x = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
+        if (!DIF && geo.lgQ) x = x * ntt_lat_twiddle(T, P, geo, gm & ((1u << P.S) - 1), c);
+        ntt_lat_put(tile, e, elems, x);
+    }
+}
+// stage t of the 2^S-point transforms of the tile's columns: lane = (sub-problem g, butterfly j, column c)
+template<class F, bool DIF, bool INV>
+SPPARK_DEVFN void ntt_lat_stage(F* tile, const ntt_tables<F>& T, const ntt_pass& P, unsigned t, unsigned tid, unsigned nt)
+{
+    const unsigned S = P.S, nb = 1u << (P.lgG + S - 1 + P.lgC), C = 1u << P.lgC, elems = 2 * nb;
+    const unsigned lgh = DIF ? S - 1 - t : t, half = 1u << lgh;
+    for (unsigned bf = tid; bf < nb; bf += nt) {
+        const unsigned c = bf & (C - 1), r = bf >> P.lgC, j = r & ((1u << (S - 1)) - 1), g = r >> (S - 1);
+        const unsigned off = j & (half - 1), m0 = ((j >> lgh) << (lgh + 1)) + off, m1 = m0 + half;
+        const unsigned i0 = (((g << S) + m0) << P.lgC) + c, i1 = (((g << S) + m1) << P.lgC) + c;
+        F sum, dif;
+        const F x0 = ntt_lat_get(tile, i0, elems), x1 = ntt_lat_get(tile, i1, elems);
+        if (DIF) {                                              // natural in -> bit-reversed out (as radix_dif)
+            const unsigned k = off << t;
+            if (F::template root_neg<INV>(S, k)) F::bfly(x1, x0, sum, dif);
+            else                                 F::bfly(x0, x1, sum, dif);
+            ntt_lat_put(tile, i0, elems, sum);
+            ntt_lat_put(tile, i1, elems, F::template mul_root<INV>(dif, S, k, T.inner));
+        } else {                                                // bit-reversed in -> natural out (as radix_dit)
+            const unsigned k = off << (S - 1 - t);
+            const F bw = F::template mul_root<INV>(x1, S, k, T.inner);
+            F::bfly(x0, bw, sum, dif);
+            const bool neg = F::template root_neg<INV>(S, k);
+            ntt_lat_put(tile, i0, elems, neg ? dif : sum);
+            ntt_lat_put(tile, i1, elems, neg ? sum : dif);
+        }
+    }
+}
+// LDS -> (GS/DIF: * w_{n_cur}^(col * rev_S(mid))) -> (* 1/n) -> HBM
+template<class F, bool DIF>
+SPPARK_DEVFN void ntt_lat_store(F* data, const F* tile, const ntt_tables<F>& T, const ntt_pass& P, size_t tile_id, unsigned tid, unsigned nt)
+{
+    const ntt_tile_geom geo = ntt_geom(P, tile_id);
+    const unsigned elems = 1u << (P.lgG + P.S + P.lgC), C = 1u << P.lgC;
+    for (unsigned e = tid; e < elems; e += nt) {
+        const unsigned c = e & (C - 1), gm = e >> P.lgC;
+        F x = ntt_lat_get(tile, e, elems);
+        if (DIF && geo.lgQ) x = x * ntt_lat_twiddle(T, P, geo, gm & ((1u << P.S) - 1), c);
+        if (P.apply_scale) x = x * T.scale;
+        data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c] = x;
+    }
+}
+template<class F, bool DIF, bool INV>
+__global__ __launch_bounds__(1024)
+void k_ntt_pass_lat(F* data, ntt_tables<F> T, ntt_pass P)
+{
+    extern __shared__ unsigned char ntt_lds[];
+    F* tile = reinterpret_cast<F*>(ntt_lds);
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    ntt_lat_load<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+    __syncthreads();
+    for (unsigned t = 0; t < P.S; t++) {
+        ntt_lat_stage<F, DIF, INV>(tile, T, P, t, tid, nt);
+        __syncthreads();
+    }
+    ntt_lat_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+}
+
 // (R1, R2) = (ceil(S/2), floor(S/2)); CALL(R1, R2) is expanded for the pass's S
 #define SPPARK_NTT_DISPATCH_S(S, CALL)                                  \
     switch (S) {                                                        \
@@ -563,6 +678,18 @@ static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg
         rem -= S;
     }
     return pl;
+}
+
+// The plan of the one-stage-per-round passes (k_ntt_pass_lat; 256-bit fields): passes of <= smax stages; tiles of
+// 2^7 .. 2^10 elements, at least 256 of them where the transform has that many -- a small transform is latency-bound and
+// wants every CU, a large one wants 128-byte rows (four 32-byte elements).  lgc / lgtile >= 0 override the shape
+// (SPPARK_NTT_LAT_LGC / _LGTILE; profiles/r04_ntt_wide_lat_planes.log).
+static inline ntt_plan make_ntt_lat_plan(unsigned lg_n, unsigned smax, int lgc = -1, int lgtile = -1)
+{
+    const unsigned np = (lg_n + smax - 1) / smax, s0 = (lg_n + np - 1) / np;
+    const unsigned tile_lg = lgtile >= 0 ? (unsigned)lgtile : lg_n < 15 ? 7u : lg_n > 18 ? 10u : lg_n - 8;
+    const unsigned c_lg = lgc >= 0 ? (unsigned)lgc : tile_lg > s0 ? (tile_lg - s0 < 2u ? tile_lg - s0 : 2u) : 0u;
+    return make_ntt_plan(lg_n, c_lg, tile_lg > s0 + c_lg ? tile_lg : s0 + c_lg, smax);
 }
 
 } // namespace sppark_amd

@@ -127,6 +127,11 @@ template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int i
 
 static unsigned g_r64_min = 12, g_r64_direct = 20;          // as ntt_engine's knobs (SPPARK_NTT_R64_MIN / _DIRECT)
 extern "C" void emu_ntt_plan(unsigned r64_min, unsigned r64_direct) { g_r64_min = r64_min; g_r64_direct = r64_direct; }
+// the one-stage-per-round passes of the 256-bit fields (k_ntt_pass_lat): stages per pass (0: the register passes),
+// log2 columns per tile row, log2 tile elements -- as ntt_engine's lat_* choices
+static unsigned g_lat_smax = sizeof(F) > 8 ? 8 : 0;         // as ntt_engine<F>::LAT_SMAX
+static int g_lat_lgc = -1, g_lat_lgtile = -1;               // -1: the shape by size (make_ntt_lat_plan)
+extern "C" void emu_ntt_lat(unsigned smax, int lgc, int lgtile) { g_lat_smax = smax; g_lat_lgc = lgc; g_lat_lgtile = lgtile; }
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
@@ -159,7 +164,8 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
 #ifndef EMU_SMAX
 #define EMU_SMAX (sizeof(F) > 8 ? 4 : 8)        // as ntt_engine<F>::S_MAX
 #endif
-    ntt_plan pl = make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
+    const bool lat = g_lat_smax != 0;
+    ntt_plan pl = lat ? make_ntt_lat_plan(lg, g_lat_smax, g_lat_lgc, g_lat_lgtile) : make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
     if (sizeof(F) <= 8 && lg >= 12 && lg >= g_r64_min) {
         emu_r64_passes<F>(d, lg, gs, inverse, T, nt, g_r64_direct);
         pl.npass = 0;
@@ -186,6 +192,20 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
             pass_tw.resize((size_t)1 << P.lg_cur);
             for (size_t k = 0; k < pass_tw.size(); k++) pass_table_item(pass_tw.data(), T, P.lg_cur, P.S, k, inverse && scale_pass == (int)i);
             T.pass_tw = pass_tw.data();
+        }
+        if (lat) {
+            tile.resize(tile_elems);
+#define EMU_LAT(DIF, INV)                                                                                          \
+            for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {                                        \
+                for (unsigned tid = 0; tid < nt; tid++) ntt_lat_load<F, DIF>(d, tile.data(), T, P, tile_id, tid, nt); \
+                for (unsigned t = 0; t < P.S; t++)                                                                 \
+                    for (unsigned tid = 0; tid < nt; tid++) ntt_lat_stage<F, DIF, INV>(tile.data(), T, P, t, tid, nt); \
+                for (unsigned tid = 0; tid < nt; tid++) ntt_lat_store<F, DIF>(d, tile.data(), T, P, tile_id, tid, nt); \
+            }
+            if (gs) { if (inverse) { EMU_LAT(true, true) } else { EMU_LAT(true, false) } }
+            else    { if (inverse) { EMU_LAT(false, true) } else { EMU_LAT(false, false) } }
+#undef EMU_LAT
+            continue;
         }
         for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {
 #define EMU_ROUNDS(R1, R2)                                                                                         \

@@ -27,6 +27,8 @@ def _emu(feature):
     L.emu_lde.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
     L.emu_ntt_plan.argtypes = [ctypes.c_uint, ctypes.c_uint]
     L.emu_ntt_plan.restype = None
+    L.emu_ntt_lat.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int]
+    L.emu_ntt_lat.restype = None
     return L
 
 
@@ -40,18 +42,24 @@ def test_ntt_kernels_on_host(oracle, field, feature):
         f = lambda x, order, direction, typ: O.ntt_fr(curve, x, order, direction, typ)
     else:
         f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
-    for lg in (list(range(1, 15)) + [16]) if field in ("gl64", "bb31") else (list(range(1, 12)) + [13]):
-        x = recipe.ntt_input(field, lg, 100 + lg)
-        for order in range(4):
-            for direction in range(2):
-                for typ in range(2):
-                    # (above 2^13: standard transforms only; NN / RR -- the tiled bit reversal with several `mid`
-                    # bits, in its 16-byte form for the single-word fields -- in the forward direction only)
-                    if lg > 13 and (typ == 1 or (order in (0, 3) and direction == 1)):
-                        continue
-                    y = x.copy()
-                    L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 10 else 256)
-                    assert (y == f(x, order, direction, typ)).all(), (field, lg, order, direction, typ)
+    wide = field in ("bls12_381", "bn254")
+    # the 256-bit fields: the engine's default passes (one stage per round, up to 8 stages) and the register passes
+    # (radix-4 x radix-4; SPPARK_NTT_LAT_SMAX=0)
+    for lat in ((8, 0) if wide else (0,)):
+        L.emu_ntt_lat(lat, -1, -1)
+        for lg in (list(range(1, 15)) + [16]) if not wide else (list(range(1, 12)) + [13]):
+            x = recipe.ntt_input(field, lg, 100 + lg)
+            for order in range(4):
+                for direction in range(2):
+                    for typ in range(2):
+                        # (above 2^13: standard transforms only; NN / RR -- the tiled bit reversal with several `mid`
+                        # bits, in its 16-byte form for the single-word fields -- in the forward direction only)
+                        if lg > 13 and (typ == 1 or (order in (0, 3) and direction == 1)):
+                            continue
+                        y = x.copy()
+                        L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 10 else 256)
+                        assert (y == f(x, order, direction, typ)).all(), (field, lat, lg, order, direction, typ)
+    L.emu_ntt_lat(8 if wide else 0, -1, -1)
 
 
 @pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR"),
@@ -102,4 +110,41 @@ def test_ntt_radix64_plan_on_host(oracle, field, feature):
             L.emu_ntt(z.ctypes.data, lg, 1, 0, 0, 256)
             assert (z == f(x, 1, 0, 0)).all()
     finally:
+        L.emu_ntt_plan(12, 20)
+
+
+@pytest.mark.parametrize("field,feature", [("bls12_381", "BLS12_381"), ("bn254", "BN254"), ("bb31", "BABY_BEAR"), ("gl64", "GOLDILOCKS")])
+def test_ntt_one_stage_per_round_passes_on_host(oracle, field, feature):
+    """k_ntt_pass_lat's rounds (load, S stages in LDS with one butterfly per lane, store) under several pass shapes:
+    stages per pass 8 / 6 / 5 / 3, tile rows of 1 / 4 / 16 columns, tiles that hold several sub-problems -- every order,
+    direction and type against the oracle.  (The kernel is launched for the 256-bit fields only; BabyBear and
+    Goldilocks run the same index math here -- Goldilocks with its sign-folded power-of-two roots, root_neg, which exist
+    up to order 64: passes of at most 6 stages.)"""
+    O = oracle
+    L = _emu(feature)
+    if field in ("bls12_381", "bn254"):
+        curve = O.BLS12_381 if field == "bls12_381" else O.BN254
+        f = lambda x, order, direction, typ: O.ntt_fr(curve, x, order, direction, typ)
+    else:
+        f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+    try:
+        L.emu_ntt_plan(99, 20)                                      # (Goldilocks: generic passes, not the radix-64 plan)
+        for smax, lgc, lgtile in ((8, -1, -1), (8, 2, 10), (8, 0, 8), (6, 4, 11), (5, 1, 9), (3, 2, 6)):
+            if field == "gl64" and smax > 6:
+                continue
+            L.emu_ntt_lat(smax, lgc, lgtile)
+            for lg in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+                if lg > 11 and (smax, lgc) not in ((8, -1), (6, 4)):
+                    continue
+                x = recipe.ntt_input(field, lg, 500 + lg)
+                for order in range(4):
+                    for direction in range(2):
+                        for typ in range(2):
+                            if lg > 10 and (typ == 1 or order in (0, 3)):
+                                continue
+                            y = x.copy()
+                            L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 9 else 256)
+                            assert (y == f(x, order, direction, typ)).all(), (field, smax, lgc, lgtile, lg, order, direction, typ)
+    finally:
+        L.emu_ntt_lat(8 if field in ("bls12_381", "bn254") else 0, -1, -1)      # the engine's defaults
         L.emu_ntt_plan(12, 20)

@@ -420,12 +420,13 @@ def test_ntt_cached_tables_and_scratch_are_bounded_and_releasable(oracle, libs):
         assert (y == f(x, 1, 0, 0)).all()
         t16 = L.sppark_ntt_cached_tables()
         assert t16 > 1 and 0 < L.sppark_ntt_cached_scratch_bytes() <= 1 << 30
-        x2 = recipe.ntt_input(field, 12, 6)
+        # a smaller transform that is the lower passes of the 2^16 one (radix-64 plan: 2^12; the 256-bit fields' passes
+        # of 8 stages: 2^8) adds its own root tables and finds the inter-pass tables -- keyed by the sub-problem size,
+        # not by the transform size -- already there
+        x2 = recipe.ntt_input(field, 8 if field in WIDE else 12, 6)
         y2 = x2.copy()
         sppark_amd.NTT(0, y2, Ord.NR, field)
         assert (y2 == f(x2, 1, 0, 0)).all()
-        # a 2^12 transform is the lower passes of the 2^16 one: it adds its own root tables and finds the inter-pass
-        # tables (keyed by the sub-problem size, not by the transform size) already there
         assert L.sppark_ntt_cached_tables() == t16 + 1
         z = x.copy()
         sppark_amd.iNTT(0, z, Ord.RN, field)                    # the table that carries 1/n belongs to this size

@@ -11,6 +11,7 @@ dt = torch.int32 if field == "bb31" else torch.int64
 hi = 0x78000000 if field == "bb31" else (1 << 62)
 x = torch.randint(0, hi, ((1 << (lg + lb)) * words,), dtype=dt, device="cuda")
 if words == 4: x[3::4] &= 0x0fffffffffffffff
+torch.cuda.set_stream(torch.cuda.Stream())                  # non-null: on the NULL stream sppark_ntt synchronises after every call
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     sppark_amd.LDE(0, x, lg, lb, field, stream=s)

@@ -5,6 +5,7 @@ import torch
 import sppark_amd
 from sppark_amd import NTTInputOutputOrder as Ord
 
+torch.cuda.set_stream(torch.cuda.Stream())                  # non-null: on the NULL stream sppark_ntt synchronises after every call
 stream = torch.cuda.current_stream().cuda_stream
 FIELDS = os.environ.get("NTT_FIELDS", "gl64,bb31,bls12_381,bn254").split(",")      # e.g. NTT_FIELDS=gl64 NTT_LGS=12,16,24
 LGS = [int(v) for v in os.environ["NTT_LGS"].split(",")] if os.environ.get("NTT_LGS") else None

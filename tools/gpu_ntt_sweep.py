@@ -5,6 +5,7 @@ import torch
 import sppark_amd
 from sppark_amd import NTTInputOutputOrder as Ord
 
+torch.cuda.set_stream(torch.cuda.Stream())                  # non-null: on the NULL stream sppark_ntt synchronises after every call
 stream = torch.cuda.current_stream().cuda_stream
 fields = sys.argv[1:] or ["gl64", "bb31"]
 for field in fields:

@@ -4,6 +4,7 @@ import torch, sppark_amd
 from sppark_amd import NTTInputOutputOrder as Ord
 lg = int(sys.argv[1])
 x = torch.randint(0, 2**62, ((1 << lg) * 4,), dtype=torch.int64, device="cuda"); x[3::4] &= 0x0fffffffffffffff
+torch.cuda.set_stream(torch.cuda.Stream())                  # non-null: on the NULL stream sppark_ntt synchronises after every call
 s = torch.cuda.current_stream().cuda_stream
 for spec in sys.argv[2:]:
     smax, lgc, lgt = spec.split(":")

@@ -259,7 +259,9 @@ SppError sppark_g1_generate(void *out, size_t stride, size_t n, uint64_t seed);
 void *sppark_gpu_ptr_alloc(size_t bytes);
 void *sppark_gpu_ptr_get(void *const *ref);
 
-/* NTT on a device- or host-resident buffer with an explicit stream. */
+/* NTT on a device- or host-resident buffer with an explicit stream.  On a device buffer and a non-NULL stream the call
+ * only ENQUEUES the kernels (as NTT::Base_dev_ptr, ntt/ntt.cuh:344-350); with stream == NULL, or on a host buffer, it
+ * returns when the result is in place (as compute_ntt).  Callers that time or pipeline transforms pass their stream. */
 SppError sppark_ntt(size_t device_id, void *inout, uint32_t lg_domain_size,
                     int ntt_order, int ntt_direction, int ntt_type, void *stream);
 

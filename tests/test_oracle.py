@@ -299,3 +299,29 @@ def test_root_convention_variants(oracle):
     finally:
         O.set_root_conventions(False, False)
     assert L.oracle_gl64_root(32) == 0x185629dcda58878c and L.oracle_bb31_root(27) == 0x1ffffedc
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only in the build container")
+def test_reference_ntt_build_recipe(oracle):
+    """oracle/Makefile `ref_ntt`: the reference's own NTT builds for gfx950 through its HIP path from the sources where
+    they lie -- nine libraries, each exporting the reference's compute_ntt (poc/ntt-cuda/cuda/ntt_api.cu:25-36) and the
+    forwarders of oracle/ref_ntt_shim.cu; they hold gfx950 device code and none of sppark_amd's symbols.  (They RUN on
+    the GPU box only: tests/test_ntt_vs_reference_gpu.py.)"""
+    import subprocess
+    O = oracle
+    here = os.path.dirname(os.path.abspath(O.__file__))
+    subprocess.check_call(["make", "-s", "-C", here, "ref_ntt"])
+    for field in O.REF_NTT_FIELDS:
+        assert O.ref_ntt_available(field), field
+        so = os.path.join(here, "_ref", "libref_ntt_%s.so" % field)
+        syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+        for s in ("compute_ntt", "cuda_available", "ref_ntt_dev", "ref_ntt_dev_timed", "ref_lde_aux", "ref_ntt_elem_bytes"):
+            assert (" T " + s + "\n") in syms, (field, s)
+        assert "sppark_amd" not in syms and "sppark_ntt" not in syms     # (the reference has a class sppark_error of its own)
+        fat = subprocess.run(["strings", "-n", "6", so], capture_output=True, text=True).stdout
+        assert "gfx950" in fat, field
+    # the recipe is in .gitignore (outputs never committed) and NOT in .gpurunignore (they travel to the GPU box)
+    root = os.path.dirname(here)
+    assert "oracle/_ref/" in open(os.path.join(root, ".gitignore")).read()
+    ignore = os.path.join(root, ".gpurunignore")
+    assert not os.path.exists(ignore) or "oracle/_ref" not in open(ignore).read()

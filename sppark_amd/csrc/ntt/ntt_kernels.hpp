@@ -681,7 +681,7 @@ static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg
 }
 
 // The plan of the one-stage-per-round passes (k_ntt_pass_lat; 256-bit fields): passes of <= smax stages; tiles of
-// 2^7 .. 2^10 elements, at least 256 of them where the transform has that many -- a small transform is latency-bound and
+// 2^7 .. 2^10 elements, at least 256 of them from 2^16 elements on -- a small transform is latency-bound and
 // wants every CU, a large one wants 128-byte rows (four 32-byte elements).  lgc / lgtile >= 0 override the shape
 // (SPPARK_NTT_LAT_LGC / _LGTILE; profiles/r04_ntt_wide_lat_planes.log).
 static inline ntt_plan make_ntt_lat_plan(unsigned lg_n, unsigned smax, int lgc = -1, int lgtile = -1)

@@ -131,6 +131,16 @@ extern "C" void emu_ntt_plan(unsigned r64_min, unsigned r64_direct) { g_r64_min 
 // log2 columns per tile row, log2 tile elements -- as ntt_engine's lat_* choices
 static unsigned g_lat_smax = sizeof(F) > 8 ? 8 : 0;         // as ntt_engine<F>::LAT_SMAX
 static int g_lat_lgc = -1, g_lat_lgtile = -1;               // -1: the shape by size (make_ntt_lat_plan)
+// the plan of the one-stage-per-round passes for a size, as the engine makes it: out[4 * i ..] = {lg_cur, S, lgC, lgG} of
+// pass i (GS order); returns the number of passes
+extern "C" unsigned emu_ntt_lat_plan(unsigned lg, unsigned smax, int lgc, int lgtile, unsigned out[64])
+{
+    const ntt_plan pl = make_ntt_lat_plan(lg, smax, lgc, lgtile);
+    for (unsigned i = 0; i < pl.npass && i < 16; i++) {
+        out[4 * i] = pl.pass[i].lg_cur; out[4 * i + 1] = pl.pass[i].S; out[4 * i + 2] = pl.pass[i].lgC; out[4 * i + 3] = pl.pass[i].lgG;
+    }
+    return pl.npass;
+}
 extern "C" void emu_ntt_lat(unsigned smax, int lgc, int lgtile) { g_lat_smax = smax; g_lat_lgc = lgc; g_lat_lgtile = lgtile; }
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)

@@ -29,6 +29,8 @@ def _emu(feature):
     L.emu_ntt_plan.restype = None
     L.emu_ntt_lat.argtypes = [ctypes.c_uint, ctypes.c_int, ctypes.c_int]
     L.emu_ntt_lat.restype = None
+    L.emu_ntt_lat_plan.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
+    L.emu_ntt_lat_plan.restype = ctypes.c_uint
     return L
 
 
@@ -148,3 +150,33 @@ def test_ntt_one_stage_per_round_passes_on_host(oracle, field, feature):
     finally:
         L.emu_ntt_lat(8 if field in ("bls12_381", "bn254") else 0, -1, -1)      # the engine's defaults
         L.emu_ntt_plan(12, 20)
+
+
+def test_one_stage_per_round_plan_invariants():
+    """make_ntt_lat_plan (what ntt_engine::run launches k_ntt_pass_lat with) for every size a 256-bit field can have and
+    the shapes the knobs allow: the passes' stages add up to lg n, each splits what the previous one left, a tile never
+    exceeds 2048 elements (1024 lanes at one butterfly per lane, 64 KB of LDS at 32 bytes per element), its row is inside
+    the sub-problem's row (or the tile holds whole sub-problems), and the default shape gives a transform of 2^16 or more
+    elements at least 256 tiles."""
+    L = _emu("BLS12_381")
+    out = (ctypes.c_uint * 64)()
+    for smax, lgc, lgtile in ((8, -1, -1), (6, -1, -1), (4, -1, -1), (8, 2, 10), (8, 0, 8), (8, 3, 11), (7, 4, 11), (5, 4, 9), (1, -1, -1)):
+        for lg in range(1, 33):
+            if (lg + smax - 1) // smax > 16:
+                continue                                            # (more passes than a plan holds: smax = 1 above 2^16)
+            npass = L.emu_ntt_lat_plan(lg, smax, lgc, lgtile, out)
+            assert 1 <= npass <= 16
+            rem = lg
+            for i in range(npass):
+                lg_cur, S, lgC, lgG = out[4 * i:4 * i + 4]
+                assert lg_cur == rem and 1 <= S <= smax and S <= rem, (smax, lg, i)
+                lgQ = lg_cur - S
+                assert lgC <= lgQ and (lgG == 0 or lgC == lgQ), (smax, lg, i)
+                assert lgG <= lg - lg_cur, (smax, lg, i)            # whole sub-problems that exist
+                tile = lgG + S + lgC
+                assert tile <= 11 and tile <= lg, (smax, lgc, lgtile, lg, i, tile)
+                if lgc < 0 and lg >= 16 and i == 0:
+                    assert lg - tile >= 8, (smax, lg, tile)         # >= 256 tiles
+                rem -= S
+            assert rem == 0
+            assert max(out[4 * i + 1] for i in range(npass)) - min(out[4 * i + 1] for i in range(npass)) <= 1      # near-equal split

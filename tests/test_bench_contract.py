@@ -44,3 +44,23 @@ def test_recorded_bench_line_schema():
         e = sh["msm_ms_at_2^%d" % lg]
         assert e["equals_oracle"] is True and e["ms"] > 0
     assert sh["msm_ms_at_2^25"]["ms"] < d["ms_per_step"] < 2.2 * sh["msm_ms_at_2^25"]["ms"]
+
+
+def test_tools_and_job_scripts_parse():
+    """tools/*.py byte-compile and tools/jobs/*.sh pass `bash -n`: the measurement helpers named in profiles/ and DESIGN.md
+    are at least syntactically whole (they run on the GPU box only)."""
+    import glob
+    import py_compile
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pys = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(pys) >= 20
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for p in pys:
+            py_compile.compile(p, doraise=True, cfile=os.path.join(tmp, os.path.basename(p) + "c"))
+    shs = sorted(glob.glob(os.path.join(root, "tools", "jobs", "*.sh")) + glob.glob(os.path.join(root, "tools", "*.sh")))
+    assert shs
+    for p in shs:
+        r = subprocess.run(["bash", "-n", p], capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stderr)

@@ -5,6 +5,7 @@
 #include "../msm/curve_select.hpp"
 #include "../msm/msm_kernels.hpp"
 #include "../msm/msm_coop_kernels.hpp"
+#include "../msm/msm_g2c_kernels.hpp"
 #include "../msm/msm_sort_kernels.hpp"
 
 // the big kernels are instantiated in their own translation units
@@ -42,6 +43,10 @@ extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, buc
                                                            const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
+#if !defined(SPPARK_FP2_32LIMB)
+extern template __global__ void k_accumulate_g2c<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
+                                                               const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
+#endif
 extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
                                                      unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<fp2_d>(bucket2_m*, u32*, const u32*, const bucket2_m*, unsigned, u32*);

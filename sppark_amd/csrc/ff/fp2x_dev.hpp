@@ -24,6 +24,7 @@ template<class P, int LB> struct fp2x_dev {
     static constexpr int NL = fp::NL;
     static constexpr int N = 2 * fp::NL;                // words of the in-memory image (internal limbs)
     static constexpr int NW = 2 * P::N;                 // 32-bit words of the standard wire form
+    static constexpr int FP2_NR = P::FP2_NR;            // u^2 = -FP2_NR
     fp c0, c1;
 
     SPPARK_DEVFN static fp2x_dev from_wire(const u32* w)

@@ -47,6 +47,8 @@ template<class FD, class FH, class FRp>
 class msm_t {
 public:
     typedef FD fp_d;
+    // the coordinate field is Fp2 over the loosely-reduced field: the cooperative accumulation exists for it
+    static constexpr bool G2_COOP_BUILT = field_is_internal<FD>::value && !field_is_montx<FD>::value;
     typedef mont_dev<FRp> fr_d;
     typedef FH fp_h;
     typedef typename xyzz_dev<fp_d>::mem_t bucket_t;       // memory image: wire format
@@ -221,6 +223,9 @@ public:
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_accumulate<fp_d, false>, 256, 0) == hipSuccess && nb > 0)
                 tune.resident_lanes = (size_t)std::min(nb, 2) * 256 * (size_t)gpu->prop.multiProcessorCount;
             else (void)hipGetLastError();
+        }
+        if constexpr (G2_COOP_BUILT) {              // A/B switch of the one-shot entry points (no tuning call reaches their pooled contexts)
+            if (const char* e = getenv("SPPARK_G2_COOP")) tune.g2_coop = (unsigned)atoi(e);
         }
         if (stream == nullptr) {
             // a non-blocking private stream (a blocking one pays an implicit legacy-stream check on
@@ -570,8 +575,19 @@ private:
                 const u32* sorted = (const u32*)(blob + l.sorted[b]);
                 const u32* off = (const u32*)(blob + l.off[b]);
                 dim3 grid((p.chunks_per_win + 255) / 256, wn);
+                bool by_pairs = false;              // G2: one Fp2 component per wave (NOT the default; unmeasured on hardware)
+                if constexpr (G2_COOP_BUILT) {
+                    if (tune.g2_coop) {
+                        by_pairs = true;
+                        dim3 grid2((p.chunks_per_win + 63) / 64, wn);
+                        hipLaunchKernelGGL((k_accumulate_g2c<fp_d, false>), grid2, dim3(G2C_NT), 0, stream,
+                                           buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
+                                           p.n, p.NB, p.L, p.chunks_per_win, w0);
+                    }
+                }
                 // (fields with their own records read them at their own stride and ignore this one)
-                if (flagged)
+                if (by_pairs) {}
+                else if (flagged)
                     hipLaunchKernelGGL((k_accumulate<fp_d, true>), grid, dim3(256), 0, stream,
                                        buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
                                        p.n, p.NB, p.L, p.chunks_per_win, w0);

@@ -27,11 +27,48 @@
 #include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
 #include "../../sppark_amd/csrc/ec/jacobian_host.hpp"
 #include "../../sppark_amd/csrc/ff/fp2_host.hpp"
+#ifdef SPPARK_G2
+#include "../../sppark_amd/csrc/msm/msm_g2c_kernels.hpp"
+#endif
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 using namespace sppark_amd;
+
+// Work-groups that meet at barriers (the cooperative G2 accumulation, msm/msm_g2c_kernels.hpp: a pair of waves = 128 host
+// threads here; as tests/emu/emu_coop.cpp does for the four-wave operations): the two hooks of ec/xyzz_coop.hpp
+namespace {
+struct wg_barrier {
+    std::mutex m; std::condition_variable cv;
+    unsigned count = 0, gen = 0, n = 128;
+    int vote = 0, result = 0;
+    int wait(int v)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        vote |= v;
+        const unsigned g = gen;
+        if (++count == n) { result = vote; vote = 0; count = 0; gen++; cv.notify_all(); return result; }
+        cv.wait(lk, [&] { return gen != g; });
+        return result;
+    }
+} g_bar;
+void run_group(unsigned nthreads, const std::function<void(unsigned)>& body)
+{
+    g_bar.n = nthreads;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++) th.emplace_back(body, t);
+    for (auto& t : th) t.join();
+}
+int g_g2c = 0;              // the G2 accumulation by wave pairs (msm_tunables::g2_coop)
+} // namespace
+extern "C" void sppark_emu_barrier() { (void)g_bar.wait(0); }
+extern "C" int sppark_emu_barrier_or(int v) { return g_bar.wait(v); }
+extern "C" void emu_g2c(int on) { g_g2c = on; }
 
 // plan/tunables only (no HIP runtime needed)
 struct msm_plan { unsigned n, wbits, nwins, nbits, NB, HB, LB, NA, L, chunks_per_win, nslabs, slab_sz, F, K; };
@@ -233,6 +270,23 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     // fields with their own records (ff/montx_dev.hpp): k_convert_points first, as msm_driver.hpp does
     std::vector<uint4> conv;
     pts = convert_points<inst_fp>(conv, pts, npoints, stride, flagged);
+#ifdef SPPARK_G2
+    if constexpr (field_is_internal<inst_fp>::value && !field_is_montx<inst_fp>::value) {
+        if (g_g2c) {                                // k_accumulate_g2c: 64 chunks per pair of waves
+            static g2c_lds<inst_fp> ex;
+            for (unsigned w = 0; w < p.nwins; w++)
+                for (unsigned c0 = 0; c0 < ((p.chunks_per_win + 63) / 64) * 64; c0 += 64)
+                    run_group(G2C_NT, [&](unsigned tid) {
+                        const g2c_ctx<inst_fp> c{&ex, tid >> 6, tid & 63};
+                        if (c.role == 0) accumulate_chunk_g2c<inst_fp, false, 0>(buckets.data(), keyA.data(), ptA.data(), pts, sorted.data(), off.data(),
+                                                                                 p.n, p.NB, p.L, p.chunks_per_win, c0 + c.lane, w, 0, c);
+                        else             accumulate_chunk_g2c<inst_fp, false, 1>(buckets.data(), keyA.data(), ptA.data(), pts, sorted.data(), off.data(),
+                                                                                 p.n, p.NB, p.L, p.chunks_per_win, c0 + c.lane, w, 0, c);
+                    });
+        }
+    }
+    if (!g_g2c)
+#endif
     for (unsigned w = 0; w < p.nwins; w++)
         for (unsigned chunk = 0; chunk < ((p.chunks_per_win + 255) / 256) * 256; chunk++) {
             if (flagged) accumulate_chunk<inst_fp, true>(buckets.data(), keyA.data(), ptA.data(), pts, (unsigned)stride,
@@ -412,6 +466,58 @@ extern "C" int emu_fp2x_op(int op, int ka, void* out, const void* a, const void*
 // The bucket invariant of ec/xyzzx2_dev.hpp under a chain of operations: after every step the accumulator's internal
 // image (X | Y | ZZZ | ZZ, 4 * N words) is appended to |out|.  Steps: set(p0); madd(p_i, i odd) for i < n; then
 // add(copy of the state after n/2 steps); dbl(); madd(p_0) again.  G2 builds only (returns the number of images, 0 otherwise).
+// The same chain of set / madd steps as emu_g2_chain's first part, run by the COOPERATIVE bucket class for 64 lanes at
+// once: lane l starts at point l and adds points l+1, l+2, ... (indices mod n), lane 3 additionally meets its own start
+// point again right away (the doubling case), lane 5 the negated start point (infinity), lane 7 starts from a point at
+// infinity when one is in the list.  After every step every lane's image is appended to |out| (64 images per step) --
+// and to |ref| the image of the serial class run on the same sequence.  Returns the number of steps (0: not a G2 build).
+extern "C" int emu_g2c_chain(void* out, void* ref, const unsigned char* points, size_t stride, size_t n, unsigned steps)
+{
+#ifdef SPPARK_G2
+    if constexpr (field_is_internal<inst_fp>::value && !field_is_montx<inst_fp>::value) {
+        typedef xyzz_dev<inst_fp> B;
+        std::vector<uint4> conv((size_t)n * affine_loader<inst_fp>::STRIDE / 16 + 1);
+        const bool flagged = stride > 2 * sizeof(fp2_host<curve_p::fp>);
+        for (size_t i = 0; i < n; i++) {
+            if (flagged) affine_loader<inst_fp>::template convert<true>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+            else         affine_loader<inst_fp>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+        }
+        const unsigned char* rec = (const unsigned char*)conv.data();
+        // entry s of lane l: (point index, negate)
+        auto entry = [&](unsigned l, unsigned s, size_t& idx, bool& neg) {
+            idx = (l + s) % n; neg = ((l + s) & 1) != 0;
+            if (l == 3 && s == 1) { idx = l % n; neg = (l & 1) != 0; }           // the same point again: doubling
+            if (l == 5 && s == 1) { idx = l % n; neg = (l & 1) == 0; }           // its negative: infinity
+        };
+        B::mem_t* o = (B::mem_t*)out; B::mem_t* rf = (B::mem_t*)ref;
+        for (unsigned l = 0; l < 64; l++) {                                      // serial reference
+            B acc; acc.set_inf();
+            for (unsigned s = 0; s < steps; s++) {
+                size_t idx; bool neg; entry(l, s, idx, neg);
+                const affine_dev<inst_fp> pt = load_affine<inst_fp, false>(rec, idx, 0);
+                if (s == 0) acc.set(pt, neg); else acc.madd(pt, neg);
+                acc.store(&rf[(size_t)s * 64 + l]);
+            }
+        }
+        static g2c_lds<inst_fp> ex;
+        run_group(G2C_NT, [&](unsigned tid) {
+            const g2c_ctx<inst_fp> c{&ex, tid >> 6, tid & 63};
+            g2c_bucket<inst_fp> acc; acc.set_inf();
+            for (unsigned s = 0; s < steps; s++) {
+                size_t idx; bool neg; entry(c.lane, s, idx, neg);
+                const g2c_affine<inst_fp> pt = g2c_affine<inst_fp>::load(rec, idx, c.role);
+                bool restart = s == 0;
+                if (pt.inf && restart) { acc.set_inf(); restart = false; }
+                if (c.role == 0) acc.template madd<0>(pt, neg, restart, c); else acc.template madd<1>(pt, neg, restart, c);
+                acc.store(&o[(size_t)s * 64 + c.lane], c.role);
+            }
+        });
+        return (int)steps;
+    }
+#endif
+    (void)out; (void)ref; (void)points; (void)stride; (void)n; (void)steps;
+    return 0;
+}
 extern "C" int emu_g2_chain(void* out, const unsigned char* points, size_t stride, size_t n)
 {
 #ifdef SPPARK_G2

@@ -98,3 +98,19 @@ def test_cooperative_kernels_fit_one_work_group_per_cu():
         # sized by the driver (top_bits_coop_lds) under the 160 KB of a CU
         assert int(md.get("group_segment_fixed_size") or 0) <= 40 * 1024, (name[:60], md)
         assert int(md.get("private_segment_fixed_size") or 0) <= 1280, (name[:60], "scratch", md)
+
+
+@pytest.mark.parametrize("obj", ["bls12_381__msm_k_accumulate.hip__SPPARK_G2.o", "bn254__msm_k_accumulate.hip__SPPARK_G2.o",
+                                 "bls12_377__msm_k_accumulate.hip__SPPARK_G2.o"])
+def test_g2_one_component_per_wave_kernel_fits_two_waves_per_simd(obj):
+    """k_accumulate_g2c (msm_g2c_kernels.hpp; not the default path): a pair of waves per 64 chunks is only worth having
+    if BOTH fit a SIMD twice over -- at most 256 registers, no scratch (the two earlier attempts at two G2 waves per
+    SIMD died of spills), and four 128-lane work-groups' exchange areas within a CU's 160 KB of LDS."""
+    meta = _kernels(obj)
+    hit = {k: v for k, v in meta.items() if "k_accumulate_g2c" in k and "vgpr_count" in v}
+    assert len(hit) == 1, sorted(meta)
+    md = next(iter(hit.values()))
+    assert int(md.get("max_flat_workgroup_size") or 0) == 128
+    assert int(md.get("vgpr_count") or 0) <= 256, md
+    assert int(md.get("private_segment_fixed_size") or 0) == 0, md
+    assert 4 * int(md.get("group_segment_fixed_size") or 0) <= 160 * 1024, md

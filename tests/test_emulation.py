@@ -38,6 +38,9 @@ def _emu(feature, g2=False):
     L.emu_fixed_base.argtypes = [vp, vp, sz, sz, vp, cu]
     L.emu_fp2x_op.argtypes = [ci, ci, vp, vp, vp, sz]
     L.emu_g2_chain.argtypes = [vp, vp, sz, sz]
+    L.emu_g2c_chain.argtypes = [vp, vp, vp, sz, sz, cu]
+    L.emu_g2c.argtypes = [ci]
+    L.emu_g2c.restype = None
     return L
 
 
@@ -103,6 +106,41 @@ def test_msm_g2_pipeline_on_host(oracle, curve):
         out = np.zeros(3 * fb, dtype=np.uint8)
         L.emu_msm(P(out), P(p_), p_.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2, 1, None, 0)
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, p_, s_, algo=0, param=4)).all()
+
+
+@pytest.mark.parametrize("curve", [2, 3, 5])
+def test_g2_one_component_per_wave_on_host(oracle, curve):
+    """ec/xyzz2_coop.hpp + msm/msm_g2c_kernels.hpp (NOT the default path: msm_tunables::g2_coop): the G2 bucket with one
+    Fp2 component per wave, a pair of waves = 128 host threads meeting at the barriers of the exchange.
+    (i) chains of set / madd steps on 64 lanes -- a lane that meets its start point again (the cooperative doubling), one
+    that meets its negative (infinity, then a fresh start), points at infinity in the list -- leave BIT-IDENTICAL images
+    to the serial class after every step; (ii) the whole G2 MSM on the host with the accumulation run by wave pairs
+    equals the oracle, ragged chunk counts, flagged and plain records, the all-equal-points case included."""
+    O = oracle
+    L = _emu({2: "BLS12_381", 3: "BN254", 5: "BLS12_377"}[curve], g2=True)
+    fb = O.FP_BYTES[curve]
+    words = {2: 28, 3: 20, 5: 28}[curve] * 4                    # internal XYZZ image: 4 coordinates x 2 components x NL limbs
+    pts, _sc = recipe.msm_inputs(curve, 70, 99, flagged=True)     # (edge cases on: the list holds points at infinity)
+    steps = 6
+    out = np.zeros((steps * 64, words), dtype=np.uint32); ref = np.zeros_like(out)
+    assert L.emu_g2c_chain(P(out), P(ref), P(pts), pts.shape[1], pts.shape[0], steps) == steps
+    assert (out == ref).all(), np.argwhere((out != ref).any(axis=1))[:8].ravel()
+    assert ref.any()
+    try:
+        L.emu_g2c(1)
+        for n, wb, LL, F, K, ns, flagged in ((1, 0, 0, 0, 0, 0, True), (33, 0, 0, 0, 0, 0, False), (600, 0, 0, 0, 0, 0, True),
+                                             (500, 7, 4, 4, 2, 3, False), (300, 11, 16, 8, 4, 2, True)):
+            p_, s_ = recipe.msm_inputs(curve, n, 4321 + n + wb, flagged=flagged)
+            res = np.zeros(3 * fb, dtype=np.uint8)
+            L.emu_msm(P(res), P(p_), p_.shape[1], n, P(s_), 0, wb, LL, F, K, ns, 1, None, 0)
+            assert (O.jac_to_affine(curve, res) == O.msm_affine(curve, p_, s_, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
+        p_, s_ = recipe.msm_inputs(curve, 400, 5, edge=False, flagged=True)
+        same = p_.copy(); same[:] = p_[0]
+        res = np.zeros(3 * fb, dtype=np.uint8)
+        L.emu_msm(P(res), P(same), same.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2, 1, None, 0)
+        assert (O.jac_to_affine(curve, res) == O.msm_affine(curve, same, s_, algo=0, param=4)).all()
+    finally:
+        L.emu_g2c(0)
 
 
 def test_msm_skewed_scalars_on_host(oracle):

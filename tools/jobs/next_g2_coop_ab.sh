@@ -1,0 +1,10 @@
+#!/bin/bash
+# PREPARED FOR THE NEXT ROUND (never run: round 4's GPU budget was spent when it was written).
+# The G2 accumulation with one Fp2 component per wave (SPPARK_G2_COOP=1; ec/xyzz2_coop.hpp, msm/msm_g2c_kernels.hpp):
+# parity of the G2 GPU tests with the switch on, then the A/B at 2^20 / 2^22.  Everything under short timeouts.
+mkdir -p gpurun_out; out=gpurun_out/next_g2_coop_ab.log; : > $out
+SPPARK_G2_COOP=1 timeout 400 python -m pytest tests/test_msm_gpu.py -q -x -m gpu -k "g2" --timeout 120 2>&1 | tail -4 | tee -a $out
+for sw in 0 1; do
+  echo "== SPPARK_G2_COOP=$sw" | tee -a $out
+  SPPARK_G2_COOP=$sw timeout 200 python tools/gpu_g2_bench.py 2>&1 | grep -v amdgpu | tee -a $out
+done

@@ -11,7 +11,9 @@ SPPARK_NTT_PASS_ALL(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
 #if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // wide fields stop at 4 stages per pass in registers ...
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
 #else                                                              // ... and run up to 8 with one stage per round
-template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), false>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
-template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), true>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+#define SPPARK_NTT_LAT_DEFINE(INV, R) \
+    template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), INV, R>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+SPPARK_NTT_LAT_DEFINE(false, 0) SPPARK_NTT_LAT_DEFINE(true, 0)
+SPPARK_NTT_LAT_DEFINE(false, 2) SPPARK_NTT_LAT_DEFINE(true, 2) SPPARK_NTT_LAT_DEFINE(false, 3) SPPARK_NTT_LAT_DEFINE(true, 3)     // (SPPARK_NTT_LAT_TAIL)
 #endif
 }

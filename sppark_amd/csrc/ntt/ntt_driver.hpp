@@ -226,9 +226,12 @@ public:
 
         // tuning knobs (tools/gpu_ntt_sweep.py), read once per process; the LDS tile is clamped to what
         // the element size allows (160 KB per work-group: 2^14 eight-byte elements, 2^12 32-byte ones)
-        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; };
+        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; unsigned lat_tail; };
         static const knobs_t knobs = [] {
-            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1};
+            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1, 0};
+            // 2 or 3: that many small-half stages of a one-stage-per-round pass in registers (ntt_lat_tail_dif / _head_dit);
+            // NOT the default -- host-emulated only so far
+            if (const char* e = getenv("SPPARK_NTT_LAT_TAIL")) { unsigned v = (unsigned)atoi(e); if (v == 2 || v == 3) k.lat_tail = v; }
             // 256-bit fields: stages per one-stage-per-round pass (0: the register passes), columns per tile row and tile
             // elements (log2; default: by size, lat_shape())
             if (const char* e = getenv("SPPARK_NTT_LAT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v <= 8) k.lat_smax = R64 ? 0 : v; }
@@ -320,12 +323,18 @@ public:
             unsigned tiles = (unsigned)(n / tile_elems);
             if constexpr (!R64) {
                 if (lat) {                                      // one butterfly per lane and stage, the tile in LDS throughout
-                    const unsigned lanes = (unsigned)std::min<size_t>(std::max<size_t>(tile_elems / 2, 64), 1024);
+                    const unsigned tail = knobs.lat_tail && P.S >= knobs.lat_tail ? knobs.lat_tail : 0;
+                    const unsigned lanes = (unsigned)std::min<size_t>(std::max<size_t>(tile_elems / 2, 64), tail ? 512 : 1024);
                     const size_t lat_lds = tile_elems * sizeof(F);
-                    if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, true, true>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);
-                              else         hipLaunchKernelGGL((k_ntt_pass_lat<F, true, false>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); }
-                    else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, false, true>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);
-                              else         hipLaunchKernelGGL((k_ntt_pass_lat<F, false, false>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); }
+#define SPPARK_LAT_LAUNCH(R)                                                                                   \
+                    do {                                                                                       \
+                        if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, true, true, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);    \
+                                  else         hipLaunchKernelGGL((k_ntt_pass_lat<F, true, false, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); } \
+                        else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, false, true, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);   \
+                                  else         hipLaunchKernelGGL((k_ntt_pass_lat<F, false, false, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); } \
+                    } while (0)
+                    if (tail == 3) SPPARK_LAT_LAUNCH(3); else if (tail == 2) SPPARK_LAT_LAUNCH(2); else SPPARK_LAT_LAUNCH(0);
+#undef SPPARK_LAT_LAUNCH
                     continue;
                 }
             }

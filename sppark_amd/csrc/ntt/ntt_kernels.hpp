@@ -401,20 +401,77 @@ SPPARK_DEVFN void ntt_lat_store(F* data, const F* tile, const ntt_tables<F>& T, 
         data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c] = x;
     }
 }
-template<class F, bool DIF, bool INV>
-__global__ __launch_bounds__(1024)
+// The R stages with the SMALL halves (the last ones of a DIF pass, the first ones of a DIT pass) in REGISTERS, fused with the
+// store / the load: they act on groups of 2^R consecutive rows, i.e. they are radix_dif<R> / radix_dit<R> of those rows,
+// whose twiddles w_{2^R}^k are compile-time indices -- the k = 0 ones cost nothing there, whereas a stage of the round
+// form executes its product for the whole wave when any lane's twiddle is not 1: 0.625 instead of 1.0 executed products
+// per element for R = 3, and three LDS round trips and barriers less.  The price is 2^R elements per lane in that phase
+// (a quarter of the lanes busy): a gain where a pass is throughput-bound, a loss on the small latency-bound transforms.
+// NOT the default (SPPARK_NTT_LAT_TAIL=R; written at the end of round 4 without GPU time: host-emulated only).
+// fn(0), fn(1), ..., fn(N - 1) as N separate inlined calls: `#pragma unroll` gives up on a loop whose body holds a 256-bit
+// product (the element array would then be indexed at run time, i.e. live in scratch)
+template<unsigned I, unsigned N> struct ntt_static_for {
+    template<class Fn> SPPARK_DEVFN static void run(Fn&& fn) { fn(I); ntt_static_for<I + 1, N>::run(fn); }
+};
+template<unsigned N> struct ntt_static_for<N, N> { template<class Fn> SPPARK_DEVFN static void run(Fn&&) {} };
+
+template<class F, bool INV, unsigned R>
+SPPARK_DEVFN void ntt_lat_tail_dif(F* data, const F* tile, const ntt_tables<F>& T, const ntt_pass& P, size_t tile_id, unsigned tid, unsigned nt)
+{
+    const ntt_tile_geom geo = ntt_geom(P, tile_id);
+    const unsigned elems = 1u << (P.lgG + P.S + P.lgC), C = 1u << P.lgC;
+    for (unsigned gi = tid; gi < (elems >> R); gi += nt) {
+        const unsigned c = gi & (C - 1), grp = gi >> P.lgC;
+        F x[1u << R];
+        #pragma unroll
+        for (unsigned a = 0; a < (1u << R); a++) x[a] = ntt_lat_get(tile, (((grp << R) + a) << P.lgC) + c, elems);
+        radix_dif<F, INV, R>(x, T.inner);
+        ntt_static_for<0, (1u << R)>::run([&](unsigned a) {
+            const unsigned gm = (grp << R) + a;
+            F y = x[a];
+            if (geo.lgQ) y = y * ntt_lat_twiddle(T, P, geo, gm & ((1u << P.S) - 1), c);
+            if (P.apply_scale) y = y * T.scale;
+            data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c] = y;
+        });
+    }
+}
+template<class F, bool INV, unsigned R>
+SPPARK_DEVFN void ntt_lat_head_dit(const F* data, F* tile, const ntt_tables<F>& T, const ntt_pass& P, size_t tile_id, unsigned tid, unsigned nt)
+{
+    const ntt_tile_geom geo = ntt_geom(P, tile_id);
+    const unsigned elems = 1u << (P.lgG + P.S + P.lgC), C = 1u << P.lgC;
+    for (unsigned gi = tid; gi < (elems >> R); gi += nt) {
+        const unsigned c = gi & (C - 1), grp = gi >> P.lgC;
+        F x[1u << R];
+        ntt_static_for<0, (1u << R)>::run([&](unsigned a) {
+            const unsigned gm = (grp << R) + a;
+            x[a] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
+            if (geo.lgQ) x[a] = x[a] * ntt_lat_twiddle(T, P, geo, gm & ((1u << P.S) - 1), c);
+        });
+        radix_dit<F, INV, R>(x, T.inner);
+        #pragma unroll
+        for (unsigned a = 0; a < (1u << R); a++) ntt_lat_put(tile, (((grp << R) + a) << P.lgC) + c, elems, x[a]);
+    }
+}
+// R = 0: every stage a round.  R > 0 (P.S >= R): the small-half stages in registers.
+// (with a register phase: at most 512 lanes, so that the 2^R elements of a lane have 256 registers to live in)
+template<class F, bool DIF, bool INV, unsigned R = 0>
+__global__ __launch_bounds__(R ? 512 : 1024)
 void k_ntt_pass_lat(F* data, ntt_tables<F> T, ntt_pass P)
 {
     extern __shared__ unsigned char ntt_lds[];
     F* tile = reinterpret_cast<F*>(ntt_lds);
     const unsigned tid = threadIdx.x, nt = blockDim.x;
-    ntt_lat_load<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+    if (DIF || R == 0) ntt_lat_load<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+    else               ntt_lat_head_dit<F, INV, R>(data, tile, T, P, blockIdx.x, tid, nt);
     __syncthreads();
-    for (unsigned t = 0; t < P.S; t++) {
+    // DIF: stages 0 .. S-R-1 as rounds, then the tail; DIT: the head did stages 0 .. R-1, rounds R .. S-1
+    for (unsigned t = DIF ? 0 : R; t < (DIF ? P.S - R : P.S); t++) {
         ntt_lat_stage<F, DIF, INV>(tile, T, P, t, tid, nt);
         __syncthreads();
     }
-    ntt_lat_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+    if (DIF && R != 0) ntt_lat_tail_dif<F, INV, R>(data, tile, T, P, blockIdx.x, tid, nt);
+    else               ntt_lat_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
 }
 
 // (R1, R2) = (ceil(S/2), floor(S/2)); CALL(R1, R2) is expanded for the pass's S

@@ -31,6 +31,8 @@ def _emu(feature):
     L.emu_ntt_lat.restype = None
     L.emu_ntt_lat_plan.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
     L.emu_ntt_lat_plan.restype = ctypes.c_uint
+    L.emu_ntt_lat_tail.argtypes = [ctypes.c_uint]
+    L.emu_ntt_lat_tail.restype = None
     return L
 
 
@@ -131,12 +133,15 @@ def test_ntt_one_stage_per_round_passes_on_host(oracle, field, feature):
         f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
     try:
         L.emu_ntt_plan(99, 20)                                      # (Goldilocks: generic passes, not the radix-64 plan)
-        for smax, lgc, lgtile in ((8, -1, -1), (8, 2, 10), (8, 0, 8), (6, 4, 11), (5, 1, 9), (3, 2, 6)):
+        # (tail: SPPARK_NTT_LAT_TAIL -- the 2 or 3 small-half stages of a pass in registers, fused with its store / load)
+        for smax, lgc, lgtile, tail in ((8, -1, -1, 0), (8, 2, 10, 0), (8, 0, 8, 0), (6, 4, 11, 0), (5, 1, 9, 0), (3, 2, 6, 0),
+                                        (8, -1, -1, 3), (8, 2, 10, 2), (6, 4, 11, 3), (5, 1, 9, 3), (3, 2, 6, 2)):
             if field == "gl64" and smax > 6:
                 continue
             L.emu_ntt_lat(smax, lgc, lgtile)
+            L.emu_ntt_lat_tail(tail)
             for lg in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13):
-                if lg > 11 and (smax, lgc) not in ((8, -1), (6, 4)):
+                if lg > 11 and (smax, lgc, tail) not in ((8, -1, 0), (6, 4, 0), (8, -1, 3)):
                     continue
                 x = recipe.ntt_input(field, lg, 500 + lg)
                 for order in range(4):
@@ -146,8 +151,9 @@ def test_ntt_one_stage_per_round_passes_on_host(oracle, field, feature):
                                 continue
                             y = x.copy()
                             L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 9 else 256)
-                            assert (y == f(x, order, direction, typ)).all(), (field, smax, lgc, lgtile, lg, order, direction, typ)
+                            assert (y == f(x, order, direction, typ)).all(), (field, smax, lgc, lgtile, tail, lg, order, direction, typ)
     finally:
+        L.emu_ntt_lat_tail(0)
         L.emu_ntt_lat(8 if field in ("bls12_381", "bn254") else 0, -1, -1)      # the engine's defaults
         L.emu_ntt_plan(12, 20)
 

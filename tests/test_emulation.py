@@ -128,16 +128,16 @@ def test_g2_one_component_per_wave_on_host(oracle, curve):
     assert ref.any()
     try:
         L.emu_g2c(1)
-        for n, wb, LL, F, K, ns, flagged in ((1, 0, 0, 0, 0, 0, True), (33, 0, 0, 0, 0, 0, False), (600, 0, 0, 0, 0, 0, True),
-                                             (500, 7, 4, 4, 2, 3, False), (300, 11, 16, 8, 4, 2, True)):
+        # (every 64 chunks of a window are 128 host threads here: sizes kept small)
+        for n, wb, LL, F, K, ns, flagged in ((1, 16, 4, 4, 2, 1, True), (70, 13, 4, 4, 2, 3, False), (300, 13, 16, 8, 4, 2, True)):
             p_, s_ = recipe.msm_inputs(curve, n, 4321 + n + wb, flagged=flagged)
             res = np.zeros(3 * fb, dtype=np.uint8)
             L.emu_msm(P(res), P(p_), p_.shape[1], n, P(s_), 0, wb, LL, F, K, ns, 1, None, 0)
             assert (O.jac_to_affine(curve, res) == O.msm_affine(curve, p_, s_, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
-        p_, s_ = recipe.msm_inputs(curve, 400, 5, edge=False, flagged=True)
+        p_, s_ = recipe.msm_inputs(curve, 150, 5, edge=False, flagged=True)
         same = p_.copy(); same[:] = p_[0]
         res = np.zeros(3 * fb, dtype=np.uint8)
-        L.emu_msm(P(res), P(same), same.shape[1], 400, P(s_), 0, 8, 8, 4, 4, 2, 1, None, 0)
+        L.emu_msm(P(res), P(same), same.shape[1], 150, P(s_), 0, 13, 8, 4, 4, 2, 1, None, 0)
         assert (O.jac_to_affine(curve, res) == O.msm_affine(curve, same, s_, algo=0, param=4)).all()
     finally:
         L.emu_g2c(0)

@@ -24,7 +24,10 @@ namespace sppark_amd {
 
 // exchange area of one wave pair: five slots of [component][limb][lane] words (limb-major, lane-contiguous: conflict-free)
 // and one flag word per component and lane
-template<class F2> struct g2c_lds { u32 w[5][2][F2::NL][64]; u32 flag[2][64]; };
+template<class F2> struct g2c_lds {
+    u32 w[5][2][F2::NL][64]; u32 flag[2][64];
+    SPPARK_BND(double bv[5][2][64]; double bl[5][2][64];)       // (host bound tracking: the claims travel with the limbs)
+};
 
 template<class F2> struct g2c_ctx {
     typedef typename F2::fp fp;
@@ -34,12 +37,14 @@ template<class F2> struct g2c_ctx {
     {
         #pragma unroll
         for (int j = 0; j < F2::NL; j++) ex->w[slot][role][j][lane] = v.l[j];
+        SPPARK_BND(ex->bv[slot][role][lane] = v.bv; ex->bl[slot][role][lane] = v.bl;)
     }
     SPPARK_DEVFN fp other(unsigned slot) const
     {
         fp r;
         #pragma unroll
         for (int j = 0; j < F2::NL; j++) r.l[j] = ex->w[slot][role ^ 1][j][lane];
+        SPPARK_BND(r.bnd_set(ex->bv[slot][role ^ 1][lane], ex->bl[slot][role ^ 1][lane]);)
         return r;
     }
     SPPARK_DEVFN void put_flag(u32 f) const { ex->flag[role][lane] = f; }

@@ -27,7 +27,10 @@ namespace sppark_amd {
 
 // exchange area of one work-group: two sets (alternating per level, so that a level's writes never meet the previous
 // level's reads) of four slots of NL x 64 words
-template<class F> struct coop_lds { u32 w[2][4][F::NL][64]; };
+template<class F> struct coop_lds {
+    u32 w[2][4][F::NL][64];
+    SPPARK_BND(double bv[2][4][64]; double bl[2][4][64];)      // (host bound tracking: the claims travel with the limbs)
+};
 
 // Work-group barrier / barrier with an OR-vote.  Host emulation (tests/emu/emu_coop.cpp) runs a work-group as 256 host
 // threads and supplies the two hooks.
@@ -61,6 +64,7 @@ template<class F> struct coop_ctx {
     {
         #pragma unroll
         for (int j = 0; j < F::NL; j++) ex->w[par][slot][j][lane] = v.l[j];
+        SPPARK_BND(ex->bv[par][slot][lane] = v.bv; ex->bl[par][slot][lane] = v.bl;)
     }
     // (reads the set written by the level that just ended: call after next_level())
     SPPARK_DEVFN F get(unsigned slot) const
@@ -68,6 +72,7 @@ template<class F> struct coop_ctx {
         F r;
         #pragma unroll
         for (int j = 0; j < F::NL; j++) r.l[j] = ex->w[par ^ 1][slot][j][lane];
+        SPPARK_BND(r.bnd_set(ex->bv[par ^ 1][slot][lane], ex->bl[par ^ 1][slot][lane]);)
         return r;
     }
     SPPARK_DEVFN void next_level() { coop_barrier(); par ^= 1; }

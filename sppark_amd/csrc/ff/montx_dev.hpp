@@ -71,6 +71,9 @@ SPPARK_DEVFN void macxs2(u64& acc0, u32 a0, u64& acc1, u32 a1, u32 b)
 #endif
 }
 
+#if defined(SPPARK_HOST_EMULATION) && defined(SPPARK_TRACK_BOUNDS)
+extern "C" void sppark_bound_violation(const char* what, double got, double limit);
+#endif
 template<class P, int LB> struct montx_dev {
     static constexpr int NW = P::N;                         // 32-bit words of the standard wire form
     static constexpr int NL = (P::NBITS + 8 + LB - 1) / LB; // >= 8 bits of head-room above the modulus
@@ -80,6 +83,31 @@ template<class P, int LB> struct montx_dev {
     static_assert((double)NL * (double)(1ull << 31) * (double)(1ull << LB) + (double)NL * (double)(1ull << LB) * (double)(1ull << LB)
                   < 18446744073709551616.0, "a column (one fat operand) must fit the 64-bit accumulator");
     u32 l[NL];
+
+    // ---- machine-checked contracts (host emulation only: tests/emu/emu_bounds.cpp, -DSPPARK_TRACK_BOUNDS) ----------------
+    // Every value carries what the comments of this file and of ec/xyzzx*_dev.hpp CLAIM about it -- value < bv * p, every
+    // limb <= bl * (2^LB - 1), so that sums of normalised values and the fat constants of sub / neg are exact: a fat limb
+    // is below (B + 1) 2^LB, and "limbs < 2^31" reads bl <= 2^(31-LB) -- every operation checks its operands against its stated contract and derives the claim of its
+    // result from the rules written at its definition.  The numbers in the limbs play no part: what is checked is the
+    // worst case the bounds allow, for ALL inputs, not the sample that happens to be run.  Compiled out everywhere else.
+#if defined(SPPARK_HOST_EMULATION) && defined(SPPARK_TRACK_BOUNDS)
+# define SPPARK_BND(...) __VA_ARGS__
+    double bv = -1.0, bl = -1.0;                                // unset until a rule or the harness sets them
+    static double rho()                                         // 2^RBITS / p
+    {
+        double p = 0.0;
+        for (int i = NW - 1; i >= 0; i--) p = p * 4294967296.0 + (double)P::MOD[i];
+        double r = 1.0;
+        for (int i = 0; i < RBITS; i++) r *= 2.0;
+        return r / p;
+    }
+    static constexpr double FAT_LEFT = (double)(1u << (31 - LB));   // limbs < 2^31 in units of 2^LB
+    static void bnd(bool ok, const char* what, double got, double lim) { if (!ok) sppark_bound_violation(what, got, lim); }
+    void bnd_set(double v, double lm) { bv = v; bl = lm; }
+    void bnd_known(const char* what) const { bnd(bv >= 0.0 && bl >= 0.0, what, bv, 0.0); }
+#else
+# define SPPARK_BND(...)
+#endif
 
     SPPARK_DEVFN static constexpr u32 limb_of(const u32* w, int j)
     {
@@ -143,7 +171,7 @@ template<class P, int LB> struct montx_dev {
 
     // 1 in the internal domain = 2^RBITS mod p
     SPPARK_DEVFN static montx_dev one()
-    {   montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = pow2_tab<RBITS - 32 * NW>::T.l[j]; return r;   }
+    {   montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = pow2_tab<RBITS - 32 * NW>::T.l[j]; SPPARK_BND(r.bnd_set(1.0, 1.0);) return r;   }
 
     // standard wire form (x * 2^(32 NW), 32-bit words, canonical) -> internal (x * 2^RBITS),
     // normalised, < 2p:  w * 2^(2*RBITS - 32 NW) / 2^RBITS
@@ -152,6 +180,7 @@ template<class P, int LB> struct montx_dev {
         montx_dev a, k;
         #pragma unroll
         for (int j = 0; j < NL; j++) { a.l[j] = limb_of(w, j); k.l[j] = pow2_tab<2 * (RBITS - 32 * NW)>::T.l[j]; }
+        SPPARK_BND(a.bnd_set(1.0, 1.0); k.bnd_set(1.0, 1.0);)       // canonical wire words, a constant below p
         return a * k;
     }
     // internal (any admissible lazy value: limbs < 2^31) -> canonical standard wire words:
@@ -161,12 +190,15 @@ template<class P, int LB> struct montx_dev {
         montx_dev k;
         #pragma unroll
         for (int j = 0; j < NL; j++) k.l[j] = pow2_tab<0>::T.l[j];
+        SPPARK_BND(k.bnd_set(1.0, 1.0);)
         (*this * k).cond_sub_p().to_words(w);                       // the product: < v*p/2^RBITS + p < 2p
     }
     // a normalised value < 2p -> its canonical representative: r - p if r >= p, limb-wise with borrow
     SPPARK_DEVFN montx_dev cond_sub_p() const
     {
+        SPPARK_BND(bnd_known("cond_sub_p: operand"); bnd(bl <= 1.0, "cond_sub_p: normalised", bl, 1.0); bnd(bv <= 2.0, "cond_sub_p: < 2p", bv, 2.0);)
         montx_dev r = *this;
+        SPPARK_BND(r.bnd_set(1.0, 1.0);)
         u32 d[NL]; int bw = 0;
         #pragma unroll
         for (int j = 0; j < NL; j++) {
@@ -203,7 +235,7 @@ template<class P, int LB> struct montx_dev {
     {   montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = w[j]; return r;   }
     SPPARK_DEVFN void to_wire(u32* w) const { for (int j = 0; j < NL; j++) w[j] = l[j]; }
 
-    SPPARK_DEVFN static montx_dev zero() { montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = 0; return r; }
+    SPPARK_DEVFN static montx_dev zero() { montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = 0; SPPARK_BND(r.bnd_set(0.0, 0.0);) return r; }
     SPPARK_DEVFN bool limbs_all_zero() const
     {   u32 acc = l[0]; for (int j = 1; j < NL; j++) acc |= l[j]; return acc == 0;   }
 
@@ -214,6 +246,8 @@ template<class P, int LB> struct montx_dev {
         #pragma unroll
         for (int j = 0; j < NL - 1; j++) { u32 v = l[j] + c; r.l[j] = v & MASK; c = v >> LB; }
         r.l[NL - 1] = l[NL - 1] + c;
+        // (limb + carry must not wrap: limbs <= 15 * 2^LB; the top limb of a value < bv p is far below 2^LB)
+        SPPARK_BND(bnd_known("norm: operand"); bnd(bl <= 15.0, "norm: limbs", bl, 15.0); r.bnd_set(bv, bl < 1.0 ? bl : 1.0);)
         return r;
     }
 
@@ -223,6 +257,7 @@ template<class P, int LB> struct montx_dev {
         montx_dev r;
         #pragma unroll
         for (int j = 0; j < NL; j++) r.l[j] = a.l[j] + b.l[j];
+        SPPARK_BND(a.bnd_known("+: left"); b.bnd_known("+: right"); r.bnd_set(a.bv + b.bv, a.bl + b.bl); bnd(r.bl < 16.0, "+: limbs wrap", r.bl, 16.0);)
         return r;
     }
 
@@ -233,6 +268,11 @@ template<class P, int LB> struct montx_dev {
         montx_dev r;
         #pragma unroll
         for (int j = 0; j < NL; j++) r.l[j] = a.l[j] + (fat_tab<K, B>::T.l[j] - b.l[j]);
+        SPPARK_BND(a.bnd_known("sub: minuend"); b.bnd_known("sub: subtrahend");
+                   bnd(b.bv <= (double)(K - 1), "sub<K>: subtrahend < (K-1) p", b.bv, (double)(K - 1));
+                   bnd(b.bl <= (double)B, "sub<K,B>: subtrahend's limbs <= B 2^LB", b.bl, (double)B);
+                   r.bnd_set(a.bv + (double)K, a.bl + (double)(B + 1));
+                   bnd(r.bl < 16.0, "sub: limbs wrap", r.bl, 16.0);)
         return r;
     }
     // K*p - b, same contract
@@ -241,6 +281,10 @@ template<class P, int LB> struct montx_dev {
         montx_dev r;
         #pragma unroll
         for (int j = 0; j < NL; j++) r.l[j] = fat_tab<K, B>::T.l[j] - b.l[j];
+        SPPARK_BND(b.bnd_known("neg: operand");
+                   bnd(b.bv <= (double)(K - 1), "neg<K>: operand < (K-1) p", b.bv, (double)(K - 1));
+                   bnd(b.bl <= (double)B, "neg<K,B>: operand's limbs <= B 2^LB", b.bl, (double)B);
+                   r.bnd_set((double)K, (double)(B + 1));)
         return r;
     }
 
@@ -283,6 +327,10 @@ template<class P, int LB> struct montx_dev {
             }
             A = shift_down(A);
         }
+        SPPARK_BND(a.bnd_known("*: left"); b.bnd_known("*: right");
+                   bnd(b.bl <= 1.0, "*: right operand normalised", b.bl, 1.0);
+                   bnd(a.bl <= FAT_LEFT + 1e-6, "*: left operand's limbs < 2^31", a.bl, FAT_LEFT);
+                   r.bnd_set(a.bv * b.bv / rho() + 1.0, 1.0);)
         return r;
     }
     // The Montgomery quotient digit of column k.  m = A * (-1/p) mod 2^LB makes A + m*p divisible by 2^LB;
@@ -329,6 +377,12 @@ template<class P, int LB> struct montx_dev {
             }
             A0 = shift_down(A0); A1 = shift_down(A1);
         }
+        SPPARK_BND(a0.bnd_known("mul2: a0"); b0.bnd_known("mul2: b0"); a1.bnd_known("mul2: a1"); b1.bnd_known("mul2: b1");
+                   bnd(b0.bl <= 1.0 && b1.bl <= 1.0, "mul2: right operands normalised", b0.bl > b1.bl ? b0.bl : b1.bl, 1.0);
+                   bnd(a0.bl <= (NORM0 ? 1.0 : FAT_LEFT) + 1e-6, NORM0 ? "mul2<NORM0>: a0 normalised" : "mul2: a0's limbs < 2^31", a0.bl, NORM0 ? 1.0 : FAT_LEFT);
+                   bnd(a1.bl <= (NORM1 ? 1.0 : FAT_LEFT) + 1e-6, NORM1 ? "mul2<NORM1>: a1 normalised" : "mul2: a1's limbs < 2^31", a1.bl, NORM1 ? 1.0 : FAT_LEFT);
+                   r0.bnd_set(a0.bv * b0.bv / rho() + 1.0 + (NORM0 ? 1e-6 : 0.0), 1.0);
+                   r1.bnd_set(a1.bv * b1.bv / rho() + 1.0 + (NORM1 ? 1e-6 : 0.0), 1.0);)
     }
     // (a0*b0 + a1*b1) / 2^RBITS with ONE Montgomery reduction (a sum of two products needs no more
     // than one: NL^2 multiply-adds saved against two separate products and a subtraction).
@@ -374,6 +428,11 @@ template<class P, int LB> struct montx_dev {
             }
             A = shift_down(A);
         }
+        SPPARK_BND(a0.bnd_known("mul_add: a0"); b0.bnd_known("mul_add: b0"); a1.bnd_known("mul_add: a1"); b1.bnd_known("mul_add: b1");
+                   bnd(b0.bl <= 1.0 && b1.bl <= 1.0, "mul_add: right operands normalised", b0.bl > b1.bl ? b0.bl : b1.bl, 1.0);
+                   bnd(a0.bl <= FAT_LEFT + 1e-6, "mul_add: a0's limbs < 2^31", a0.bl, FAT_LEFT);
+                   bnd(a1.bl <= 6.0, "mul_add: a1's limbs < 6 * 2^LB", a1.bl, 6.0);
+                   r.bnd_set((a0.bv * b0.bv + a1.bv * b1.bv) / rho() + 1.0, 1.0);)
         return r;
     }
 
@@ -407,6 +466,9 @@ template<class P, int LB> struct montx_dev {
             }
             A0 = shift_down(A0); A1 = shift_down(A1);
         }
+        SPPARK_BND(a0.bnd_known("sqr2: a0"); a1.bnd_known("sqr2: a1");
+                   bnd(a0.bl <= 1.0 && a1.bl <= 1.0, "sqr2: operands normalised", a0.bl > a1.bl ? a0.bl : a1.bl, 1.0);
+                   r0.bnd_set(a0.bv * a0.bv / rho() + 1.0 + 1e-6, 1.0); r1.bnd_set(a1.bv * a1.bv / rho() + 1.0 + 1e-6, 1.0);)
     }
 
     // a^2 / 2^RBITS.  Contract: limbs < 2^(LB+2) (cross products use the doubled operand:
@@ -444,6 +506,7 @@ template<class P, int LB> struct montx_dev {
             }
             A = shift_down(A);
         }
+        SPPARK_BND(bnd_known("sqr: operand"); bnd(bl <= 4.0, "sqr: limbs < 2^(LB+2)", bl, 4.0); r.bnd_set(bv * bv / rho() + 1.0, 1.0);)
         return r;
     }
 
@@ -471,6 +534,8 @@ template<class P, int LB> struct montx_dev {
     // the low limb filters out almost everything before the exact comparison.
     template<int KMAX> SPPARK_DEVFN bool is_zero_mod() const
     {
+        SPPARK_BND(bnd_known("is_zero_mod: operand"); bnd(bl <= 1.0, "is_zero_mod: normalised", bl, 1.0);
+                   bnd(bv <= (double)KMAX, "is_zero_mod<KMAX>: value < KMAX p", bv, (double)KMAX);)
         // (A one-multiply filter -- k*p has the low limb l[0] iff k = l[0] / p mod 2^LB -- saves ~30 scalar and
         // vector instructions per mixed addition, but hipcc then allocates 269 registers for k_accumulate
         // instead of 238: ONE wave per SIMD, 151 ms instead of 114 at 2^26 points.  Measured and reverted,

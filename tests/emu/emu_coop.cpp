@@ -156,3 +156,47 @@ extern "C" int emu_coop_points_differ(const void* a_, const void* b_, size_t n)
     }
     return bad;
 }
+
+// ---- the contracts of the cooperative operations, machine-checked (-DSPPARK_TRACK_BOUNDS; see tests/emu/emu_bounds.cpp) -----
+// coop_add / coop_dbl of ec/xyzz_coop.hpp from the LOOSEST operands the bucket invariants of ec/xyzzx_dev.hpp allow; the
+// claims travel through the exchange area with the limbs.  Returns the number of violated contracts.
+#ifdef SPPARK_TRACK_BOUNDS
+static std::atomic<int> g_violations{0};
+static std::mutex g_vm;
+static char g_first[512];
+extern "C" void sppark_bound_violation(const char* what, double got, double limit)
+{
+    std::lock_guard<std::mutex> lk(g_vm);
+    if (!g_violations.load()) snprintf(g_first, sizeof(g_first), "%s: %.6g against %.6g", what, got, limit);
+    g_violations++;
+}
+extern "C" int emu_coop_bounds(const unsigned char* points, size_t stride, size_t n, char* msg, size_t msglen)
+{
+    g_violations = 0; g_first[0] = 0;
+    if (n < 4) return -1;
+    static const double INV[4][2] = {{10, 5}, {5, 3}, {2, 1}, {2, 1}};      // X, Y, ZZZ, ZZ (ec/xyzzx_dev.hpp)
+    std::vector<uint4> conv((size_t)n * affine_loader<F>::STRIDE / 16 + 1);
+    for (size_t i = 0; i < n; i++) affine_loader<F>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+    auto pt = [&](size_t i) { affine_dev<F> p = load_affine<F, false>((const unsigned char*)conv.data(), i % n, 0); p.X.bnd_set(2, 1); p.Y.bnd_set(2, 1); return p; };
+    auto loosen = [&](xyzz_dev<F>& b) { if (b.is_inf()) return; b.X.bnd_set(INV[0][0], INV[0][1]); b.Y.bnd_set(INV[1][0], INV[1][1]); b.ZZZ.bnd_set(INV[2][0], INV[2][1]); b.ZZ.bnd_set(INV[3][0], INV[3][1]); };
+    auto check = [&](const char* op, const xyzz_dev<F>& b) {
+        if (b.is_inf()) return;
+        const F* c[4] = {&b.X, &b.Y, &b.ZZZ, &b.ZZ};
+        for (int k = 0; k < 4; k++)
+            if (!(c[k]->bv >= 0 && c[k]->bv <= INV[k][0] && c[k]->bl >= 0 && c[k]->bl <= INV[k][1])) sppark_bound_violation(op, c[k]->bv, INV[k][0]);
+    };
+    static coop_lds<F> ex;
+    run_group([&](unsigned tid) {
+        const unsigned lane = tid & 63, role = tid >> 6;
+        coop_ctx<F> c{&ex, role, lane, 0};
+        xyzz_dev<F> a; a.set(pt(lane), false); a.madd(pt(lane + 1), lane & 1); loosen(a);
+        xyzz_dev<F> b; b.set(pt(lane + 2), true); b.madd(pt(lane + 3), !(lane & 1)); loosen(b);
+        xyzz_dev<F> s = a; coop_add<F>(s, b, c); check("coop_add leaves a coordinate outside its invariant", s);
+        xyzz_dev<F> d = a; coop_dbl<F>(d, c); check("coop_dbl leaves a coordinate outside its invariant", d);
+        xyzz_dev<F> t = a; coop_add<F>(t, a, c); check("coop_add of equal operands leaves a coordinate outside its invariant", t);
+        xyzz_dev<F> h = s; coop_add<F>(h, d, c); check("coop_add in a chain", h); coop_dbl<F>(h, c); check("coop_dbl in a chain", h);
+    });
+    if (msg && msglen) { strncpy(msg, g_first, msglen - 1); msg[msglen - 1] = 0; }
+    return g_violations.load();
+}
+#endif

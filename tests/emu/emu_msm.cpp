@@ -33,7 +33,9 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -544,3 +546,63 @@ extern "C" int emu_g2_chain(void* out, const unsigned char* points, size_t strid
     (void)out; (void)points; (void)stride; (void)n;
     return 0;
 }
+
+
+// ---- the contracts of the G2 wave-pair bucket, machine-checked (-DSPPARK_TRACK_BOUNDS; see tests/emu/emu_bounds.cpp) --------
+// g2c_bucket::madd of ec/xyzz2_coop.hpp -- the plain step, the restart, the same point again (the cooperative doubling) --
+// from the LOOSEST operands the invariants of ec/xyzzx2_dev.hpp allow, component by component; the claims travel through
+// the exchange area with the limbs.  Returns the number of violated contracts (G2 builds; -1 otherwise).
+#if defined(SPPARK_TRACK_BOUNDS)
+static std::atomic<int> g_violations{0};
+static std::mutex g_vm;
+static char g_first[512];
+extern "C" void sppark_bound_violation(const char* what, double got, double limit)
+{
+    std::lock_guard<std::mutex> lk(g_vm);
+    if (!g_violations.load()) snprintf(g_first, sizeof(g_first), "%s: %.6g against %.6g", what, got, limit);
+    g_violations++;
+}
+extern "C" int emu_g2c_bounds(const unsigned char* points, size_t stride, size_t n, char* msg, size_t msglen)
+{
+#ifdef SPPARK_G2
+    if constexpr (field_is_internal<inst_fp>::value && !field_is_montx<inst_fp>::value) {
+        typedef inst_fp F2; typedef F2::fp fp;
+        g_violations = 0; g_first[0] = 0;
+        if (n < 4) return -1;
+        static const double INV[4][2] = {{9, 1}, {5, 1}, {2, 1}, {2, 1}};       // X, Y, ZZZ, ZZ (ec/xyzzx2_dev.hpp)
+        std::vector<uint4> conv((size_t)n * affine_loader<F2>::STRIDE / 16 + 1);
+        for (size_t i = 0; i < n; i++) affine_loader<F2>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
+        const unsigned char* rec = (const unsigned char*)conv.data();
+        static g2c_lds<F2> ex;
+        run_group(G2C_NT, [&](unsigned tid) {
+            const g2c_ctx<F2> c{&ex, tid >> 6, tid & 63};
+            auto pt = [&](size_t i) { g2c_affine<F2> p = g2c_affine<F2>::load(rec, i % n, c.role); p.X.bnd_set(2, 1); p.Y.bnd_set(2, 1); return p; };
+            auto loosen = [&](g2c_bucket<F2>& b) { b.X.bnd_set(INV[0][0], INV[0][1]); b.Y.bnd_set(INV[1][0], INV[1][1]); b.ZZZ.bnd_set(INV[2][0], INV[2][1]); b.ZZ.bnd_set(INV[3][0], INV[3][1]); };
+            auto check = [&](const char* op, const g2c_bucket<F2>& b) {
+                const fp* k4[4] = {&b.X, &b.Y, &b.ZZZ, &b.ZZ};
+                for (int k = 0; k < 4; k++)
+                    if (!(k4[k]->bv >= 0 && k4[k]->bv <= INV[k][0] && k4[k]->bl >= 0 && k4[k]->bl <= INV[k][1])) sppark_bound_violation(op, k4[k]->bv, INV[k][0]);
+            };
+            auto madd = [&](g2c_bucket<F2>& b, const g2c_affine<F2>& p, bool neg, bool restart) {
+                if (c.role == 0) b.template madd<0>(p, neg, restart, c); else b.template madd<1>(p, neg, restart, c);
+            };
+            for (int neg = 0; neg < 2; neg++) {
+                g2c_bucket<F2> a; a.set_inf();
+                madd(a, pt(c.lane), false, true); check("g2c madd (restart)", a);
+                madd(a, pt(c.lane + 1), neg, false); check("g2c madd after a restart", a);
+                loosen(a);
+                madd(a, pt(c.lane + 2), neg, false); check("g2c madd from loose operands", a);
+                g2c_bucket<F2> e; e.set_inf();
+                madd(e, pt(c.lane), neg, true); loosen(e);
+                madd(e, pt(c.lane), neg, false); check("g2c madd of the same point (cooperative doubling)", e);
+                for (unsigned i = 3; i < 7; i++) { madd(a, pt(c.lane + i), (i + neg) & 1, false); check("g2c madd in a chain", a); }
+            }
+        });
+        if (msg && msglen) { strncpy(msg, g_first, msglen - 1); msg[msglen - 1] = 0; }
+        return g_violations.load();
+    }
+#endif
+    (void)points; (void)stride; (void)n; (void)msg; (void)msglen;
+    return -1;
+}
+#endif

@@ -411,3 +411,78 @@ def test_cooperative_point_ops_on_host(oracle, curve, feature):
         assert (std(res[0][0]) == std(res[1][0])).all(), (fan, nrec, "buckets")
         live = res[0][1] != NONE if not last else np.zeros(2 * nthreads, dtype=bool)
         assert (std(res[0][2][live]) == std(res[1][2][live])).all(), (fan, nrec, "records")
+
+
+def _emu_bounds(feature, g2=False):
+    so = os.path.join(EMU, "libemu_bounds_%s%s.so" % (feature, "_G2" if g2 else ""))
+    src = os.path.join(EMU, "emu_bounds.cpp")
+    csrc = os.path.join(os.path.dirname(HERE), "sppark_amd", "csrc")
+    newest = max(os.stat(os.path.join(r, f)).st_mtime for r, _, fs in os.walk(csrc) for f in fs)
+    newest = max(newest, os.stat(src).st_mtime)
+    if not os.path.exists(so) or os.stat(so).st_mtime < newest:
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "-x", "hip", "--cuda-host-only", "-O1", "-std=c++17", "-fPIC", "-shared",
+                               "-DFEATURE_" + feature] + (["-DSPPARK_G2"] if g2 else []) + ["-o", so, src])
+    L = ctypes.CDLL(so)
+    L.emu_bounds_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    return L
+
+
+@pytest.mark.parametrize("curve,feature,g2", [(0, "BLS12_381", False), (1, "BN254", False), (4, "BLS12_377", False), (6, "PALLAS", False),
+                                              (2, "BLS12_381", True), (3, "BN254", True), (5, "BLS12_377", True)])
+def test_lazy_field_contracts_are_machine_checked(oracle, curve, feature, g2):
+    """ff/montx_dev.hpp with -DSPPARK_TRACK_BOUNDS (tests/emu/emu_bounds.cpp): every field value carries its CLAIMED bounds
+    (value < K p, limbs <= B 2^LB), every operation checks its operands against its stated precondition and derives its
+    result's claim by the rule at its definition.  Every point operation of the G1 / G2 bucket classes -- mixed addition
+    with and without negation, full addition, doubling, the interleaved-pair forms, the doubling and equal-operand
+    branches, conversion in and out, chains -- is started from the LOOSEST operands the memory invariants allow: no
+    precondition is violated on the way and every result is inside the invariants again.  For all inputs, not a sample.
+    And the checker itself reports deliberately broken contracts."""
+    L = _emu_bounds(feature, g2)
+    pts, _sc = recipe.msm_inputs(curve, 12, 2024, edge=False, flagged=False)
+    msg = ctypes.create_string_buffer(512)
+    nv = L.emu_bounds_run(P(pts), pts.shape[1], pts.shape[0], msg, 512)
+    assert nv == 0, (nv, msg.value.decode())
+    assert L.emu_bounds_selftest() == 5
+
+
+def _emu_tracked(src_name, tag, feature, g2=False):
+    """tests/emu/<src_name> built with -DSPPARK_TRACK_BOUNDS (the field values carry their claimed bounds)"""
+    so = os.path.join(EMU, "libemu_%s_bounds_%s%s.so" % (tag, feature, "_G2" if g2 else ""))
+    src = os.path.join(EMU, src_name)
+    csrc = os.path.join(os.path.dirname(HERE), "sppark_amd", "csrc")
+    newest = max(os.stat(os.path.join(r, f)).st_mtime for r, _, fs in os.walk(csrc) for f in fs)
+    newest = max(newest, os.stat(src).st_mtime)
+    if not os.path.exists(so) or os.stat(so).st_mtime < newest:
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "-x", "hip", "--cuda-host-only", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DSPPARK_TRACK_BOUNDS",
+                               "-DFEATURE_" + feature] + (["-DSPPARK_G2"] if g2 else []) + ["-o", so, src])
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])
+def test_cooperative_operations_keep_the_field_contracts(oracle, curve, feature):
+    """coop_add / coop_dbl (ec/xyzz_coop.hpp: the four-wave point operations of the MSM tail, a DEFAULT path) with the
+    bound tracking of test_lazy_field_contracts_are_machine_checked: from the loosest operands the bucket invariants
+    allow, through the exchange area (the claims travel with the limbs), equal operands included -- no precondition
+    violated, every result inside the invariants."""
+    L = _emu_tracked("emu_coop.cpp", "coop", feature)
+    L.emu_coop_bounds.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    pts, _sc = recipe.msm_inputs(curve, 70, 77, edge=False, flagged=False)
+    msg = ctypes.create_string_buffer(512)
+    nv = L.emu_coop_bounds(P(pts), pts.shape[1], pts.shape[0], msg, 512)
+    assert nv == 0, (nv, msg.value.decode())
+
+
+@pytest.mark.parametrize("curve,feature", [(2, "BLS12_381"), (3, "BN254"), (5, "BLS12_377")])
+def test_g2_wave_pair_bucket_keeps_the_field_contracts(oracle, curve, feature):
+    """g2c_bucket::madd (ec/xyzz2_coop.hpp, the default-off G2 accumulation by wave pairs) under the same bound tracking:
+    restart, plain step, the same point again (the cooperative doubling), chains -- from the loosest operands."""
+    L = _emu_tracked("emu_msm.cpp", "g2c", feature, g2=True)
+    L.emu_g2c_bounds.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    pts, _sc = recipe.msm_inputs(curve, 80, 78, edge=False, flagged=False)
+    msg = ctypes.create_string_buffer(512)
+    nv = L.emu_g2c_bounds(P(pts), pts.shape[1], pts.shape[0], msg, 512)
+    assert nv == 0, (nv, msg.value.decode())

@@ -64,6 +64,11 @@ SppError mult_pippenger_inf(void *out, const void *points, size_t npoints,
  * (poc/msm-cuda/src/lib.rs:84-119). */
 SppError mult_pippenger_fp2_inf(void *out, const void *points, size_t npoints,
                                 const void *scalars, size_t ffi_affine_sz);
+/* Not in the reference: which bucket-accumulation kernel mult_pippenger_fp2_inf runs (process-wide).  0 = automatic:
+ * a PAIR of waves per 64 mixed additions, one Fp2 component per wave (msm/msm_g2c_kernels.hpp), over the 14-limb base
+ * fields (BLS12-381, BLS12-377: 2^22 points 47.8 -> 40.2 ms), one lane per addition over the 10-limb one (alt_bn128);
+ * 1 / 2 force either.  Same result either way; the tests run both against the oracle. */
+SppError sppark_msm_g2_path(unsigned mode);
 
 /* poc/msm-cuda/cuda/pippenger.cu:20-25.  points: Affine_t (X | Y, infinity
  * encoded as all-zero), stride 2*sizeof(fp); same scalars/out as above. */

@@ -445,3 +445,32 @@ def ref_lde(field, x, lg_blowup, want_aux=False):
         return buf.view(x.dtype), aux.view(x.dtype)
     assert L.ref_lde(_ptr(buf), lg, lg_blowup) == 0
     return buf.view(x.dtype)
+
+
+# ------------- the reference's own device field classes fp_t / fr_t (ff/mont_t.hip), _ref/libref_field_<curve>.so -
+# oracle/Makefile: ref_field; oracle/ref_field_shim.cu.  GPU box only; the only reference-held pin of the MSM side.
+_REF_FIELD = {}
+REF_FIELD_CURVES = ("bls12_381", "bn254", "bls12_377", "pallas", "vesta")
+
+
+def ref_field_available(curve):
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_field_%s.so" % curve))
+
+
+def ref_field_op(curve, field, op, a, b=None):
+    """element-wise op of the reference's fp_t (field 0) / fr_t (field 1) on the GPU (ff/mont_t.hip:96-218):
+    0 a+b, 1 a-b, 2 a*b, 3 sqr, 4 to(), 5 from().  |a|, |b|: uint8 arrays of n elements in the reference's memory image."""
+    if curve not in _REF_FIELD:
+        L = ctypes.CDLL(os.path.join(_HERE, "_ref", "libref_field_%s.so" % curve), mode=ctypes.RTLD_LOCAL)
+        L.ref_field_op.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.ref_field_bytes.argtypes = [ctypes.c_int]; L.ref_field_bytes.restype = ctypes.c_size_t
+        _REF_FIELD[curve] = L
+    L = _REF_FIELD[curve]
+    a = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    b = a if b is None else np.ascontiguousarray(b).view(np.uint8).reshape(-1)
+    eb = L.ref_field_bytes(field)
+    assert a.nbytes % eb == 0 and a.nbytes == b.nbytes
+    out = np.zeros_like(a)
+    rc = L.ref_field_op(field, op, _ptr(out), _ptr(a), _ptr(b), a.nbytes // eb)
+    assert rc == 0, rc
+    return out

@@ -15,8 +15,12 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
-OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj")
+# SPPARK_LIBDIR=<name> (a directory beside lib/, e.g. lib_tuning): a second set of libraries with other flags for an A/B
+# job -- "SPPARK_LIBDIR=lib_tuning SPPARK_EXTRA_FLAGS=-DSPPARK_TUNING python -m sppark_amd.build --only gl64,bb31" -- which
+# the tools select with the same variable (sppark_amd/ffi.py).  The tests and bench.py never set it.
+_LIBNAME = os.environ.get("SPPARK_LIBDIR", "lib")
+LIBDIR = os.path.join(HERE, _LIBNAME)
+OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj" if _LIBNAME == "lib" else "obj_" + _LIBNAME)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wno-duplicate-decl-specifier"]

@@ -44,7 +44,7 @@ extern template __global__ void k_accumulate<fp2_d, false>(bucket2_m*, u32*, buc
 extern template __global__ void k_accumulate<fp2_d, true>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 #if !defined(SPPARK_FP2_32LIMB)
-extern template __global__ void k_accumulate_g2c<fp2_d, false>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
+extern template __global__ void k_accumulate_g2c<fp2_d>(bucket2_m*, u32*, bucket2_m*, const unsigned char*, unsigned,
                                                                const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 #endif
 extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, const bucket2_m*,
@@ -100,6 +100,7 @@ template<class Fn> static RustError guarded(Fn&& fn)
 // (SPPARK_MSM_CACHE_BYTES, default 32 GiB); sppark_msm_release_cached() frees the scratch of
 // every idle context.  The pool itself is never destroyed: destructors running HIP calls at
 // process exit would race the runtime's own teardown.
+#include <atomic>
 #include <mutex>
 #include <thread>
 template<class Impl> class ctx_pool {
@@ -236,6 +237,12 @@ SPPARK_FFI RustError mult_pippenger(void* out, const void* points, size_t npoint
 {   return one_shot(out, points, npoints, scalars, false, 2 * sizeof(fp_d));   }
 
 #ifndef SPPARK_NO_G2
+// which accumulation kernel the G2 entry point runs (process-wide: its contexts are pooled): 0 = automatic (wave pairs,
+// one Fp2 component per wave, for the 14-limb base fields; one lane per addition otherwise), 1 = wave pairs, 2 = one lane.
+// Both compute the same buckets; the switch exists so that the tests hold BOTH against the oracle.
+static std::atomic<unsigned> g2_path{0};
+SPPARK_FFI RustError sppark_msm_g2_path(unsigned mode)
+{   return guarded([&] { if (mode > 2) HIP_OK(hipErrorInvalidValue); g2_path.store(mode, std::memory_order_relaxed); });   }
 // poc/msm-cuda/cuda/pippenger_inf.cu:41-47: the same over G2 (coordinates in Fp2)
 SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_t npoints,
                                             const void* scalars, size_t ffi_affine_sz)
@@ -243,6 +250,7 @@ SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_
     memset(out, 0, sizeof(point2_t));
     return guarded([&] {
         borrowed<msm2_impl> msm(-1);
+        msm->tune.g2_coop = g2_path.load(std::memory_order_relaxed);
         if (is_device_pointer(points) || is_device_pointer(scalars)) HIP_OK(hipDeviceSynchronize());
         point2_t r;
         msm->invoke(r, points, npoints, scalars, false, ffi_affine_sz);
@@ -353,16 +361,26 @@ SPPARK_FFI RustError sppark_msm_multi_shards_ms(void* out, const void* const* po
 // Elliptic-curve addition is not an RCCL reduction operator, so the exchange is ONE ncclAllGather of the ranks'
 // Jacobian partial sums (144 bytes each for BLS12-381 G1) and every rank adds the nranks points on its host:
 // all ranks return the same point.  RCCL is bound at run time (util/rccl_dyn.hpp).
+// |out| may be the same buffer as |partial| (the natural call after an MSM entry point wrote |out|): the partial sum is
+// copied before |out| is cleared.
 SPPARK_FFI RustError sppark_msm_rccl_sum(void* out, const void* partial, int g2, void* nccl_comm, void* stream)
 {
 #ifndef SPPARK_NO_G2
-    memset(out, 0, g2 ? sizeof(point2_t) : sizeof(point_t));
-    return guarded([&] { if (g2) rccl_sum<point2_t>(out, partial, nccl_comm, stream); else rccl_sum<point_t>(out, partial, nccl_comm, stream); });
+    const size_t bytes = g2 ? sizeof(point2_t) : sizeof(point_t);
+    unsigned char mine[sizeof(point2_t)];
+    if (partial) memcpy(mine, partial, bytes);
+    memset(out, 0, bytes);
+    return guarded([&] {
+        const void* src = partial ? mine : nullptr;
+        if (g2) rccl_sum<point2_t>(out, src, nccl_comm, stream); else rccl_sum<point_t>(out, src, nccl_comm, stream);
+    });
 #else
+    unsigned char mine[sizeof(point_t)];
+    if (partial) memcpy(mine, partial, sizeof(point_t));
     store_inf(out);
     return guarded([&] {
         if (g2) throw hip_error(ENOTSUP, "this curve has no G2");
-        rccl_sum<point_t>(out, partial, nccl_comm, stream);
+        rccl_sum<point_t>(out, partial ? mine : nullptr, nccl_comm, stream);
     });
 #endif
 }

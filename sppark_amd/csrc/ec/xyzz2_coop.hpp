@@ -1,6 +1,7 @@
 // G2 buckets with ONE Fp2 COMPONENT PER WAVE: two waves of a 128-lane work-group carry one vector of 64 mixed additions.
-// (Round 4, NOT the default: msm_tunables::g2_coop / SPPARK_G2_COOP=1.  Written and run on the host emulation at the end
-// of a round whose GPU budget was spent; unmeasured on hardware.)
+// (Written in round 4 on the host emulation, measured and adopted in round 5 for the 14-limb base fields:
+// BLS12-381 G2 2^22 47.8 -> 40.2 ms, 2^20 15.3 -> 14.0 ms; the 10-limb alt_bn128 loses 9 % and keeps the one-lane kernel;
+// profiles/r05_g2_coop_ab.log.)
 //
 // Why.  The G2 accumulation over fp2x_dev holds a whole Fp2 bucket, an Fp2 point and the temporaries of a mixed addition
 // in one lane: 414 registers, ONE wave per SIMD, 0.164 vector instructions per clock where the two-wave G1 kernel issues

@@ -10,8 +10,8 @@ template __global__ void k_accumulate<inst_fp, false>(inst_m*, u32*, inst_m*, co
                                                    const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 template __global__ void k_accumulate<inst_fp, true>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
                                                   const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
-#if defined(SPPARK_G2) && !defined(SPPARK_FP2_32LIMB)     // G2: the accumulation with one Fp2 component per wave (not the default)
-template __global__ void k_accumulate_g2c<inst_fp, false>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
+#if defined(SPPARK_G2) && !defined(SPPARK_FP2_32LIMB)     // G2: the accumulation with one Fp2 component per wave
+template __global__ void k_accumulate_g2c<inst_fp>(inst_m*, u32*, inst_m*, const unsigned char*, unsigned,
                                                           const u32*, const u32*, unsigned, unsigned, unsigned, unsigned, unsigned);
 #endif
 #ifndef SPPARK_G2

@@ -180,10 +180,12 @@ private:
     void need_aux()
     {
         if (aux) return;
-        // The sort of the following window groups.  SPPARK_MSM_AUX_CUS=N confines it to N compute
-        // units (experiment knob; default: an ordinary stream on all CUs).
+        // The sort of the following window groups: an ordinary stream on all CUs.  (Tuning builds, -DSPPARK_TUNING:
+        // SPPARK_MSM_AUX_CUS=N confines it to N compute units.)
         unsigned ncu = 0;
+#ifdef SPPARK_TUNING
         if (const char* e = getenv("SPPARK_MSM_AUX_CUS")) ncu = (unsigned)atoi(e);
+#endif
         const unsigned total = (unsigned)gpu->prop.multiProcessorCount;
         hipError_t err = hipErrorNotSupported;
         if (ncu && ncu < total) {
@@ -219,13 +221,14 @@ public:
         {
             // lanes of k_accumulate the device runs at once -- at most two waves per SIMD (two 256-lane work-groups per CU):
             // a third resident wave adds no throughput -- : the plan fits the accumulation's grid to whole rounds of them
-            int nb = 0;
+            // (asked on the context's OWN device, not whichever one happens to be current: the answer feeds the plan)
+            int nb = 0, cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != gpu->hip_id) HIP_OK(hipSetDevice(gpu->hip_id));
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_accumulate<fp_d, false>, 256, 0) == hipSuccess && nb > 0)
                 tune.resident_lanes = (size_t)std::min(nb, 2) * 256 * (size_t)gpu->prop.multiProcessorCount;
             else (void)hipGetLastError();
-        }
-        if constexpr (G2_COOP_BUILT) {              // A/B switch of the one-shot entry points (no tuning call reaches their pooled contexts)
-            if (const char* e = getenv("SPPARK_G2_COOP")) tune.g2_coop = (unsigned)atoi(e);
+            if (cur >= 0 && cur != gpu->hip_id) (void)hipSetDevice(cur);
         }
         if (stream == nullptr) {
             // a non-blocking private stream (a blocking one pays an implicit legacy-stream check on
@@ -575,12 +578,16 @@ private:
                 const u32* sorted = (const u32*)(blob + l.sorted[b]);
                 const u32* off = (const u32*)(blob + l.off[b]);
                 dim3 grid((p.chunks_per_win + 255) / 256, wn);
-                bool by_pairs = false;              // G2: one Fp2 component per wave (NOT the default; unmeasured on hardware)
+                // G2: one Fp2 component per wave (msm_g2c_kernels.hpp).  The default for the 14-limb base fields: BLS12-381 G2
+                // 2^22 47.8 -> 40.2 ms, 2^20 15.3 -> 14.0; NOT for the 10-limb one, whose whole Fp2 bucket fits a lane at two
+                // waves per SIMD already (alt_bn128 G2 2^22 21.6 -> 23.6 ms); profiles/r05_g2_coop_ab.log.
+                // tune.g2_coop: 0 = that rule, 1 = wave pairs, 2 = one lane per addition (sppark_msm_g2_path).
+                bool by_pairs = false;
                 if constexpr (G2_COOP_BUILT) {
-                    if (tune.g2_coop) {
+                    if (tune.g2_coop == 1 || (tune.g2_coop == 0 && fp_d::NL >= 14)) {
                         by_pairs = true;
                         dim3 grid2((p.chunks_per_win + 63) / 64, wn);
-                        hipLaunchKernelGGL((k_accumulate_g2c<fp_d, false>), grid2, dim3(G2C_NT), 0, stream,
+                        hipLaunchKernelGGL((k_accumulate_g2c<fp_d>), grid2, dim3(G2C_NT), 0, stream,
                                            buckets, keyA, ptA, d_points, (unsigned)stride, sorted, off,
                                            p.n, p.NB, p.L, p.chunks_per_win, w0);
                     }

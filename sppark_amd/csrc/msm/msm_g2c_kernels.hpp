@@ -1,6 +1,8 @@
 // The G2 accumulation with one Fp2 component per wave (ec/xyzz2_coop.hpp): k_accumulate's walk over the sorted entries
-// of a chunk, by a PAIR of waves per 64 chunks.  NOT the default (msm_tunables::g2_coop / SPPARK_G2_COOP=1): written
-// and run on the host emulation (tests/emu/emu_msm.cpp, SPPARK_G2) at the end of round 4, unmeasured on hardware.
+// of a chunk, by a PAIR of waves per 64 chunks.  The default accumulation of G2 over the 14-limb base fields (BLS12-381,
+// BLS12-377; msm_driver.hpp, msm_tunables::g2_coop): BLS12-381 G2 2^22 47.8 -> 40.2 ms, profiles/r05_g2_coop_ab.log.
+// Covered on the GPU by every G2 test (tests/test_msm_gpu.py runs them over both accumulation paths) and on the host
+// emulation (tests/emu/emu_msm.cpp, SPPARK_G2).
 //
 // Same inputs, same outputs (records, keys, buckets) as accumulate_chunk<fp2x_dev> in msm_kernels.hpp.  The control flow
 // is made UNIFORM over the work-group, because every mixed addition contains barriers: each lane runs exactly L
@@ -12,7 +14,7 @@
 
 namespace sppark_amd {
 
-template<class F2, bool FLAGGED, unsigned ROLE>
+template<class F2, unsigned ROLE>
 SPPARK_DEVFN void accumulate_chunk_g2c(xyzz_mem<F2::N>* buckets, u32* rec_key, xyzz_mem<F2::N>* rec_pt,
                                        const unsigned char* points,
                                        const u32* sorted, const u32* off,
@@ -67,7 +69,8 @@ SPPARK_DEVFN void accumulate_chunk_g2c(xyzz_mem<F2::N>* buckets, u32* rec_key, x
 }
 
 static constexpr unsigned G2C_NT = 128;             // a pair of waves
-template<class F2, bool FLAGGED>
+// (the converted records carry their own infinity flag: one instantiation serves both wire layouts)
+template<class F2>
 __global__ __launch_bounds__(128, 2)
 void k_accumulate_g2c(xyzz_mem<F2::N>* __restrict__ buckets,
                       u32* __restrict__ rec_key, xyzz_mem<F2::N>* __restrict__ rec_pt,
@@ -78,10 +81,16 @@ void k_accumulate_g2c(xyzz_mem<F2::N>* __restrict__ buckets,
     (void)stride;                                   // (the converted records have their own stride)
     __shared__ g2c_lds<F2> ex;
     const g2c_ctx<F2> c{&ex, threadIdx.x >> 6, threadIdx.x & 63};
-    // the component is wave-uniform: one branch here, two specialised walks
-    if (c.role == 0) accumulate_chunk_g2c<F2, FLAGGED, 0>(buckets, rec_key, rec_pt, points, sorted, off, n, NB, L, chunks_per_win,
+    // The component is WAVE-uniform: one branch here, two specialised walks (each wave computes only its component's
+    // formula of every Fp2 product).  The two walks execute the same sequence of work-group barriers -- every barrier sits
+    // in madd / dbl_affine / coop_any, which both call at the same points of the same trip counts -- and no barrier is
+    // under a condition that differs between the LANES of a wave.  A work-group barrier on CDNA is s_barrier, which
+    // counts arriving WAVES, not program addresses (and the fences around it are per wave), so the two copies of each
+    // barrier pair up; the vote (coop_any -> __ockl_wgred_or_i32) is one out-of-line routine with one LDS cell whatever
+    // the call site.  Exercised on hardware by every G2 GPU test.
+    if (c.role == 0) accumulate_chunk_g2c<F2, 0>(buckets, rec_key, rec_pt, points, sorted, off, n, NB, L, chunks_per_win,
                                                           blockIdx.x * 64 + c.lane, blockIdx.y, w_base, c);
-    else             accumulate_chunk_g2c<F2, FLAGGED, 1>(buckets, rec_key, rec_pt, points, sorted, off, n, NB, L, chunks_per_win,
+    else             accumulate_chunk_g2c<F2, 1>(buckets, rec_key, rec_pt, points, sorted, off, n, NB, L, chunks_per_win,
                                                           blockIdx.x * 64 + c.lane, blockIdx.y, w_base, c);
 }
 

@@ -27,7 +27,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
-    unsigned g2_coop = 0;               // G2 only: the accumulation with one Fp2 component per wave (msm_g2c_kernels.hpp; default off, SPPARK_G2_COOP=1)
+    unsigned g2_coop = 0;               // G2 only: the accumulation with one Fp2 component per wave (msm_g2c_kernels.hpp): 0 = for the 14-limb base fields, 1 = always, 2 = never
     size_t resident_lanes = 0;          // lanes of k_accumulate the device holds at once (set by the driver from the occupancy query; 0 = unknown)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)

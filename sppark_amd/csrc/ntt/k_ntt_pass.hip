@@ -8,12 +8,15 @@ namespace sppark_amd {
 #define SPPARK_NTT_DEFINE(DIF, INV, R1, R2) \
     template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
+#if SPPARK_NTT_DIF                                                 // (one of the two units carries the small-transform kernel)
+template __global__ void k_ntt_small<ntt_fr_t, false>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
+template __global__ void k_ntt_small<ntt_fr_t, true>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
+#endif
 #if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // wide fields stop at 4 stages per pass in registers ...
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
 #else                                                              // ... and run up to 8 with one stage per round
-#define SPPARK_NTT_LAT_DEFINE(INV, R) \
-    template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), INV, R>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
-SPPARK_NTT_LAT_DEFINE(false, 0) SPPARK_NTT_LAT_DEFINE(true, 0)
-SPPARK_NTT_LAT_DEFINE(false, 2) SPPARK_NTT_LAT_DEFINE(true, 2) SPPARK_NTT_LAT_DEFINE(false, 3) SPPARK_NTT_LAT_DEFINE(true, 3)     // (SPPARK_NTT_LAT_TAIL)
+#define SPPARK_NTT_LAT_DEFINE(INV) \
+    template __global__ void k_ntt_pass_lat<ntt_fr_t, (SPPARK_NTT_DIF != 0), INV>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
+SPPARK_NTT_LAT_DEFINE(false) SPPARK_NTT_LAT_DEFINE(true)
 #endif
 }

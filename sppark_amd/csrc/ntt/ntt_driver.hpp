@@ -105,11 +105,26 @@ class ntt_engine {
     // ones from L2 / the Infinity Cache).  The per-element alternative is a lo x hi product per twiddle: one of the ~3.5
     // products per element and pass.  BLS12-381 Fr 2^24 forward (profiles/r03_ntt_wide_tables.log): 2.80 ms without
     // tables, 2.43 with tables up to 2^16, 2.33 up to 2^20, 2.25 up to 2^24 -- even the table as large as the data pays,
-    // the passes are bound by their products.  SPPARK_NTT_WIDE_TABLE=<log2> moves the limit (0: no tables).
+    // the passes are bound by their products.  (Tuning builds, -DSPPARK_TUNING: SPPARK_NTT_WIDE_TABLE=<log2> moves the
+    // limit, 0 = no tables.)
     static unsigned wide_table_lg()
     {
+#ifdef SPPARK_TUNING
         static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_WIDE_TABLE"); return e ? (unsigned)atoi(e) : 24u; }();
         return v;
+#else
+        return 24u;
+#endif
+    }
+    // transforms up to this size run as one launch of one work-group (tuning builds: SPPARK_NTT_SMALL_MAX, 0 = never)
+    static unsigned small_max_lg()
+    {
+#ifdef SPPARK_TUNING
+        static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_SMALL_MAX"); return e ? std::min((unsigned)atoi(e), NTT_SMALL_MAX_LG) : NTT_SMALL_MAX_LG; }();
+        return v;
+#else
+        return NTT_SMALL_MAX_LG;
+#endif
     }
     // the inter-pass twiddle table of a pass on sub-problems of 2^lg_cur elements (built once per
     // (device, size, direction, pass shape); null when the pass generates its twiddles instead)
@@ -213,6 +228,18 @@ public:
         const size_t n = (size_t)1 << lg;
         const unsigned egrid = (unsigned)((n + 255) / 256);
 
+        // up to 2^10 elements: the whole transform -- permutations, coset powers and 1/n included -- by one work-group
+        // in one launch (k_ntt_small, ntt_kernels.hpp)
+        if (lg <= small_max_lg()) {
+            const unsigned flags = ntt_small_flags(order, inverse != 0, type == NTT_COSET);
+            const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
+            const size_t lds = (n + n / 2) * sizeof(F);
+            if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
+            else         hipLaunchKernelGGL((k_ntt_small<F, false>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
+            HIP_OK(hipGetLastError());
+            return;
+        }
+
         bool bitrev, gs;
         switch (order) {
             case NTT_NN: bit_reverse(d, lg, stream);
@@ -224,18 +251,19 @@ public:
         if (!inverse && type == NTT_COSET)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
 
-        // tuning knobs (tools/gpu_ntt_sweep.py), read once per process; the LDS tile is clamped to what
-        // the element size allows (160 KB per work-group: 2^14 eight-byte elements, 2^12 32-byte ones)
-        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; unsigned lat_tail; };
+        // The plan's shape parameters.  A shipped library uses the constants; a tuning build (-DSPPARK_TUNING, e.g.
+        // SPPARK_EXTRA_FLAGS=-DSPPARK_TUNING python -m sppark_amd.build; tools/gpu_ntt_sweep.py) reads them from the
+        // environment once per process.  The LDS tile is clamped to what the element size allows (160 KB per
+        // work-group: 2^14 eight-byte elements, 2^12 32-byte ones; the one-stage-per-round passes stay within the
+        // 64 KB a launch gets without raising the kernel's limit).
+        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; };
         static const knobs_t knobs = [] {
-            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1, 0};
-            // 2 or 3: that many small-half stages of a one-stage-per-round pass in registers (ntt_lat_tail_dif / _head_dit);
-            // NOT the default -- host-emulated only so far
-            if (const char* e = getenv("SPPARK_NTT_LAT_TAIL")) { unsigned v = (unsigned)atoi(e); if (v == 2 || v == 3) k.lat_tail = v; }
+            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1};
+#ifdef SPPARK_TUNING
             // 256-bit fields: stages per one-stage-per-round pass (0: the register passes), columns per tile row and tile
             // elements (log2; default: by size, lat_shape())
             if (const char* e = getenv("SPPARK_NTT_LAT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v <= 8) k.lat_smax = R64 ? 0 : v; }
-            if (const char* e = getenv("SPPARK_NTT_LAT_LGC")) { int v = atoi(e); if (v >= 0 && v <= 4) k.lat_lgc = v; }
+            if (const char* e = getenv("SPPARK_NTT_LAT_LGC")) { int v = atoi(e); if (v >= 0 && v <= 3) k.lat_lgc = v; }
             if (const char* e = getenv("SPPARK_NTT_LAT_LGTILE")) { int v = atoi(e); if (v >= 6 && v <= 11) k.lat_lgt = v; }
             if (const char* e = getenv("SPPARK_NTT_R64_MIN")) k.r64_min = (unsigned)atoi(e);          // 99: the 8-stage plan only
             if (const char* e = getenv("SPPARK_NTT_R64_DIRECT")) k.r64_direct = (unsigned)atoi(e);    // largest single inter-pass table (log2)
@@ -246,6 +274,7 @@ public:
                 while (((size_t)sizeof(F) << cap) > 160 * 1024) cap--;
                 if (v >= 8 && v <= cap) k.lgt = v;
             }
+#endif
             if (k.lgt < k.smax + 1) k.lgt = k.smax + 1;
             return k;
         }();
@@ -323,18 +352,13 @@ public:
             unsigned tiles = (unsigned)(n / tile_elems);
             if constexpr (!R64) {
                 if (lat) {                                      // one butterfly per lane and stage, the tile in LDS throughout
-                    const unsigned tail = knobs.lat_tail && P.S >= knobs.lat_tail ? knobs.lat_tail : 0;
-                    const unsigned lanes = (unsigned)std::min<size_t>(std::max<size_t>(tile_elems / 2, 64), tail ? 512 : 1024);
+                    const unsigned lanes = (unsigned)std::min<size_t>(std::max<size_t>(tile_elems / 2, 64), 1024);
                     const size_t lat_lds = tile_elems * sizeof(F);
-#define SPPARK_LAT_LAUNCH(R)                                                                                   \
-                    do {                                                                                       \
-                        if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, true, true, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);    \
-                                  else         hipLaunchKernelGGL((k_ntt_pass_lat<F, true, false, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); } \
-                        else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, false, true, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);   \
-                                  else         hipLaunchKernelGGL((k_ntt_pass_lat<F, false, false, R>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); } \
-                    } while (0)
-                    if (tail == 3) SPPARK_LAT_LAUNCH(3); else if (tail == 2) SPPARK_LAT_LAUNCH(2); else SPPARK_LAT_LAUNCH(0);
-#undef SPPARK_LAT_LAUNCH
+                    if (lat_lds > 64 * 1024) HIP_OK(hipErrorInvalidValue);      // (only a tuning build can ask for such a tile)
+                    if (gs) { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, true, true>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);
+                              else         hipLaunchKernelGGL((k_ntt_pass_lat<F, true, false>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); }
+                    else    { if (inverse) hipLaunchKernelGGL((k_ntt_pass_lat<F, false, true>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P);
+                              else         hipLaunchKernelGGL((k_ntt_pass_lat<F, false, false>), dim3(tiles), dim3(lanes), lat_lds, stream, d, T, P); }
                     continue;
                 }
             }

@@ -401,77 +401,121 @@ SPPARK_DEVFN void ntt_lat_store(F* data, const F* tile, const ntt_tables<F>& T, 
         data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c] = x;
     }
 }
-// The R stages with the SMALL halves (the last ones of a DIF pass, the first ones of a DIT pass) in REGISTERS, fused with the
-// store / the load: they act on groups of 2^R consecutive rows, i.e. they are radix_dif<R> / radix_dit<R> of those rows,
-// whose twiddles w_{2^R}^k are compile-time indices -- the k = 0 ones cost nothing there, whereas a stage of the round
-// form executes its product for the whole wave when any lane's twiddle is not 1: 0.625 instead of 1.0 executed products
-// per element for R = 3, and three LDS round trips and barriers less.  The price is 2^R elements per lane in that phase
-// (a quarter of the lanes busy): a gain where a pass is throughput-bound, a loss on the small latency-bound transforms.
-// NOT the default (SPPARK_NTT_LAT_TAIL=R; written at the end of round 4 without GPU time: host-emulated only).
-// fn(0), fn(1), ..., fn(N - 1) as N separate inlined calls: `#pragma unroll` gives up on a loop whose body holds a 256-bit
-// product (the element array would then be indexed at run time, i.e. live in scratch)
-template<unsigned I, unsigned N> struct ntt_static_for {
-    template<class Fn> SPPARK_DEVFN static void run(Fn&& fn) { fn(I); ntt_static_for<I + 1, N>::run(fn); }
-};
-template<unsigned N> struct ntt_static_for<N, N> { template<class Fn> SPPARK_DEVFN static void run(Fn&&) {} };
-
-template<class F, bool INV, unsigned R>
-SPPARK_DEVFN void ntt_lat_tail_dif(F* data, const F* tile, const ntt_tables<F>& T, const ntt_pass& P, size_t tile_id, unsigned tid, unsigned nt)
-{
-    const ntt_tile_geom geo = ntt_geom(P, tile_id);
-    const unsigned elems = 1u << (P.lgG + P.S + P.lgC), C = 1u << P.lgC;
-    for (unsigned gi = tid; gi < (elems >> R); gi += nt) {
-        const unsigned c = gi & (C - 1), grp = gi >> P.lgC;
-        F x[1u << R];
-        #pragma unroll
-        for (unsigned a = 0; a < (1u << R); a++) x[a] = ntt_lat_get(tile, (((grp << R) + a) << P.lgC) + c, elems);
-        radix_dif<F, INV, R>(x, T.inner);
-        ntt_static_for<0, (1u << R)>::run([&](unsigned a) {
-            const unsigned gm = (grp << R) + a;
-            F y = x[a];
-            if (geo.lgQ) y = y * ntt_lat_twiddle(T, P, geo, gm & ((1u << P.S) - 1), c);
-            if (P.apply_scale) y = y * T.scale;
-            data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c] = y;
-        });
-    }
-}
-template<class F, bool INV, unsigned R>
-SPPARK_DEVFN void ntt_lat_head_dit(const F* data, F* tile, const ntt_tables<F>& T, const ntt_pass& P, size_t tile_id, unsigned tid, unsigned nt)
-{
-    const ntt_tile_geom geo = ntt_geom(P, tile_id);
-    const unsigned elems = 1u << (P.lgG + P.S + P.lgC), C = 1u << P.lgC;
-    for (unsigned gi = tid; gi < (elems >> R); gi += nt) {
-        const unsigned c = gi & (C - 1), grp = gi >> P.lgC;
-        F x[1u << R];
-        ntt_static_for<0, (1u << R)>::run([&](unsigned a) {
-            const unsigned gm = (grp << R) + a;
-            x[a] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
-            if (geo.lgQ) x[a] = x[a] * ntt_lat_twiddle(T, P, geo, gm & ((1u << P.S) - 1), c);
-        });
-        radix_dit<F, INV, R>(x, T.inner);
-        #pragma unroll
-        for (unsigned a = 0; a < (1u << R); a++) ntt_lat_put(tile, (((grp << R) + a) << P.lgC) + c, elems, x[a]);
-    }
-}
-// R = 0: every stage a round.  R > 0 (P.S >= R): the small-half stages in registers.
-// (with a register phase: at most 512 lanes, so that the 2^R elements of a lane have 256 registers to live in)
-template<class F, bool DIF, bool INV, unsigned R = 0>
-__global__ __launch_bounds__(R ? 512 : 1024)
+// Fusing the small-half stages with the store / load in registers (radix_dif<R> / radix_dit<R> of 2^R consecutive rows,
+// R = 2 | 3) was written in round 4 and measured in round 5: slower at every size (BLS12-381 Fr 2^24 forward 2.12 ->
+// 2.28 ms with R = 2, 3.01 with R = 3; profiles/r05_ntt_lat_tail_ab.log) -- a quarter of the lanes busy in that phase
+// costs more than the 0.375 products per element it saves.  Removed.
+template<class F, bool DIF, bool INV>
+__global__ __launch_bounds__(1024)
 void k_ntt_pass_lat(F* data, ntt_tables<F> T, ntt_pass P)
 {
     extern __shared__ unsigned char ntt_lds[];
     F* tile = reinterpret_cast<F*>(ntt_lds);
     const unsigned tid = threadIdx.x, nt = blockDim.x;
-    if (DIF || R == 0) ntt_lat_load<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
-    else               ntt_lat_head_dit<F, INV, R>(data, tile, T, P, blockIdx.x, tid, nt);
+    ntt_lat_load<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
     __syncthreads();
-    // DIF: stages 0 .. S-R-1 as rounds, then the tail; DIT: the head did stages 0 .. R-1, rounds R .. S-1
-    for (unsigned t = DIF ? 0 : R; t < (DIF ? P.S - R : P.S); t++) {
+    for (unsigned t = 0; t < P.S; t++) {
         ntt_lat_stage<F, DIF, INV>(tile, T, P, t, tid, nt);
         __syncthreads();
     }
-    if (DIF && R != 0) ntt_lat_tail_dif<F, INV, R>(data, tile, T, P, blockIdx.x, tid, nt);
-    else               ntt_lat_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+    ntt_lat_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
+}
+
+// ---- whole transforms of <= 2^10 elements: ONE work-group, ONE launch (round 5) ----------------------------------------
+// A small transform is pure latency: one launch costs ~3 us whatever it does, and the passes above gave a 2^8 transform
+// to SIXTEEN lanes (radix-16 in registers: 8 us of dependent arithmetic in one wave) and a 2^9 / 2^10 one two launches,
+// with a third for the bit reversal of the NN / RR orders and a fourth for a coset -- the only sizes at which the
+// reference's own build was ahead (3.0 / 4.6 / 5.1 us against 8.0 / 6.4 / 8.2, profiles/r04_ntt_vs_reference_timing.log;
+// it runs <= 2^10 in one launch too, ntt/ntt.cuh:106-107).  Here the whole array lives in LDS, a lane owns ONE butterfly
+// per stage (n/2 lanes: the shortest dependent chain), and everything the driver would otherwise launch around the
+// stages is folded into the load and the store: the bit-reversal permutations of the four orders (ntt/ntt.cuh:174-209),
+// the coset powers g^k (ntt/kernels.cu:131-153) and 1/n.  Twiddles w^k, k < n/2, are copied from the root table into
+// LDS while the data loads.  Any field: the 256-bit ones use the chunk planes of ntt_lat_get / _put.
+// Same function of the array as the driver's general path; the emulation and the GPU tests hold both against the oracle.
+enum { NTT_SMALL_GS = 1,            // GS / DIF stages (natural in -> bit-reversed out); else CT / DIT
+       NTT_SMALL_PERM_IN = 2,       // the array is bit-reversed on the way in (NN)
+       NTT_SMALL_PERM_OUT = 4,      // ... on the way out (RR)
+       NTT_SMALL_BITREV = 8,        // the reference's |bitrev| flag: which index the coset powers follow
+       NTT_SMALL_COSET_IN = 16,     // forward coset: x[p] *= g^(bitrev ? rev(p) : p) before the stages
+       NTT_SMALL_COSET_OUT = 32 };  // inverse coset: x[p] *= g^-(bitrev ? p : rev(p)) after them
+static constexpr unsigned NTT_SMALL_MAX_LG = 10;
+
+template<class F>
+SPPARK_DEVFN void ntt_small_load(const F* data, F* tile, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
+                                 unsigned tid, unsigned nt)
+{
+    const unsigned lg = T.lg_n, n = 1u << lg, nh = n >> 1;
+    F* tw = tile + n;
+    for (unsigned k = tid; k < nh; k += nt) ntt_lat_put(tw, k, nh ? nh : 1, T.lo[k]);
+    for (unsigned e = tid; e < n; e += nt) {
+        F x = data[e];
+        const unsigned p = (flags & NTT_SMALL_PERM_IN) ? bit_rev32(e, lg) : e;
+        if (flags & NTT_SMALL_COSET_IN) x = x * G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(p, lg) : p];
+        ntt_lat_put(tile, p, n, x);
+    }
+}
+// stage t of lg: GS halves n/2, n/4, ..., 1 (twiddle w^(j 2^t) on the difference); CT halves 1, 2, ..., n/2 (twiddle
+// w^(j 2^(lg-1-t)) on the odd input).  The half-1 stage multiplies by w^0: no product (a uniform branch).
+template<class F, bool GS>
+SPPARK_DEVFN void ntt_small_stage(F* tile, unsigned lg, unsigned t, unsigned tid, unsigned nt)
+{
+    const unsigned n = 1u << lg, nh = n >> 1;
+    const F* tw = tile + n;
+    const unsigned lgh = GS ? lg - 1 - t : t, half = 1u << lgh, sh = lg - 1 - lgh;
+    for (unsigned bf = tid; bf < nh; bf += nt) {
+        const unsigned j = bf & (half - 1), i0 = ((bf >> lgh) << (lgh + 1)) + j, i1 = i0 + half;
+        const F u = ntt_lat_get(tile, i0, n);
+        F v = ntt_lat_get(tile, i1, n), sum, dif;
+        if (GS) {
+            F::bfly(u, v, sum, dif);
+            if (lgh != 0) dif = dif * ntt_lat_get(tw, j << sh, nh);
+        } else {
+            if (lgh != 0) v = v * ntt_lat_get(tw, j << sh, nh);
+            F::bfly(u, v, sum, dif);
+        }
+        ntt_lat_put(tile, i0, n, sum);
+        ntt_lat_put(tile, i1, n, dif);
+    }
+}
+template<class F, bool INV>
+SPPARK_DEVFN void ntt_small_store(F* data, const F* tile, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
+                                  unsigned tid, unsigned nt)
+{
+    const unsigned lg = T.lg_n, n = 1u << lg;
+    for (unsigned p = tid; p < n; p += nt) {
+        F x = ntt_lat_get(tile, p, n);
+        if (INV) x = x * T.scale;
+        if (flags & NTT_SMALL_COSET_OUT) x = x * G.lo[(flags & NTT_SMALL_BITREV) ? p : bit_rev32(p, lg)];
+        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(p, lg) : p] = x;
+    }
+}
+template<class F, bool INV>
+__global__ __launch_bounds__(512)
+void k_ntt_small(F* data, ntt_tables<F> T, ntt_tables<F> G, unsigned flags)
+{
+    extern __shared__ unsigned char ntt_lds[];
+    F* tile = reinterpret_cast<F*>(ntt_lds);
+    const unsigned tid = threadIdx.x, nt = blockDim.x, lg = T.lg_n;
+    ntt_small_load<F>(data, tile, T, G, flags, tid, nt);
+    __syncthreads();
+    if (flags & NTT_SMALL_GS)                                   // (uniform over the launch)
+        for (unsigned t = 0; t < lg; t++) { ntt_small_stage<F, true>(tile, lg, t, tid, nt); __syncthreads(); }
+    else
+        for (unsigned t = 0; t < lg; t++) { ntt_small_stage<F, false>(tile, lg, t, tid, nt); __syncthreads(); }
+    ntt_small_store<F, INV>(data, tile, T, G, flags, tid, nt);
+}
+// the flags of an (order, direction, type) call -- ntt/ntt.cuh:174-209: NN = bit_rev + CT, NR = GS, RN = CT, RR = GS + bit_rev
+static inline unsigned ntt_small_flags(int order, bool inverse, bool coset)
+{
+    unsigned f = 0;
+    switch (order) {
+        case 0:  f = NTT_SMALL_PERM_IN | NTT_SMALL_BITREV; break;
+        case 1:  f = NTT_SMALL_GS; break;
+        case 2:  f = NTT_SMALL_BITREV; break;
+        default: f = NTT_SMALL_GS | NTT_SMALL_BITREV | NTT_SMALL_PERM_OUT; break;
+    }
+    if (coset) f |= inverse ? NTT_SMALL_COSET_OUT : NTT_SMALL_COSET_IN;
+    return f;
 }
 
 // (R1, R2) = (ceil(S/2), floor(S/2)); CALL(R1, R2) is expanded for the pass's S

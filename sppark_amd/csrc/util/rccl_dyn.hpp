@@ -5,19 +5,26 @@
 // on using that one, because a communicator is only valid inside the library instance that made it.  So the caller
 // creates the communicator (ncclCommInitRank in ITS copy), and the three entry points used here are looked up in the
 // library SPPARK_RCCL_LIB names when set, else in the copy that is already mapped (RTLD_NOLOAD), else in librccl.so.1.
-// Types and enum values come from <rccl/rccl.h>; nothing of it is called directly.
+// The few types and values of the NCCL/RCCL ABI that these three calls need are declared HERE (they have been stable
+// since NCCL 2.0: ncclSuccess = 0, ncclUint8 = 1, an opaque communicator handle), so the libraries build on a ROCm
+// install without the rccl development headers; tests/test_abi.py checks them against <rccl/rccl.h> where that exists.
 #pragma once
 #include "runtime.hpp"
-#include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <cerrno>
 
 namespace sppark_amd {
 
+typedef struct ncclComm* ncclComm_t;                // opaque (rccl.h: typedef struct ncclComm* ncclComm_t)
+typedef int ncclResult_t;                           // enum; ncclSuccess = 0
+typedef int ncclDataType_t;                         // enum; ncclUint8 = 1 (ncclInt8 = 0)
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint8 = 1;
+
 struct rccl_dyn {
-    decltype(&ncclAllGather)      all_gather = nullptr;
-    decltype(&ncclCommCount)      comm_count = nullptr;
-    decltype(&ncclGetErrorString) error_string = nullptr;
+    ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
+    const char*  (*error_string)(ncclResult_t) = nullptr;
     std::string origin;
 
     static const rccl_dyn& get()

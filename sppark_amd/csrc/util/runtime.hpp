@@ -156,7 +156,7 @@ struct dev_scratch_pool {
         {
             std::lock_guard<std::mutex> lk(m);
             idle.push_back(item{dev, p, bytes});
-            // the smallest buffers go first: over the count, or while the idle bytes exceed the limit
+            // over the count (more than four idle buffers): the smallest goes; over the byte limit: the largest
             for (;;) {
                 size_t total = 0;
                 for (auto& it : idle) total += it.bytes;

@@ -32,7 +32,8 @@ class SpparkError(RuntimeError):
 
 
 def lib_path(name):
-    return os.path.join(_HERE, "lib", "libsppark_%s.so" % name)
+    # (SPPARK_LIBDIR: a second build with other flags for an A/B job of tools/, see sppark_amd/build.py)
+    return os.path.join(_HERE, os.environ.get("SPPARK_LIBDIR", "lib"), "libsppark_%s.so" % name)
 
 
 def load(name):
@@ -66,6 +67,8 @@ def load(name):
         if name not in NO_G2:
             L.mult_pippenger_fp2_inf.argtypes = [vp, vp, sz, vp, sz]
             L.mult_pippenger_fp2_inf.restype = _Error
+            L.sppark_msm_g2_path.argtypes = [ctypes.c_uint]
+            L.sppark_msm_g2_path.restype = _Error
             L.sppark_g2_jacobian_sum.argtypes = [vp, vp, sz]
             L.sppark_g2_jacobian_sum.restype = None
             L.sppark_g2_to_affine.argtypes = [vp, vp]

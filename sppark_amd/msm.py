@@ -237,6 +237,13 @@ def batch_addition(points, bitmap, refmap=None, curve="bls12_381", ffi_affine_sz
     return out
 
 
+def set_g2_path(mode, curve="bls12_381"):
+    """sppark_msm_g2_path: the accumulation kernel of the G2 entry point (process-wide per library): 0 = automatic
+    (a pair of waves per addition, one Fp2 component each, for the 14-limb base fields), 1 = wave pairs, 2 = one lane."""
+    L = ffi.load(curve)
+    ffi.check(L, L.sppark_msm_g2_path(int(mode)))
+
+
 def multi_scalar_mult_fp2_arkworks(points, scalars, curve="bls12_381", ffi_affine_sz=None):
     """mult_pippenger_fp2_inf (poc/msm-cuda/src/lib.rs:84-119): MSM over G2.
 

@@ -280,9 +280,9 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
                 for (unsigned c0 = 0; c0 < ((p.chunks_per_win + 63) / 64) * 64; c0 += 64)
                     run_group(G2C_NT, [&](unsigned tid) {
                         const g2c_ctx<inst_fp> c{&ex, tid >> 6, tid & 63};
-                        if (c.role == 0) accumulate_chunk_g2c<inst_fp, false, 0>(buckets.data(), keyA.data(), ptA.data(), pts, sorted.data(), off.data(),
+                        if (c.role == 0) accumulate_chunk_g2c<inst_fp, 0>(buckets.data(), keyA.data(), ptA.data(), pts, sorted.data(), off.data(),
                                                                                  p.n, p.NB, p.L, p.chunks_per_win, c0 + c.lane, w, 0, c);
-                        else             accumulate_chunk_g2c<inst_fp, false, 1>(buckets.data(), keyA.data(), ptA.data(), pts, sorted.data(), off.data(),
+                        else             accumulate_chunk_g2c<inst_fp, 1>(buckets.data(), keyA.data(), ptA.data(), pts, sorted.data(), off.data(),
                                                                                  p.n, p.NB, p.L, p.chunks_per_win, c0 + c.lane, w, 0, c);
                     });
         }

@@ -131,8 +131,6 @@ extern "C" void emu_ntt_plan(unsigned r64_min, unsigned r64_direct) { g_r64_min 
 // log2 columns per tile row, log2 tile elements -- as ntt_engine's lat_* choices
 static unsigned g_lat_smax = sizeof(F) > 8 ? 8 : 0;         // as ntt_engine<F>::LAT_SMAX
 static int g_lat_lgc = -1, g_lat_lgtile = -1;               // -1: the shape by size (make_ntt_lat_plan)
-static unsigned g_lat_tail = 0;                              // SPPARK_NTT_LAT_TAIL: 0, 2 or 3 small-half stages in registers
-extern "C" void emu_ntt_lat_tail(unsigned r) { g_lat_tail = r; }
 // the plan of the one-stage-per-round passes for a size, as the engine makes it: out[4 * i ..] = {lg_cur, S, lgC, lgG} of
 // pass i (GS order); returns the number of passes
 extern "C" unsigned emu_ntt_lat_plan(unsigned lg, unsigned smax, int lgc, int lgtile, unsigned out[64])
@@ -144,6 +142,10 @@ extern "C" unsigned emu_ntt_lat_plan(unsigned lg, unsigned smax, int lgc, int lg
     return pl.npass;
 }
 extern "C" void emu_ntt_lat(unsigned smax, int lgc, int lgtile) { g_lat_smax = smax; g_lat_lgc = lgc; g_lat_lgtile = lgtile; }
+
+// transforms up to this size as ONE work-group (k_ntt_small); as ntt_engine::small_max_lg(); 0 = the general path
+static unsigned g_small_max = NTT_SMALL_MAX_LG;
+extern "C" void emu_ntt_small(unsigned max_lg) { g_small_max = max_lg; }
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
@@ -163,6 +165,23 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     }
     F two = F::one() + F::one();
     ntt_tables<F> T{lo.data(), hi.data(), inner.data(), lg, h, finv(field_pow(two, lg))}, G{glo.data(), ghi.data(), nullptr, lg, h, F::one()};
+
+    if (lg <= g_small_max) {                                    // k_ntt_small: load | lg stages | store, barriers between
+        const unsigned flags = ntt_small_flags(order, inverse != 0, type == 1);
+        const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
+        std::vector<F> tile(n + n / 2 + 1);
+        for (unsigned tid = 0; tid < lanes; tid++) ntt_small_load<F>(d, tile.data(), T, G, flags, tid, lanes);
+        for (unsigned t = 0; t < lg; t++)
+            for (unsigned tid = 0; tid < lanes; tid++) {
+                if (flags & NTT_SMALL_GS) ntt_small_stage<F, true>(tile.data(), lg, t, tid, lanes);
+                else                      ntt_small_stage<F, false>(tile.data(), lg, t, tid, lanes);
+            }
+        for (unsigned tid = 0; tid < lanes; tid++) {
+            if (inverse) ntt_small_store<F, true>(d, tile.data(), T, G, flags, tid, lanes);
+            else         ntt_small_store<F, false>(d, tile.data(), T, G, flags, tid, lanes);
+        }
+        return 0;
+    }
 
     bool bitrev, gs;
     switch (order) {
@@ -207,26 +226,15 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
         }
         if (lat) {
             tile.resize(tile_elems);
-            // (R: as ntt_engine::run picks the kernel -- the knob's value where the pass has that many stages, else 0)
-#define EMU_LAT(DIF, INV, R)                                                                                       \
+#define EMU_LAT(DIF, INV)                                                                                          \
             for (size_t tile_id = 0; tile_id < n / tile_elems; tile_id++) {                                        \
-                for (unsigned tid = 0; tid < nt; tid++) {                                                          \
-                    if (DIF || R == 0) ntt_lat_load<F, DIF>(d, tile.data(), T, P, tile_id, tid, nt);               \
-                    else               ntt_lat_head_dit<F, INV, (R ? R : 1)>(d, tile.data(), T, P, tile_id, tid, nt); \
-                }                                                                                                  \
-                for (unsigned t = DIF ? 0 : R; t < (DIF ? P.S - R : P.S); t++)                                     \
+                for (unsigned tid = 0; tid < nt; tid++) ntt_lat_load<F, DIF>(d, tile.data(), T, P, tile_id, tid, nt); \
+                for (unsigned t = 0; t < P.S; t++)                                                                 \
                     for (unsigned tid = 0; tid < nt; tid++) ntt_lat_stage<F, DIF, INV>(tile.data(), T, P, t, tid, nt); \
-                for (unsigned tid = 0; tid < nt; tid++) {                                                          \
-                    if (DIF && R != 0) ntt_lat_tail_dif<F, INV, (R ? R : 1)>(d, tile.data(), T, P, tile_id, tid, nt); \
-                    else               ntt_lat_store<F, DIF>(d, tile.data(), T, P, tile_id, tid, nt);              \
-                }                                                                                                  \
+                for (unsigned tid = 0; tid < nt; tid++) ntt_lat_store<F, DIF>(d, tile.data(), T, P, tile_id, tid, nt); \
             }
-#define EMU_LAT_R(DIF, INV)                                                                                        \
-            do { const unsigned r = g_lat_tail && P.S >= g_lat_tail ? g_lat_tail : 0;                              \
-                 if (r == 3) { EMU_LAT(DIF, INV, 3) } else if (r == 2) { EMU_LAT(DIF, INV, 2) } else { EMU_LAT(DIF, INV, 0) } } while (0)
-            if (gs) { if (inverse) EMU_LAT_R(true, true); else EMU_LAT_R(true, false); }
-            else    { if (inverse) EMU_LAT_R(false, true); else EMU_LAT_R(false, false); }
-#undef EMU_LAT_R
+            if (gs) { if (inverse) { EMU_LAT(true, true) } else { EMU_LAT(true, false) } }
+            else    { if (inverse) { EMU_LAT(false, true) } else { EMU_LAT(false, false) } }
 #undef EMU_LAT
             continue;
         }

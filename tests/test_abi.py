@@ -142,3 +142,29 @@ def test_header_is_plain_c_and_cxx(tmp_path):
         src = tmp_path / ("t." + ext)
         src.write_text(body)
         subprocess.check_call([cc, std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)])
+
+
+def test_rccl_abi_constants_match_the_installed_header(tmp_path):
+    """csrc/util/rccl_dyn.hpp declares the handful of NCCL/RCCL ABI facts it needs itself (so that the libraries build
+    without the rccl development headers): hold them against <rccl/rccl.h> where that header is installed."""
+    import subprocess
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl development header on this machine")
+    src = tmp_path / "rccl_abi.cpp"
+    src.write_text('''
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <type_traits>
+static_assert((int)ncclSuccess == 0, "ncclSuccess");
+static_assert((int)ncclUint8 == 1 && (int)ncclInt8 == 0, "ncclUint8");
+static_assert(sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int), "enums are ints");
+static_assert(std::is_pointer<ncclComm_t>::value, "opaque communicator handle");
+static_assert(std::is_same<decltype(&ncclAllGather), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value, "ncclAllGather");
+static_assert(std::is_same<decltype(&ncclCommCount), ncclResult_t (*)(const ncclComm_t, int*)>::value, "ncclCommCount");
+static_assert(std::is_same<decltype(&ncclGetErrorString), const char* (*)(ncclResult_t)>::value, "ncclGetErrorString");
+int main() { return 0; }
+''')
+    r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--cuda-host-only", "-std=c++17", "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

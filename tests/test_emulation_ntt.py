@@ -31,9 +31,41 @@ def _emu(feature):
     L.emu_ntt_lat.restype = None
     L.emu_ntt_lat_plan.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint)]
     L.emu_ntt_lat_plan.restype = ctypes.c_uint
-    L.emu_ntt_lat_tail.argtypes = [ctypes.c_uint]
-    L.emu_ntt_lat_tail.restype = None
+    L.emu_ntt_small.argtypes = [ctypes.c_uint]
+    L.emu_ntt_small.restype = None
     return L
+
+
+FIELDS = [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR"), ("bls12_381", "BLS12_381"), ("bn254", "BN254")]
+
+
+def _oracle_ntt(O, field):
+    if field in ("bls12_381", "bn254"):
+        curve = O.BLS12_381 if field == "bls12_381" else O.BN254
+        return lambda x, order, direction, typ: O.ntt_fr(curve, x, order, direction, typ)
+    return O.ntt_gl64 if field == "gl64" else O.ntt_bb31
+
+
+@pytest.mark.parametrize("field,feature", FIELDS)
+def test_small_transforms_in_one_work_group_on_host(oracle, field, feature):
+    """k_ntt_small (what ntt_engine::run launches up to 2^10 elements: load with the order's permutation and the coset
+    powers, lg one-butterfly-per-lane stages in LDS, store with 1/n, the inverse coset powers and RR's permutation):
+    every size 2^1 .. 2^10, every order, direction and type against the oracle, with the lane counts the driver uses."""
+    L = _emu(feature)
+    f = _oracle_ntt(oracle, field)
+    L.emu_ntt_small(10)
+    for lg in range(1, 11):
+        x = recipe.ntt_input(field, lg, 900 + lg)
+        for order in range(4):
+            for direction in range(2):
+                for typ in range(2):
+                    y = x.copy()
+                    L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64)
+                    assert (y == f(x, order, direction, typ)).all(), (field, lg, order, direction, typ)
+        # forward then inverse is the identity in every order pairing the reference's tests use (poc/ntt-cuda/tests/ntt.rs)
+        y = x.copy()
+        L.emu_ntt(y.ctypes.data, lg, 1, 0, 1, 64); L.emu_ntt(y.ctypes.data, lg, 2, 1, 1, 64)
+        assert (y == x).all()
 
 
 @pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR"),
@@ -47,6 +79,7 @@ def test_ntt_kernels_on_host(oracle, field, feature):
     else:
         f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
     wide = field in ("bls12_381", "bn254")
+    L.emu_ntt_small(0)                                          # the general path at every size (k_ntt_small has its own test)
     # the 256-bit fields: the engine's default passes (one stage per round, up to 8 stages) and the register passes
     # (radix-4 x radix-4; SPPARK_NTT_LAT_SMAX=0)
     for lat in ((8, 0) if wide else (0,)):
@@ -64,6 +97,7 @@ def test_ntt_kernels_on_host(oracle, field, feature):
                         L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 10 else 256)
                         assert (y == f(x, order, direction, typ)).all(), (field, lat, lg, order, direction, typ)
     L.emu_ntt_lat(8 if wide else 0, -1, -1)
+    L.emu_ntt_small(10)
 
 
 @pytest.mark.parametrize("field,feature", [("gl64", "GOLDILOCKS"), ("bb31", "BABY_BEAR"),
@@ -132,16 +166,14 @@ def test_ntt_one_stage_per_round_passes_on_host(oracle, field, feature):
     else:
         f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
     try:
+        L.emu_ntt_small(0)                                          # the passes, also where the engine runs k_ntt_small
         L.emu_ntt_plan(99, 20)                                      # (Goldilocks: generic passes, not the radix-64 plan)
-        # (tail: SPPARK_NTT_LAT_TAIL -- the 2 or 3 small-half stages of a pass in registers, fused with its store / load)
-        for smax, lgc, lgtile, tail in ((8, -1, -1, 0), (8, 2, 10, 0), (8, 0, 8, 0), (6, 4, 11, 0), (5, 1, 9, 0), (3, 2, 6, 0),
-                                        (8, -1, -1, 3), (8, 2, 10, 2), (6, 4, 11, 3), (5, 1, 9, 3), (3, 2, 6, 2)):
+        for smax, lgc, lgtile in ((8, -1, -1), (8, 2, 10), (8, 0, 8), (6, 4, 11), (5, 1, 9), (3, 2, 6)):
             if field == "gl64" and smax > 6:
                 continue
             L.emu_ntt_lat(smax, lgc, lgtile)
-            L.emu_ntt_lat_tail(tail)
             for lg in (1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13):
-                if lg > 11 and (smax, lgc, tail) not in ((8, -1, 0), (6, 4, 0), (8, -1, 3)):
+                if lg > 11 and (smax, lgc) not in ((8, -1), (6, 4)):
                     continue
                 x = recipe.ntt_input(field, lg, 500 + lg)
                 for order in range(4):
@@ -151,11 +183,11 @@ def test_ntt_one_stage_per_round_passes_on_host(oracle, field, feature):
                                 continue
                             y = x.copy()
                             L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64 if lg < 9 else 256)
-                            assert (y == f(x, order, direction, typ)).all(), (field, smax, lgc, lgtile, tail, lg, order, direction, typ)
+                            assert (y == f(x, order, direction, typ)).all(), (field, smax, lgc, lgtile, lg, order, direction, typ)
     finally:
-        L.emu_ntt_lat_tail(0)
         L.emu_ntt_lat(8 if field in ("bls12_381", "bn254") else 0, -1, -1)      # the engine's defaults
         L.emu_ntt_plan(12, 20)
+        L.emu_ntt_small(10)
 
 
 def test_one_stage_per_round_plan_invariants():

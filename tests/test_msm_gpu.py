@@ -483,9 +483,23 @@ def test_go_bridge_smoke_and_gpu_ptr(libs):
 
 # ------------------------------------------------------------------- G2 --------
 G2 = [("bls12_381", 2), ("bn254", 3), ("bls12_377", 5)]
+G2_PATHS = [(1, "wave_pairs"), (2, "one_lane")]
 
 
-def test_msm_g2_golden_vectors(oracle, libs):
+@pytest.fixture(params=G2_PATHS, ids=[p[1] for p in G2_PATHS])
+def g2_path(request, libs):
+    """Both accumulation kernels of the G2 entry point (sppark_msm_g2_path): a pair of waves per addition with one Fp2
+    component each (msm_g2c_kernels.hpp; the default over the 14-limb base fields) and one lane per addition
+    (k_accumulate<fp2x_dev>; the default over alt_bn128).  Every G2 test runs under both, on every curve."""
+    import sppark_amd
+    for name, _ in G2:
+        sppark_amd.set_g2_path(request.param[0], name)
+    yield request.param[1]
+    for name, _ in G2:
+        sppark_amd.set_g2_path(0, name)
+
+
+def test_msm_g2_golden_vectors(oracle, libs, g2_path):
     """mult_pippenger_fp2_inf against the vectors produced by the reference's own templates
     over Fp2 and the 30*G2 KAT of an independent Python group law."""
     import sppark_amd
@@ -507,7 +521,7 @@ def test_msm_g2_golden_vectors(oracle, libs):
 
 @pytest.mark.parametrize("name,curve", G2)
 @pytest.mark.parametrize("n", [1, 3, 64, 65, 1000, 4097, 1 << 14])
-def test_msm_g2_vs_oracle(oracle, libs, name, curve, n):
+def test_msm_g2_vs_oracle(oracle, libs, g2_path, name, curve, n):
     """the shape of poc/msm-cuda/tests/msm.rs:41-63 (G2 against a CPU MSM) + ragged sizes"""
     import sppark_amd
     O = oracle
@@ -516,7 +530,7 @@ def test_msm_g2_vs_oracle(oracle, libs, name, curve, n):
     assert (sppark_amd.to_affine_g2(out, name) == O.msm_affine(curve, pts, sc, algo=0, param=8)).all(), (name, n)
 
 
-def test_msm_g2_edge_cases(oracle, libs):
+def test_msm_g2_edge_cases(oracle, libs, g2_path):
     import torch
     import sppark_amd
     O = oracle
@@ -543,7 +557,7 @@ def test_msm_g2_edge_cases(oracle, libs):
     assert (sppark_amd.to_affine_g2(sppark_amd.jacobian_sum_g2(np.stack([a, b]), name), name) == exp).all()
 
 
-def test_msm_g2_large_linearity(oracle, libs):
+def test_msm_g2_large_linearity(oracle, libs, g2_path):
     """2^18 G2 points: MSM(P, a) + MSM(P, b) == MSM(P, a + b mod r); the 2^12 prefix equals the oracle."""
     import sppark_amd
     O = oracle
@@ -959,12 +973,17 @@ def test_msm_rccl_exchange_single_rank(oracle, libs):
         assert (multi_gpu.msm_rccl(pts[:0], sc[:0], comm, ffi_affine_sz=pts.shape[1]) == 0).all()      # a rank without points
         part = sppark_amd.multi_scalar_mult_arkworks(pts, sc)
         assert (multi_gpu.rccl_sum(part, comm) == part).all()
+        # IN PLACE (out == partial, what a caller does right after an MSM entry point filled `out`): the partial sum is
+        # read before `out` is cleared
+        from sppark_amd import ffi
+        inplace = part.copy()
+        ffi.check(ffi.load("bls12_381"), ffi.load("bls12_381").sppark_msm_rccl_sum(inplace.ctypes.data, inplace.ctypes.data, 0, comm.handle, None))
+        assert (sppark_amd.to_affine(inplace) == exp).all()
         name2, curve2 = G2[0]
         p2, s2 = recipe.msm_inputs(curve2, 65, 99, ndistinct=16, flagged=True)
         part2 = sppark_amd.multi_scalar_mult_fp2_arkworks(p2, s2, name2)
         assert (sppark_amd.to_affine_g2(multi_gpu.rccl_sum(part2, comm, name2, g2=True), name2) == sppark_amd.to_affine_g2(part2, name2)).all()
         # a local failure (a stride below two field elements) is reported with `out` at infinity; the collective still ran
-        from sppark_amd import ffi
         L = ffi.load("bls12_381")
         out = np.full(144, 0xff, dtype=np.uint8)
         err = L.sppark_msm_rccl(out.ctypes.data, pts.ctypes.data, n, sc.ctypes.data, 0, 8, comm.handle, None)

@@ -121,10 +121,10 @@ SPPARK_DEVFN void coop_add(xyzz_dev<F>& a, const xyzz_dev<F>& b, coop_ctx<F>& c)
     c.next_level();
     const F PPP = c.get(0), Q = c.get(1), ZZ3 = c.get(2);
     const F T  = PPP + Q + Q;                                   // < 6p
-    const F X3 = F::template sub<8, 3>(RR, T);                  // < 10p, limbs <= 5*2^LB
+    const F X3 = xyzz_dev<F>::keep_x(F::template sub<8, 3>(RR, T));     // < 10p, limbs <= 5*2^LB (29-bit limbs: n)
     // level 4: Y3 = R*(Q - X3) - S1*PPP as one reduced sum of two products; ZZZ3 = (ZZZ1*ZZZ2)*PPP
     if (role == 0) {
-        const F D = F::template sub<11, 6>(Q, X3);
+        const F D = F::template sub<11, xyzz_dev<F>::BX>(Q, X3);
         c.put(0, F::mul_add(D, Rd, F::template neg<3>(S1), PPP));
     } else if (role == 3) {
         c.put(3, keep * PPP);
@@ -170,10 +170,10 @@ SPPARK_DEVFN void coop_dbl(xyzz_dev<F>& a, coop_ctx<F>& c)
     }
     c.next_level();
     const F W = c.get(0), S = c.get(1), ZZ3 = c.get(2);
-    const F X3 = F::template sub<5, 2>(c.get(3), S + S);        // < 7p, limbs <= 4*2^LB
+    const F X3 = xyzz_dev<F>::keep_x(F::template sub<5, 2>(c.get(3), S + S));   // < 7p, limbs <= 4*2^LB (29-bit limbs: n)
     // level 3: Y3 = M3*(S - X3) - W*Y as one reduced sum; ZZZ3 = ZZZ*W
     if (role == 0) {
-        const F D = F::template sub<8, 4>(S, X3);               // < 10p
+        const F D = F::template sub<8, xyzz_dev<F>::BX2>(S, X3);       // < 10p
         c.put(0, F::mul_add(D, M3, F::template neg<3>(W), Yn));
     } else if (role == 1) {
         c.put(1, a.ZZZ * W);

@@ -10,6 +10,15 @@
 //     ZZ, ZZZ  < 2p, n                  infinity: every limb of ZZ (and ZZZ) is zero
 //     affine input coordinates: < 2p, n
 //
+//   29-bit limbs (F::TIGHT: alt_bn128 G1 on NINE limbs, rho = 169): a lazy sum wraps at 8*2^LB instead of 16, the left
+//   operand of a product may reach 4*2^LB instead of 8 and mul_add takes two left operands of <= 3*2^LB each.  X is
+//   therefore kept NORMALISED (one norm() per new X3; in return it is subtracted with B = 1) and Y tighter:
+//
+//     X   < 10p, n                      Y   < 3p, limbs <= 2*2^LB          ZZ, ZZZ  < 2p, n
+//
+//   and every product of the formulas is still < 2p (the largest: P^2 with P < 13p, 169/169.3 + 1).  Both sets of
+//   bounds are machine-checked from the loosest admissible operands by tests/emu/emu_bounds.cpp.
+//
 //   These hold for every value written to memory, so any kernel can load any bucket.
 //   sub<K, B>(a, b) = a + K*p - b needs b < (K-1)*p and b's limbs <= B*(2^LB - 1);
 //   operator* needs its right operand n and its left operand's limbs < 2^31; sqr() needs n.
@@ -70,6 +79,12 @@ template<class P, int LB> struct affine_loader<montx_dev<P, LB>> {
 template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
     typedef montx_dev<P, LB> F;
     F X, Y, ZZZ, ZZ;
+    // see the table at the top: with 29-bit limbs a fresh X3 is normalised and a stored X / Y has tighter limbs
+    static constexpr bool TIGHT = F::TIGHT;
+    static constexpr int BX = TIGHT ? 1 : 6;                // limb bound of X (and of a fresh X3) as a subtrahend
+    static constexpr int BX2 = TIGHT ? 1 : 4;               // ... of the X3 of a doubling
+    SPPARK_DEVFN static F keep_x(const F& x3) { if constexpr (TIGHT) return x3.norm(); else return x3; }
+    SPPARK_DEVFN static F minus_y(const F& y) { if constexpr (TIGHT) return F::template neg<4, 2>(y); else return F::template neg<6, 4>(y); }
 
     SPPARK_DEVFN bool is_inf() const { return ZZ.limbs_all_zero(); }
     SPPARK_DEVFN void set_inf() { X = F::zero(); Y = F::zero(); ZZZ = F::zero(); ZZ = F::zero(); }
@@ -89,20 +104,21 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         F U2, S2;
         F::template mul2<true, true>(U2, S2, p.X, ZZ, p.Y, ZZZ);   // all four operands n: < 2p, n (pairs of products are interleaved)
         if (negate) S2 = F::template neg<3>(S2);            // < 3p, limbs <= 2*2^LB
-        F Pd = F::template sub<11, 6>(U2, X).norm();        // U2 - X      < 13p, n
-        F Rd = F::template sub<6, 4>(S2, Y).norm();         // +-S2 - Y    < 9p, n
+        F Pd = F::template sub<11, BX>(U2, X).norm();       // U2 - X      < 13p, n
+        F Rd;                                               // +-S2 - Y    < 9p, n (TIGHT: < 7p)
+        if constexpr (TIGHT) Rd = F::template sub<4, 2>(S2, Y).norm(); else Rd = F::template sub<6, 4>(S2, Y).norm();
 
         if (!Pd.template is_zero_mod<13>()) {               // fast path
             F PP, RR, PPP, Q;
             F::sqr2(PP, RR, Pd, Rd);                        // n, < 2p
             F::template mul2<true, false>(PPP, Q, Pd, PP, X, PP);  // Pd n; the left operand of the second one fat: allowed
             F T   = PPP + Q + Q;                            // < 6p, limbs <= 3*(2^LB - 1)
-            F X3  = F::template sub<8, 3>(RR, T);           // < 10p, limbs <= 5*2^LB
-            F D   = F::template sub<11, 6>(Q, X3);          // Q - X3      < 13p, limbs < 2^31
+            F X3  = keep_x(F::template sub<8, 3>(RR, T));   // < 10p, limbs <= 5*2^LB (TIGHT: n)
+            F D   = F::template sub<11, BX>(Q, X3);         // Q - X3      < 13p, limbs < 2^31 (TIGHT: <= 3*2^LB)
             // Y3 = R*(Q - X3) - Y1*PPP as ONE reduced sum of two products: D*Rd + (6p - Y)*PPP
             // (6p - Y: Y < 5p with limbs < 3*2^LB, negated against the fat 6p whose limbs are >= 4*2^LB - 4;
             // the result's limbs are < 5*2^LB)
-            F nY  = F::template neg<6, 4>(Y);               // < 6p
+            F nY  = minus_y(Y);                             // < 6p (TIGHT: 4p - Y < 4p, limbs <= 3*2^LB)
             Y   = F::mul_add(D, Rd, nY, PPP);               // < (13*9 + 6*2)p/rho + p < 2p, n
             F::template mul2<true, true>(ZZ, ZZZ, ZZ, PP, ZZZ, PPP);       // n x n
             X = X3;
@@ -133,8 +149,8 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
             F PPP = Pd * PP;
             F Q   = U1 * PP;
             F T   = PPP + Q + Q;
-            F X3  = F::template sub<8, 3>(Rd.sqr(), T);
-            F D   = F::template sub<11, 6>(Q, X3);
+            F X3  = keep_x(F::template sub<8, 3>(Rd.sqr(), T));
+            F D   = F::template sub<11, BX>(Q, X3);
             Y   = F::mul_add(D, Rd, F::template neg<3>(S1), PPP);      // one reduction (see madd); n, < 2p
             ZZ  = (ZZ * PP) * q.ZZ;
             ZZZ = (ZZZ * PPP) * q.ZZZ;
@@ -168,8 +184,8 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
             F::sqr2(PP, RR, Pd, Rd);
             F::template mul2<true, true>(PPP, Q, Pd, PP, U1, PP);
             F T   = PPP + Q + Q;
-            F X3  = F::template sub<8, 3>(RR, T);
-            F D   = F::template sub<11, 6>(Q, X3);
+            F X3  = keep_x(F::template sub<8, 3>(RR, T));
+            F D   = F::template sub<11, BX>(Q, X3);
             Y   = F::mul_add(D, Rd, F::template neg<3>(S1), PPP);
             F::template mul2<true, true>(t0, t1, ZZ, PP, ZZZ, PPP);
             F::template mul2<true, true>(ZZ, ZZZ, t0, q.ZZ, t1, q.ZZZ);
@@ -193,8 +209,8 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         F::template mul2<true, true>(W, S, U, V, Xn, V);
         F M3 = (M + M + M).norm();                          // < 6p
         M3s = M3.sqr();
-        F X3 = F::template sub<5, 2>(M3s, S + S);           // < 7p, limbs <= 4*2^LB
-        F D  = F::template sub<8, 4>(S, X3);                // < 10p
+        F X3 = keep_x(F::template sub<5, 2>(M3s, S + S));   // < 7p, limbs <= 4*2^LB (TIGHT: n)
+        F D  = F::template sub<8, BX2>(S, X3);              // < 10p
         Y = F::mul_add(D, M3, F::template neg<3>(W), Yn);
         F::template mul2<true, true>(ZZ, ZZZ, ZZ, V, ZZZ, W);
         X = X3;
@@ -216,8 +232,8 @@ template<class P, int LB> struct xyzz_dev<montx_dev<P, LB>> {
         F S = Xn * V;
         F M = Xn.sqr();
         F M3 = (M + M + M).norm();                          // < 6p
-        F X3 = F::template sub<5, 2>(M3.sqr(), S + S);      // < 7p, limbs <= 4*2^LB
-        F D  = F::template sub<8, 4>(S, X3);                // < 10p
+        F X3 = keep_x(F::template sub<5, 2>(M3.sqr(), S + S));     // < 7p, limbs <= 4*2^LB (TIGHT: n)
+        F D  = F::template sub<8, BX2>(S, X3);              // < 10p
         Y = F::mul_add(D, M3, F::template neg<3>(W), Yn);
         ZZ = ZZ * V; ZZZ = ZZZ * W;
         X = X3;
@@ -269,8 +285,8 @@ private:
         F S = x * V;
         F M = x.sqr();
         F M3 = (M + M + M).norm();
-        F X3 = F::template sub<5, 2>(M3.sqr(), S + S);
-        F D  = F::template sub<8, 4>(S, X3);
+        F X3 = keep_x(F::template sub<5, 2>(M3.sqr(), S + S));
+        F D  = F::template sub<8, BX2>(S, X3);
         Y = F::mul_add(D, M3, F::template neg<3>(W), y);
         X = X3; ZZ = V; ZZZ = W;
     }

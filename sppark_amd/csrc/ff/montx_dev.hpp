@@ -76,7 +76,23 @@ extern "C" void sppark_bound_violation(const char* what, double got, double limi
 #endif
 template<class P, int LB> struct montx_dev {
     static constexpr int NW = P::N;                         // 32-bit words of the standard wire form
-    static constexpr int NL = (P::NBITS + 8 + LB - 1) / LB; // >= 8 bits of head-room above the modulus
+    // head-room above the modulus: >= 8 bits with 28-bit limbs (rho = 2^RBITS / p >= 256: a product of any two values the
+    // point formulas hold is < (1 + small) p); >= 7 bits with 29-bit limbs -- NINE limbs for a 254-bit modulus, rho = 169
+    // for alt_bn128: every product of the formulas still comes out < 2 p, which is all they ask (ec/xyzzx_dev.hpp, TIGHT)
+    static constexpr int HEAD = LB <= 28 ? 8 : 7;
+    static constexpr int NL = (P::NBITS + HEAD + LB - 1) / LB;
+    // what 32-bit limbs of LB significant bits leave: a lazy sum may reach CAP * 2^LB before it wraps, the left operand
+    // of a product 2^31 = FAT_L * 2^LB.  TIGHT (LB = 29: 8 and 4 instead of 16 and 8) is what the point formulas key on.
+    static constexpr int CAP = 1 << (32 - LB);
+    static constexpr int FAT_L = 1 << (31 - LB);
+    static constexpr bool TIGHT = LB > 28;
+    // unmasked quotient digits (quotient_digit<true>) need NL (2^32 2^LB + 2^2LB) + carry < 2^64: 28-bit limbs only
+    static constexpr bool FAT_M_OK = (double)NL * (4294967296.0 * (double)(1ull << LB) + (double)(1ull << LB) * (double)(1ull << LB))
+                                     + 68719476736.0 < 18446744073709551616.0;
+    // mul_add's two left operands: limbs < 2^31 and <= 6 2^LB (LB = 28); <= 3 2^LB each with 29-bit limbs
+    static constexpr int MA_A0 = TIGHT ? 3 : FAT_L, MA_A1 = TIGHT ? 3 : 6;
+    // sqr()'s operand: limbs <= SQR_L 2^LB (cross products use the doubled operand)
+    static constexpr int SQR_L = TIGHT ? 2 : 4;
     static constexpr int N = NL;                            // words of the in-memory image (internal form)
     static constexpr u32 MASK = (1u << LB) - 1;
     static constexpr int RBITS = LB * NL;                   // Montgomery radix 2^RBITS
@@ -246,8 +262,8 @@ template<class P, int LB> struct montx_dev {
         #pragma unroll
         for (int j = 0; j < NL - 1; j++) { u32 v = l[j] + c; r.l[j] = v & MASK; c = v >> LB; }
         r.l[NL - 1] = l[NL - 1] + c;
-        // (limb + carry must not wrap: limbs <= 15 * 2^LB; the top limb of a value < bv p is far below 2^LB)
-        SPPARK_BND(bnd_known("norm: operand"); bnd(bl <= 15.0, "norm: limbs", bl, 15.0); r.bnd_set(bv, bl < 1.0 ? bl : 1.0);)
+        // (limb + carry must not wrap: limbs <= (CAP - 1) 2^LB; the top limb of a value < bv p is far below 2^LB)
+        SPPARK_BND(bnd_known("norm: operand"); bnd(bl <= (double)(CAP - 1), "norm: limbs", bl, (double)(CAP - 1)); r.bnd_set(bv, bl < 1.0 ? bl : 1.0);)
         return r;
     }
 
@@ -257,7 +273,7 @@ template<class P, int LB> struct montx_dev {
         montx_dev r;
         #pragma unroll
         for (int j = 0; j < NL; j++) r.l[j] = a.l[j] + b.l[j];
-        SPPARK_BND(a.bnd_known("+: left"); b.bnd_known("+: right"); r.bnd_set(a.bv + b.bv, a.bl + b.bl); bnd(r.bl < 16.0, "+: limbs wrap", r.bl, 16.0);)
+        SPPARK_BND(a.bnd_known("+: left"); b.bnd_known("+: right"); r.bnd_set(a.bv + b.bv, a.bl + b.bl); bnd(r.bl < (double)CAP, "+: limbs wrap", r.bl, (double)CAP);)
         return r;
     }
 
@@ -272,7 +288,7 @@ template<class P, int LB> struct montx_dev {
                    bnd(b.bv <= (double)(K - 1), "sub<K>: subtrahend < (K-1) p", b.bv, (double)(K - 1));
                    bnd(b.bl <= (double)B, "sub<K,B>: subtrahend's limbs <= B 2^LB", b.bl, (double)B);
                    r.bnd_set(a.bv + (double)K, a.bl + (double)(B + 1));
-                   bnd(r.bl < 16.0, "sub: limbs wrap", r.bl, 16.0);)
+                   bnd(r.bl < (double)CAP, "sub: limbs wrap", r.bl, (double)CAP);)
         return r;
     }
     // K*p - b, same contract
@@ -343,9 +359,9 @@ template<class P, int LB> struct montx_dev {
     template<bool FAT_M> SPPARK_DEVFN static u32 quotient_digit(u64 A, int k)
     {
         constexpr u32 PINV = P::M0 & MASK;
-        static_assert(!FAT_M || (double)NL * (4294967296.0 * (double)(1ull << LB) + (double)(1ull << LB) * (double)(1ull << LB))
-                      + 68719476736.0 < 18446744073709551616.0, "unmasked quotient digits need the head-room of normalised operands");
-        if (FAT_M && k < NL - 1) return (u32)A * (u32)P::M0;
+        // (where the accumulator has no room for unmasked digits -- 29-bit limbs -- the request is ignored: masked digits
+        // satisfy every caller's contract)
+        if (FAT_M && FAT_M_OK && k < NL - 1) return (u32)A * (u32)P::M0;
         return ((u32)A * PINV) & MASK;
     }
 
@@ -387,13 +403,13 @@ template<class P, int LB> struct montx_dev {
     // (a0*b0 + a1*b1) / 2^RBITS with ONE Montgomery reduction (a sum of two products needs no more
     // than one: NL^2 multiply-adds saved against two separate products and a subtraction).
     // Contract: b0, b1 normalised; a0's limbs < 2^31, a1's limbs < 6*2^LB, so that a column of both
-    // products and the m*p terms stays below NL*(8 + 6 + 1)*2^(2*LB) < 2^64.  The two products run
+    // products and the m*p terms stays below NL*(8 + 6 + 1)*2^(2*LB) < 2^64 (29-bit limbs: both <= 3*2^LB, 9*7*2^58).  The two products run
     // in two accumulators (their chains interleave like mul2's) that are joined once per column.
     // Output normalised, value < (a0*b0 + a1*b1)/2^RBITS + p.
     SPPARK_DEVFN static montx_dev mul_add(const montx_dev& a0, const montx_dev& b0,
                                           const montx_dev& a1, const montx_dev& b1)
     {
-        static_assert((double)NL * ((double)(1ull << 31) + 6.0 * (double)(1ull << LB) + (double)(1ull << LB)) * (double)(1ull << LB)
+        static_assert((double)NL * ((double)MA_A0 + (double)MA_A1 + 1.0) * (double)(1ull << LB) * (double)(1ull << LB) + 68719476736.0
                       < 18446744073709551616.0, "a column of two products must fit the 64-bit accumulator");
         constexpr u32 PINV = P::M0 & MASK;
         u32 m[NL];
@@ -430,8 +446,8 @@ template<class P, int LB> struct montx_dev {
         }
         SPPARK_BND(a0.bnd_known("mul_add: a0"); b0.bnd_known("mul_add: b0"); a1.bnd_known("mul_add: a1"); b1.bnd_known("mul_add: b1");
                    bnd(b0.bl <= 1.0 && b1.bl <= 1.0, "mul_add: right operands normalised", b0.bl > b1.bl ? b0.bl : b1.bl, 1.0);
-                   bnd(a0.bl <= FAT_LEFT + 1e-6, "mul_add: a0's limbs < 2^31", a0.bl, FAT_LEFT);
-                   bnd(a1.bl <= 6.0, "mul_add: a1's limbs < 6 * 2^LB", a1.bl, 6.0);
+                   bnd(a0.bl <= (double)MA_A0 + 1e-6, "mul_add: a0's limbs <= MA_A0 2^LB", a0.bl, (double)MA_A0);
+                   bnd(a1.bl <= (double)MA_A1, "mul_add: a1's limbs <= MA_A1 2^LB", a1.bl, (double)MA_A1);
                    r.bnd_set((a0.bv * b0.bv + a1.bv * b1.bv) / rho() + 1.0, 1.0);)
         return r;
     }
@@ -475,6 +491,9 @@ template<class P, int LB> struct montx_dev {
     // NL/2 of them < 2^(2LB+5) each).
     SPPARK_DEVFN montx_dev sqr() const
     {
+        // a column: at most NL/2 cross terms l[i] * 2 l[j], one diagonal term, NL quotient-digit terms, the carry
+        static_assert(((double)(NL / 2) * 2.0 * SQR_L * SQR_L + (double)(SQR_L * SQR_L) + (double)NL) * (double)(1ull << LB) * (double)(1ull << LB)
+                      + 68719476736.0 < 18446744073709551616.0, "a column of a square of limbs <= SQR_L 2^LB must fit the 64-bit accumulator");
         constexpr u32 PINV = P::M0 & MASK;
         u32 m[NL], d[NL];
         #pragma unroll
@@ -506,7 +525,7 @@ template<class P, int LB> struct montx_dev {
             }
             A = shift_down(A);
         }
-        SPPARK_BND(bnd_known("sqr: operand"); bnd(bl <= 4.0, "sqr: limbs < 2^(LB+2)", bl, 4.0); r.bnd_set(bv * bv / rho() + 1.0, 1.0);)
+        SPPARK_BND(bnd_known("sqr: operand"); bnd(bl <= (double)SQR_L, "sqr: limbs <= SQR_L 2^LB", bl, (double)SQR_L); r.bnd_set(bv * bv / rho() + 1.0, 1.0);)
         return r;
     }
 

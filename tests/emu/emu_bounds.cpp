@@ -43,8 +43,9 @@ static void set_b(F& x, double v, double l) { x.bnd_set(v, l); }
 static double val_b(const F& x) { return x.bv; }
 static double limb_b(const F& x) { return x.bl; }
 static bool unset_b(const F& x) { return x.bv < 0 || x.bl < 0; }
-// ec/xyzzx_dev.hpp: X < 10 p with limbs <= 5 2^LB, Y < 5 p with limbs <= 3 2^LB, ZZ, ZZZ < 2 p normalised
-static constexpr double INV[4][2] = {{10, 5}, {5, 3}, {2, 1}, {2, 1}};
+// ec/xyzzx_dev.hpp: X < 10 p with limbs <= 5 2^LB, Y < 5 p with limbs <= 3 2^LB, ZZ, ZZZ < 2 p normalised;
+// with 29-bit limbs (alt_bn128 G1): X < 10 p normalised, Y < 3 p with limbs <= 2 2^LB
+static constexpr double INV[4][2] = {{10, F::TIGHT ? 1.0 : 5.0}, {F::TIGHT ? 3.0 : 5.0, F::TIGHT ? 2.0 : 3.0}, {2, 1}, {2, 1}};
 #endif
 typedef xyzz_dev<F> bucket;
 

@@ -174,7 +174,7 @@ extern "C" int emu_coop_bounds(const unsigned char* points, size_t stride, size_
 {
     g_violations = 0; g_first[0] = 0;
     if (n < 4) return -1;
-    static const double INV[4][2] = {{10, 5}, {5, 3}, {2, 1}, {2, 1}};      // X, Y, ZZZ, ZZ (ec/xyzzx_dev.hpp)
+    static const double INV[4][2] = {{10, F::TIGHT ? 1.0 : 5.0}, {F::TIGHT ? 3.0 : 5.0, F::TIGHT ? 2.0 : 3.0}, {2, 1}, {2, 1}};      // X, Y, ZZZ, ZZ (ec/xyzzx_dev.hpp; TIGHT: 29-bit limbs)
     std::vector<uint4> conv((size_t)n * affine_loader<F>::STRIDE / 16 + 1);
     for (size_t i = 0; i < n; i++) affine_loader<F>::template convert<false>((unsigned char*)conv.data(), points, i, (unsigned)stride);
     auto pt = [&](size_t i) { affine_dev<F> p = load_affine<F, false>((const unsigned char*)conv.data(), i % n, 0); p.X.bnd_set(2, 1); p.Y.bnd_set(2, 1); return p; };

@@ -8,7 +8,7 @@ host field is blst, its point classes and Pippenger are not part of its HIP path
 
 Held against it, bit for bit on the memory image (little-endian 32-bit words of the Montgomery form x * 2^(32 n)):
   * ff/mont_dev.hpp   -- the wire-format class (sppark_devtest_field_op), base AND scalar field of every curve;
-  * ff/montx_dev.hpp  -- the loosely-reduced 28-bit-limb class every G1 bucket pipeline computes in, through its own
+  * ff/montx_dev.hpp  -- the loosely-reduced 28- / 29-bit-limb class every G1 bucket pipeline computes in, through its own
                          conversions: to_std(op(from_std(a), from_std(b))) must be the reference's a op b.
 """
 import os
@@ -80,7 +80,8 @@ def test_wire_field_class_equals_the_reference_field(oracle, libs, curve, name):
 
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_bucket_field_class_equals_the_reference_field(oracle, libs, curve, name):
-    """montx_dev<fp, 28> (14 limbs over the 381 / 377-bit fields, 10 over the 254 / 255-bit ones): from_std -> op -> to_std
+    """montx_dev<fp, LB> (14 limbs of 28 bits over the 381 / 377-bit fields, 10 over the 255-bit Pasta fields, NINE 29-bit
+    limbs over alt_bn128's 254 bits): from_std -> op -> to_std
     gives the reference's a op b for * sqr + -, bit for bit; from_std followed by to_std is the identity."""
     from sppark_amd import ffi
     O = oracle
@@ -88,7 +89,7 @@ def test_bucket_field_class_equals_the_reference_field(oracle, libs, curve, name
     L = ffi.load_devtest(name)
     NL = L.sppark_devtest_bucket_field_limbs()
     p, nb = O.FP_MODULUS[curve], O.FP_BYTES[curve]
-    assert NL == (14 if nb == 48 else 10)
+    assert NL == {"bls12_381": 14, "bls12_377": 14, "bn254": 9, "pallas": 10, "vesta": 10}[name]      # bn254: nine 29-bit limbs
     NW = nb // 4
     n = 4096
     va = _vectors(p, nb, n, 7 * curve + 1)

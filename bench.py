@@ -55,7 +55,9 @@ MAD_PEAK_PER_S = MAD_RATE_PEAK * 1024 * 64 * 2.4e9
 # ff/montx_dev.hpp, ec/xyzzx_dev.hpp madd: 8 products (14x14) + 2 squares (105) + 9 Montgomery reductions
 # (14x14 each; Y3 is one reduced sum of two products)
 MADS_PER_MIXED_ADD = 8 * 196 + 2 * 105 + 9 * 196
-MADS_PER_MIXED_ADD_10 = 8 * 100 + 2 * 55 + 9 * 100    # alt_bn128 / Pasta: the same formulas on 10 limbs
+MADS_PER_MIXED_ADD_9 = 8 * 81 + 2 * 45 + 9 * 81       # alt_bn128 / Pasta: the same formulas on nine 29-bit limbs (round 5)
+# G2 (wave-pair kernel): 8 Fp2 products (two sums of two base products, one reduction each: 2 x 3 x 196) + 2 Fp2 squares (2 x 2 x 196)
+MADS_PER_G2_MIXED_ADD = 8 * 6 * 196 + 2 * 4 * 196
 
 
 def cpu_model():
@@ -297,7 +299,24 @@ def main():
                          "output_equals_ours": same,
                          "speedup_forward": r_fwd / fwd, "speedup_inverse": r_inv / inv, "speedup_forward_nn": r_nn / fwd_nn}
             del xr
+        # HBM traffic of one transform: a CONSTANT from the committed rocprofv3 --pmc passes of this workload
+        # (tools/make_ntt_pmc_traffic.py), newest round first; null for any other size
+        ntt_traffic, ntt_traffic_note = None, ""
+        for fn in ("r05_ntt_gl64_pmc.json",):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    pmc = json.load(f)
+                if pmc.get("lg") == lg and pmc.get("field") == "gl64":
+                    ntt_traffic = (pmc["fetch_bytes"] + pmc["write_bytes"]) / 1e9
+                    ntt_traffic_note = ("; traffic = the transform's launches' FETCH_SIZE (x2) + WRITE_SIZE from the committed rocprofv3 --pmc "
+                                        "passes (profiles/%s: %.2f x the algorithmic bytes; a recorded constant, not measured in this run)"
+                                        % (fn, pmc["traffic_over_algorithmic"]))
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
         ntt = {"metric": "Goldilocks NTT 2^%d elements/s (forward NR / inverse RN, device-resident)" % lg,
+               "input": {"elements": 1 << lg, "values": "torch.randint(0, 2^62) on the device, generator seed 2: 2^%d independent values, all distinct positions" % lg,
+                         "seed": 2},
                "timing": "HIP events around 20 back-to-back transforms on a non-null stream, best of 3 batches",
                "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
                "through_ffi": through_ffi,
@@ -308,10 +327,8 @@ def main():
                "roofline": {"bound": "hbm", "achieved": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": NTT_BYTES_PER_ELEM * (1 << lg) / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": 3 * NTT_BYTES_PER_ELEM * (1 << lg) / 1e9 if lg == 24 else None, "traffic_unit": "GB per transform",
-                            "note": "whole forward transform vs 16 B/element algorithmic (one read + one write of the array); traffic = "
-                                    "the three launches' FETCH_SIZE (x2) + WRITE_SIZE from the committed rocprofv3 --pmc passes at 2^24 "
-                                    "(profiles/r03_ntt_gl64_pmc.txt: 268 MB per launch; a recorded constant, not measured in this run)"}}
+                            "traffic": ntt_traffic, "traffic_unit": "GB per transform",
+                            "note": "whole forward transform vs 16 B/element algorithmic (one read + one write of the array)" + ntt_traffic_note}}
 
     extras = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -329,23 +346,8 @@ def main():
             ctx.invoke(None, sc)
         torch.cuda.synchronize()
         extras["bls12_381_g1_msm_preloaded_bases_points_per_s"] = 3 * n / (time.perf_counter() - t1)
-        # fixed-base mode of the same preloaded bases (include/sppark_amd.h sppark_msm_set_points_fixed_base: the
-        # per-window multiples of every point are built once, the MSM is ONE window over windows x n entries); from
-        # 2^23 points on; the table build is a one-time cost reported beside it.  Same scalars: same expected point.
-        if n >= (1 << 23):
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            ctx.set_points(pts, fixed_base=True)
-            torch.cuda.synchronize()
-            fb = {"table_build_s": time.perf_counter() - t1, "windows": ctx.fixed_base_windows()}
-            fout = ctx.invoke(None, sc)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(3):
-                fout = ctx.invoke(None, sc)
-            torch.cuda.synchronize()
-            fb["points_per_s"] = 3 * n / (time.perf_counter() - t1)
-            fb["equals_oracle"] = bool((sppark_amd.to_affine(fout) == expect).all())
-            assert fb["equals_oracle"], "fixed-base MSM differs from the oracle"
-            extras["bls12_381_g1_msm_fixed_base"] = fb
+        # (the fixed-base mode of the same bases -- a 4.9 s one-time table build -- is measured by tools/gpu_msm_fixed.py,
+        # profiles/r05_msm_fixed_base.log, not on every driver run)
         ctx.set_points(None)
         bctx = sppark_amd.MsmContext("bn254", device_id=-1, stream=torch.cuda.current_stream().cuda_stream)
         bctx.enable_timing(True)
@@ -357,16 +359,16 @@ def main():
             b_acc.append(bctx.kernel_ms(1))
         torch.cuda.synchronize()
         extras["alt_bn128_g1_msm_points_per_s"] = 3 * n / (time.perf_counter() - t1)
-        # configs[4]: the same two rooflines for the ten-limb pipeline (96 B per point: 64-byte affine point + 32-byte scalar)
+        # configs[4]: the same two rooflines for the nine-limb pipeline (96 B per point: 64-byte affine point + 32-byte scalar)
         b_ms, b_w = float(np.mean(b_acc)), bctx.plan(n)["windows"]
-        b_mads = float(b_w) * n * MADS_PER_MIXED_ADD_10
+        b_mads = float(b_w) * n * MADS_PER_MIXED_ADD_9
         extras["alt_bn128_g1_msm_roofline"] = {
             "kernel": "k_accumulate", "kernel_ms": b_ms, "windows": b_w,
             "hbm": {"achieved": 96 * n / (b_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 96 * n / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "alu": {"bound": "v_mad_u64_u32 issue", "achieved": b_mads / (b_ms * 1e-3) / 1e12, "peak": MAD_PEAK_PER_S / 1e12,
                     "unit": "T mad/s", "frac": b_mads / (b_ms * 1e-3) / MAD_PEAK_PER_S,
-                    "note": "%d windows x points x %d multiply-adds (8 products + 2 squares + 9 reductions on 10 limbs of 28 bits); "
-                            "three waves per SIMD" % (b_w, MADS_PER_MIXED_ADD_10)}}
+                    "note": "%d windows x points x %d multiply-adds (8 products + 2 squares + 9 reductions on 9 limbs of 29 bits; "
+                            "round 4: 10 limbs of 28 bits, 2010 multiply-adds); three waves per SIMD" % (b_w, MADS_PER_MIXED_ADD_9)}}
         bexp = O.msm_affine(O.BN254, bbase.cpu().numpy(), fold.fold_scalars(bsc, PERIOD, O.FR_MODULUS[O.BN254]), algo=0, param=8)
         extras["alt_bn128_g1_msm_equals_oracle"] = bool((sppark_amd.to_affine(bout, "bn254") == bexp).all())
         assert extras["alt_bn128_g1_msm_equals_oracle"]
@@ -416,7 +418,19 @@ def main():
             for _ in range(3):
                 sppark_amd.multi_scalar_mult_fp2_arkworks(g2pts, g2sc)
             torch.cuda.synchronize()
-            extras["bls12_381_g2_msm_2^%d_points_per_s" % lg2] = 3 * (1 << lg2) / (time.perf_counter() - t1)
+            g2_s = (time.perf_counter() - t1) / 3
+            extras["bls12_381_g2_msm_2^%d_points_per_s" % lg2] = (1 << lg2) / g2_s
+            # the accumulation by wave pairs (msm/msm_g2c_kernels.hpp; round 5) against the same multiply-add peak.  The entry
+            # point is the reference's one-shot mult_pippenger_fp2_inf, which has no per-kernel timer: the WHOLE call is the
+            # denominator, so the fraction is a lower bound of the accumulation kernel's own
+            g2_w = ctx.plan(1 << lg2)["windows"]                 # (the G2 plan is make_plan() of the same point count)
+            g2_mads = float(g2_w) * (1 << lg2) * MADS_PER_G2_MIXED_ADD
+            extras["bls12_381_g2_msm_roofline_alu"] = {
+                "bound": "v_mad_u64_u32 issue", "achieved": g2_mads / g2_s / 1e12, "peak": MAD_PEAK_PER_S / 1e12, "unit": "T mad/s",
+                "frac": g2_mads / g2_s / MAD_PEAK_PER_S, "ms_per_msm": g2_s * 1e3, "windows": g2_w,
+                "note": "%d windows x points x %d multiply-adds (8 Fp2 products + 2 Fp2 squares, one Fp2 component per wave) over the "
+                        "wall clock of the whole call (sort, conversion, bucket sums included): a lower bound for k_accumulate_g2c"
+                        % (g2_w, MADS_PER_G2_MIXED_ADD)}
             del g2pts, g2sc
         except Exception as ex:                                 # noqa: BLE001  (extras never fail the bench)
             extras["bls12_381_g2_msm_error"] = repr(ex)[:200]
@@ -546,9 +560,9 @@ def main():
         nwins = plan["windows"]
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the timed run, so the
         # value is a CONSTANT read from the committed rocprofv3 --pmc passes of this same workload
-        # (profiles/r04_pmc_traffic.json, else r03 / r02 / r01), not an in-run measurement; null for any other workload.
+        # (profiles/r05_pmc_traffic.json, else r04 / r03 / ...), not an in-run measurement; null for any other workload.
         traffic, traffic_note = None, ""
-        for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     pmc = json.load(f)

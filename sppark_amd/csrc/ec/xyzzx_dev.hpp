@@ -10,13 +10,14 @@
 //     ZZ, ZZZ  < 2p, n                  infinity: every limb of ZZ (and ZZZ) is zero
 //     affine input coordinates: < 2p, n
 //
-//   29-bit limbs (F::TIGHT: alt_bn128 G1 on NINE limbs, rho = 169): a lazy sum wraps at 8*2^LB instead of 16, the left
+//   29-bit limbs (F::TIGHT: alt_bn128 and Pasta G1 on NINE limbs, rho = 169 / 128): a lazy sum wraps at 8*2^LB instead of 16, the left
 //   operand of a product may reach 4*2^LB instead of 8 and mul_add takes two left operands of <= 3*2^LB each.  X is
 //   therefore kept NORMALISED (one norm() per new X3; in return it is subtracted with B = 1) and Y tighter:
 //
 //     X   < 10p, n                      Y   < 3p, limbs <= 2*2^LB          ZZ, ZZZ  < 2p, n
 //
-//   and every product of the formulas is still < 2p (the largest: P^2 with P < 13p, 169/169.3 + 1).  Both sets of
+//   and every product of the formulas is still < 2p (the largest: P^2 with P < 13p, 169/169.3 + 1; Pasta: < 2.33p, which
+//   only ever multiplies from the right).  Both sets of
 //   bounds are machine-checked from the loosest admissible operands by tests/emu/emu_bounds.cpp.
 //
 //   These hold for every value written to memory, so any kernel can load any bucket.

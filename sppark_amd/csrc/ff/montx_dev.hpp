@@ -77,9 +77,11 @@ extern "C" void sppark_bound_violation(const char* what, double got, double limi
 template<class P, int LB> struct montx_dev {
     static constexpr int NW = P::N;                         // 32-bit words of the standard wire form
     // head-room above the modulus: >= 8 bits with 28-bit limbs (rho = 2^RBITS / p >= 256: a product of any two values the
-    // point formulas hold is < (1 + small) p); >= 7 bits with 29-bit limbs -- NINE limbs for a 254-bit modulus, rho = 169
-    // for alt_bn128: every product of the formulas still comes out < 2 p, which is all they ask (ec/xyzzx_dev.hpp, TIGHT)
-    static constexpr int HEAD = LB <= 28 ? 8 : 7;
+    // point formulas hold is < (1 + small) p); >= 6 bits with 29-bit limbs -- NINE limbs for a 254- or 255-bit modulus,
+    // rho = 169 for alt_bn128 and 128 for the Pasta fields: the largest product of the formulas, P^2 with P < 13 p, is then
+    // < 2 p resp. < 2.33 p, and nothing asks more of it (it is only ever the normalised right operand of the next
+    // products; the machine-checked bounds of tests/emu/emu_bounds.cpp say so for every operation: ec/xyzzx_dev.hpp, TIGHT)
+    static constexpr int HEAD = LB <= 28 ? 8 : 6;
     static constexpr int NL = (P::NBITS + HEAD + LB - 1) / LB;
     // what 32-bit limbs of LB significant bits leave: a lazy sum may reach CAP * 2^LB before it wraps, the left operand
     // of a product 2^31 = FAT_L * 2^LB.  TIGHT (LB = 29: 8 and 4 instead of 16 and 8) is what the point formulas key on.

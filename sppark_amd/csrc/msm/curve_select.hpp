@@ -33,16 +33,18 @@ typedef mont_dev<curve_p::fr> fr_d;
 // 28-bit limbs against eight 32-bit ones and still win: alt_bn128's accumulation 71.8 -> 66.7 ms
 // for 2^26 points (tools/gpu_r2_job11.sh), because what the 32-bit form spends on carries exceeds
 // the 56 % more multiply-adds.
-// Round 5: alt_bn128 (254 bits) on NINE 29-bit limbs: 81 instead of 100 multiply-adds per product and per reduction
-// (ff/montx_dev.hpp: seven bits of head-room, rho = 169; the point formulas keep X normalised, ec/xyzzx_dev.hpp TIGHT).
-// The 255-bit Pasta fields would be left with rho = 128, below what P^2 of the mixed addition needs: they stay on ten
-// 28-bit limbs.  -DSPPARK_BN254_LB=28 builds the former alt_bn128 library for an A/B.
+// Round 5: the 254 / 255-bit base fields (alt_bn128, Pasta) on NINE 29-bit limbs: 81 instead of 100 multiply-adds per
+// product and per reduction (ff/montx_dev.hpp: six or seven bits of head-room, rho = 169 / 128; the point formulas keep X
+// normalised, ec/xyzzx_dev.hpp TIGHT).  alt_bn128 G1 2^26: k_accumulate 64.4 -> 57.4 ms on one box
+// (profiles/r05_bn254_lb29_ab.log).  -DSPPARK_BN254_LB=28 builds the former alt_bn128 library for an A/B.
 #if defined(FEATURE_BN254) && !defined(SPPARK_BN254_LB)
 # define SPPARK_BN254_LB 29
 #endif
-#if !defined(SPPARK_FP32LIMB)    // 381 / 377 bits: 14 limbs of 28; 255 bits: 10 limbs of 28; 254 bits: 9 limbs of 29
+#if !defined(SPPARK_FP32LIMB)    // 381 / 377 bits: 14 limbs of 28; 254 / 255 bits: 9 limbs of 29
 # if defined(FEATURE_BN254)
 typedef montx_dev<curve_p::fp, SPPARK_BN254_LB> msm_fp_d;
+# elif defined(FEATURE_PALLAS) || defined(FEATURE_VESTA)
+typedef montx_dev<curve_p::fp, 29> msm_fp_d;
 # else
 typedef montx_dev<curve_p::fp, 28> msm_fp_d;
 # endif

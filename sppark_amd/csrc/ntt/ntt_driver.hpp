@@ -116,14 +116,17 @@ class ntt_engine {
         return 24u;
 #endif
     }
-    // transforms up to this size run as one launch of one work-group (tuning builds: SPPARK_NTT_SMALL_MAX, 0 = never)
+    // transforms up to this size run as one launch of one work-group: 2^11 for the single-word fields, 2^9 for the 256-bit
+    // ones (at 2^10 their two one-stage-per-round launches are faster than eight waves of 256-bit exchanges through
+    // LDS: 17.7 against 19.7 us, profiles/r05_ntt_small_*.log).  Tuning builds: SPPARK_NTT_SMALL_MAX, 0 = never.
     static unsigned small_max_lg()
     {
+        constexpr unsigned cap = ntt_small_cap<F>::value, dflt = sizeof(F) > 8 ? cap - 1 : cap;
 #ifdef SPPARK_TUNING
-        static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_SMALL_MAX"); return e ? std::min((unsigned)atoi(e), NTT_SMALL_MAX_LG) : NTT_SMALL_MAX_LG; }();
+        static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_SMALL_MAX"); return e ? std::min((unsigned)atoi(e), cap) : dflt; }();
         return v;
 #else
-        return NTT_SMALL_MAX_LG;
+        return dflt;
 #endif
     }
     // the inter-pass twiddle table of a pass on sub-problems of 2^lg_cur elements (built once per
@@ -228,12 +231,12 @@ public:
         const size_t n = (size_t)1 << lg;
         const unsigned egrid = (unsigned)((n + 255) / 256);
 
-        // up to 2^10 elements: the whole transform -- permutations, coset powers and 1/n included -- by one work-group
+        // up to 2^11 elements (256-bit fields: 2^9): the whole transform -- permutations, coset powers and 1/n included -- by one work-group
         // in one launch (k_ntt_small, ntt_kernels.hpp)
         if (lg <= small_max_lg()) {
             const unsigned flags = ntt_small_flags(order, inverse != 0, type == NTT_COSET);
             const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
-            const size_t lds = (n + n / 2) * sizeof(F);
+            const size_t lds = lanes > 64 ? 2 * (size_t)lanes * sizeof(F) : 0;      // the exchanges across waves (ntt_rx_xchg)
             if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
             else         hipLaunchKernelGGL((k_ntt_small<F, false>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
             HIP_OK(hipGetLastError());

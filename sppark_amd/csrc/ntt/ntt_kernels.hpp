@@ -30,6 +30,7 @@
 // emulation harness (tests/emu) runs the same index math on the CPU.
 #pragma once
 #include "../ff/small_fields_dev.hpp"
+#include <type_traits>
 
 namespace sppark_amd {
 
@@ -421,16 +422,23 @@ void k_ntt_pass_lat(F* data, ntt_tables<F> T, ntt_pass P)
     ntt_lat_store<F, DIF>(data, tile, T, P, blockIdx.x, tid, nt);
 }
 
-// ---- whole transforms of <= 2^10 elements: ONE work-group, ONE launch (round 5) ----------------------------------------
+// ---- whole transforms of <= 2^11 elements: ONE work-group, ONE launch (round 5) ----------------------------------------
 // A small transform is pure latency: one launch costs ~3 us whatever it does, and the passes above gave a 2^8 transform
 // to SIXTEEN lanes (radix-16 in registers: 8 us of dependent arithmetic in one wave) and a 2^9 / 2^10 one two launches,
 // with a third for the bit reversal of the NN / RR orders and a fourth for a coset -- the only sizes at which the
 // reference's own build was ahead (3.0 / 4.6 / 5.1 us against 8.0 / 6.4 / 8.2, profiles/r04_ntt_vs_reference_timing.log;
-// it runs <= 2^10 in one launch too, ntt/ntt.cuh:106-107).  Here the whole array lives in LDS, a lane owns ONE butterfly
-// per stage (n/2 lanes: the shortest dependent chain), and everything the driver would otherwise launch around the
-// stages is folded into the load and the store: the bit-reversal permutations of the four orders (ntt/ntt.cuh:174-209),
-// the coset powers g^k (ntt/kernels.cu:131-153) and 1/n.  Twiddles w^k, k < n/2, are copied from the root table into
-// LDS while the data loads.  Any field: the 256-bit ones use the chunk planes of ntt_lat_get / _put.
+// it runs <= 2^10 in one launch too, ntt/ntt.cuh:106-107).
+// Here n/2 lanes each keep ONE butterfly pair in registers for the whole transform (the shortest dependent chain there
+// is).  After a stage a lane swaps one of its two values with the lane at distance 2^d -- inside a wave by lane-permute
+// instructions (d < 6: no barrier, no LDS round trip; ntt_rx_regroup), through LDS with one barrier across waves (at
+// most three stages of a 2^10 transform) -- which is the layout of the reference's narrow kernels
+// (ntt/kernels/gs_mixed_radix_narrow.cu:58-118: shfl_bfly = ds_bpermute inside the wave, shared memory above).
+// What differs: every twiddle of the lane (one per stage, w^k from the root table) is loaded at the top, together with
+// the data and the coset powers, so that the whole transform pays ONE memory latency; and everything the driver would
+// otherwise launch around the stages is folded into the load and the store: the bit-reversal permutations of the four
+// orders (ntt/ntt.cuh:174-209), the coset powers g^k (ntt/kernels.cu:131-153) and 1/n.
+// (First version, one butterfly per lane and stage with the array in LDS and a barrier per stage: 3.9 / 4.4 / 5.2 us
+// against the reference's 3.1 / 3.6 / 4.4 on the same box, profiles/r05_ntt_small_first_version.log.)
 // Same function of the array as the driver's general path; the emulation and the GPU tests hold both against the oracle.
 enum { NTT_SMALL_GS = 1,            // GS / DIF stages (natural in -> bit-reversed out); else CT / DIT
        NTT_SMALL_PERM_IN = 2,       // the array is bit-reversed on the way in (NN)
@@ -438,71 +446,153 @@ enum { NTT_SMALL_GS = 1,            // GS / DIF stages (natural in -> bit-revers
        NTT_SMALL_BITREV = 8,        // the reference's |bitrev| flag: which index the coset powers follow
        NTT_SMALL_COSET_IN = 16,     // forward coset: x[p] *= g^(bitrev ? rev(p) : p) before the stages
        NTT_SMALL_COSET_OUT = 32 };  // inverse coset: x[p] *= g^-(bitrev ? p : rev(p)) after them
-static constexpr unsigned NTT_SMALL_MAX_LG = 10;
+// what the kernel is compiled for: 2^11 elements of a single-word field (1024 lanes, eleven twiddles in registers), 2^10
+// of a 256-bit one (512 lanes).  What the driver USES by default is ntt_engine::small_max_lg().
+template<class F> struct ntt_small_cap { static constexpr unsigned value = sizeof(F) > 8 ? 10 : 11; };
 
-template<class F>
-SPPARK_DEVFN void ntt_small_load(const F* data, F* tile, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
-                                 unsigned tid, unsigned nt)
+#if defined(SPPARK_HOST_EMULATION)
+extern "C" void sppark_emu_barrier();          // (tests/emu: the lanes of a work-group are host threads)
+#endif
+SPPARK_DEVFN void ntt_wg_barrier()
 {
-    const unsigned lg = T.lg_n, n = 1u << lg, nh = n >> 1;
-    F* tw = tile + n;
-    for (unsigned k = tid; k < nh; k += nt) ntt_lat_put(tw, k, nh ? nh : 1, T.lo[k]);
-    for (unsigned e = tid; e < n; e += nt) {
-        F x = data[e];
-        const unsigned p = (flags & NTT_SMALL_PERM_IN) ? bit_rev32(e, lg) : e;
-        if (flags & NTT_SMALL_COSET_IN) x = x * G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(p, lg) : p];
-        ntt_lat_put(tile, p, n, x);
-    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#elif defined(SPPARK_HOST_EMULATION)
+    sppark_emu_barrier();
+#endif
 }
-// stage t of lg: GS halves n/2, n/4, ..., 1 (twiddle w^(j 2^t) on the difference); CT halves 1, 2, ..., n/2 (twiddle
-// w^(j 2^(lg-1-t)) on the odd input).  The half-1 stage multiplies by w^0: no product (a uniform branch).
-template<class F, bool GS>
-SPPARK_DEVFN void ntt_small_stage(F* tile, unsigned lg, unsigned t, unsigned tid, unsigned nt)
+template<unsigned I, unsigned N> struct ntt_static_for {        // fn(I), ..., fn(N - 1) with a compile-time index
+    template<class Fn> SPPARK_DEVFN static void run(Fn&& fn) { fn(std::integral_constant<unsigned, I>()); ntt_static_for<I + 1, N>::run(fn); }
+};
+template<unsigned N> struct ntt_static_for<N, N> { template<class Fn> SPPARK_DEVFN static void run(Fn&&) {} };
+
+// After a stage the lanes l and l ^ 2^D regroup: the one with bit D clear keeps the two SUMS (its own and its partner's), the
+// other one the two DIFFERENCES -- (x0, x1) = (sum, sum') resp. (dif', dif).
+//   D = 5, 4   v_permlane32_swap / v_permlane16_swap (gfx950): "rows 2, 3 of the first operand are swapped with rows 0, 1
+//              of the second" / "odd rows ... with even rows" -- applied to (sum, dif) that IS the regrouping, one VALU
+//              instruction per 32-bit word, no select;
+//   D = 3, 1, 0  the partner's value by a DPP move (row_ror:8, quad_perm [2,3,0,1] / [1,0,3,2]);  D = 2  ds_bpermute;
+//   D >= 6 (across waves), and EVERY exchange of the host emulation: through LDS -- two buffers of |lanes| elements used in
+//              turn, so that ONE barrier per exchange is enough (a lane can only write a buffer again after the barrier of
+//              the exchange in between, which every lane reaches with its read of that buffer behind it).
+template<class F> SPPARK_DEVFN F ntt_rx_pick(bool first, const F& a, const F& b) { return first ? a : b; }
+template<class F, unsigned D>
+SPPARK_DEVFN void ntt_rx_regroup(F& x0, F& x1, const F& sum, const F& dif, unsigned lane, F* lds, unsigned lanes, unsigned& par)
 {
-    const unsigned n = 1u << lg, nh = n >> 1;
-    const F* tw = tile + n;
-    const unsigned lgh = GS ? lg - 1 - t : t, half = 1u << lgh, sh = lg - 1 - lgh;
-    for (unsigned bf = tid; bf < nh; bf += nt) {
-        const unsigned j = bf & (half - 1), i0 = ((bf >> lgh) << (lgh + 1)) + j, i1 = i0 + half;
-        const F u = ntt_lat_get(tile, i0, n);
-        F v = ntt_lat_get(tile, i1, n), sum, dif;
-        if (GS) {
-            F::bfly(u, v, sum, dif);
-            if (lgh != 0) dif = dif * ntt_lat_get(tw, j << sh, nh);
-        } else {
-            if (lgh != 0) v = v * ntt_lat_get(tw, j << sh, nh);
-            F::bfly(u, v, sum, dif);
+    const bool upper = ((lane >> D) & 1u) != 0;
+    const F send = ntt_rx_pick(upper, sum, dif);
+    F recv;
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr unsigned W = sizeof(F) / 4;
+    static_assert(sizeof(F) % 4 == 0, "whole words");
+    if constexpr (D == 5 || D == 4) {
+        u32 s[W], d[W];
+        __builtin_memcpy(s, &sum, sizeof(F)); __builtin_memcpy(d, &dif, sizeof(F));
+        #pragma unroll
+        for (unsigned k = 0; k < W; k++) {
+            if constexpr (D == 5) { auto r = __builtin_amdgcn_permlane32_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
+            else                  { auto r = __builtin_amdgcn_permlane16_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
         }
-        ntt_lat_put(tile, i0, n, sum);
-        ntt_lat_put(tile, i1, n, dif);
+        __builtin_memcpy(&x0, s, sizeof(F)); __builtin_memcpy(&x1, d, sizeof(F));
+        return;
+    } else if constexpr (D < 6) {
+        u32 w[W];
+        __builtin_memcpy(w, &send, sizeof(F));
+        #pragma unroll
+        for (unsigned k = 0; k < W; k++) {
+            if constexpr (D == 3)      w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x128, 0xf, 0xf, false);   // row_ror:8
+            else if constexpr (D == 1) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+            else if constexpr (D == 0) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+            else                       w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)(((lane & 63u) ^ (1u << D)) << 2), (int)w[k]);
+        }
+        __builtin_memcpy(&recv, w, sizeof(F));
+    } else
+#endif
+    {
+        F* buf = lds + (size_t)par * lanes;
+        par ^= 1;
+        ntt_lat_put(buf, lane, lanes, send);
+        ntt_wg_barrier();
+        recv = ntt_lat_get(buf, lane ^ (1u << D), lanes);
     }
+    x0 = ntt_rx_pick(upper, recv, sum); x1 = ntt_rx_pick(upper, dif, recv);
 }
-template<class F, bool INV>
-SPPARK_DEVFN void ntt_small_store(F* data, const F* tile, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
-                                  unsigned tid, unsigned nt)
+
+// lane |l| of |lanes| = max(n/2, 64) (lanes beyond n/2 carry zeros through the same exchanges and touch no memory)
+template<class F, bool INV, bool GS>
+SPPARK_DEVFN void ntt_rx_run(F* data, F* lds, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
+                             unsigned l, unsigned lanes)
 {
-    const unsigned lg = T.lg_n, n = 1u << lg;
-    for (unsigned p = tid; p < n; p += nt) {
-        F x = ntt_lat_get(tile, p, n);
-        if (INV) x = x * T.scale;
-        if (flags & NTT_SMALL_COSET_OUT) x = x * G.lo[(flags & NTT_SMALL_BITREV) ? p : bit_rev32(p, lg)];
-        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(p, lg) : p] = x;
+    constexpr unsigned MAXLG = ntt_small_cap<F>::value;
+    const unsigned lg = T.lg_n, nh = 1u << (lg - 1);
+    const bool live = l < nh;
+    const unsigned lq = live ? l : 0;                           // (idle lanes read the tables at valid indices)
+    // positions of the lane's pair in the working array: GS (l, l + n/2) -> (2l, 2l + 1); CT (2l, 2l + 1) -> (l, l + n/2)
+    const unsigned pin0 = GS ? lq : 2 * lq, pin1 = GS ? lq + nh : 2 * lq + 1;
+    const unsigned pout0 = GS ? 2 * lq : lq, pout1 = GS ? 2 * lq + 1 : lq + nh;
+    F x0 = F(), x1 = F(), w[MAXLG - 1], g0 = F(), g1 = F();
+    // ---- every load of the transform, issued together ------------------------------------------------------------------
+    if (live) {
+        x0 = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin0, lg) : pin0];
+        x1 = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin1, lg) : pin1];
+    }
+    // w[d] is the twiddle of the stage with halves of 2^(d+1) elements -- GS: stage lg-2-d, followed by the exchange at
+    // distance 2^d; CT: stage d+1, preceded by it -- and in both networks it is w^((l mod 2^(d+1)) 2^(lg-2-d))
+    ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
+        constexpr unsigned d = decltype(K)::value;
+        if (d + 2 <= lg) w[d] = T.lo[(lq & ((2u << d) - 1)) << (lg - 2 - d)];
+    });
+    if (flags & NTT_SMALL_COSET_IN) {
+        g0 = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin0, lg) : pin0];
+        g1 = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin1, lg) : pin1];
+    } else if (flags & NTT_SMALL_COSET_OUT) {
+        g0 = G.lo[(flags & NTT_SMALL_BITREV) ? pout0 : bit_rev32(pout0, lg)];
+        g1 = G.lo[(flags & NTT_SMALL_BITREV) ? pout1 : bit_rev32(pout1, lg)];
+    }
+    if (flags & NTT_SMALL_COSET_IN) { x0 = x0 * g0; x1 = x1 * g1; }
+    // ---- the stages ----------------------------------------------------------------------------------------------------
+    unsigned par = 0;
+    F sum, dif;
+    if (GS) {
+        // stage lg-2-d: (x0 + x1, (x0 - x1) w), then the lanes l and l ^ 2^d regroup: the lower one keeps the sums, the
+        // upper one the differences
+        ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
+            constexpr unsigned d = MAXLG - 2 - decltype(K)::value;              // MAXLG - 2, ..., 1, 0
+            if (d + 2 <= lg) {
+                F::bfly(x0, x1, sum, dif);
+                dif = dif * w[d];
+                ntt_rx_regroup<F, d>(x0, x1, sum, dif, l, lds, lanes, par);
+            }
+        });
+        F::bfly(x0, x1, sum, dif);                              // the last stage: halves of 1, w^0
+        x0 = sum; x1 = dif;
+    } else {
+        F::bfly(x0, x1, sum, dif);                              // stage 0: halves of 1, w^0
+        ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
+            constexpr unsigned d = decltype(K)::value;          // exchange at distance 2^d, then stage d + 1
+            if (d + 2 <= lg) {
+                ntt_rx_regroup<F, d>(x0, x1, sum, dif, l, lds, lanes, par);
+                F::bfly(x0, x1 * w[d], sum, dif);
+            }
+        });
+        x0 = sum; x1 = dif;
+    }
+    // ---- the store -----------------------------------------------------------------------------------------------------
+    if (INV) { x0 = x0 * T.scale; x1 = x1 * T.scale; }
+    if (flags & NTT_SMALL_COSET_OUT) { x0 = x0 * g0; x1 = x1 * g1; }
+    if (live) {
+        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout0, lg) : pout0] = x0;
+        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout1, lg) : pout1] = x1;
     }
 }
 template<class F, bool INV>
-__global__ __launch_bounds__(512)
+__global__ __launch_bounds__(1u << (ntt_small_cap<F>::value - 1))
 void k_ntt_small(F* data, ntt_tables<F> T, ntt_tables<F> G, unsigned flags)
 {
     extern __shared__ unsigned char ntt_lds[];
-    F* tile = reinterpret_cast<F*>(ntt_lds);
-    const unsigned tid = threadIdx.x, nt = blockDim.x, lg = T.lg_n;
-    ntt_small_load<F>(data, tile, T, G, flags, tid, nt);
-    __syncthreads();
-    if (flags & NTT_SMALL_GS)                                   // (uniform over the launch)
-        for (unsigned t = 0; t < lg; t++) { ntt_small_stage<F, true>(tile, lg, t, tid, nt); __syncthreads(); }
-    else
-        for (unsigned t = 0; t < lg; t++) { ntt_small_stage<F, false>(tile, lg, t, tid, nt); __syncthreads(); }
-    ntt_small_store<F, INV>(data, tile, T, G, flags, tid, nt);
+    F* lds = reinterpret_cast<F*>(ntt_lds);
+    if (flags & NTT_SMALL_GS) ntt_rx_run<F, INV, true>(data, lds, T, G, flags, threadIdx.x, blockDim.x);      // (uniform over the launch)
+    else                      ntt_rx_run<F, INV, false>(data, lds, T, G, flags, threadIdx.x, blockDim.x);
 }
 // the flags of an (order, direction, type) call -- ntt/ntt.cuh:174-209: NN = bit_rev + CT, NR = GS, RN = CT, RR = GS + bit_rev
 static inline unsigned ntt_small_flags(int order, bool inverse, bool coset)

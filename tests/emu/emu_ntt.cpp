@@ -8,6 +8,10 @@
 #include "../../sppark_amd/csrc/ff/fr256_dev.hpp"
 #include <vector>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 using namespace sppark_amd;
 
 #if defined(FEATURE_GOLDILOCKS)
@@ -143,8 +147,34 @@ extern "C" unsigned emu_ntt_lat_plan(unsigned lg, unsigned smax, int lgc, int lg
 }
 extern "C" void emu_ntt_lat(unsigned smax, int lgc, int lgtile) { g_lat_smax = smax; g_lat_lgc = lgc; g_lat_lgtile = lgtile; }
 
+// k_ntt_small keeps a butterfly pair per lane and swaps values between lanes (ntt_rx_xchg): here a work-group is |n|
+// HOST THREADS, every exchange goes through the emulated LDS buffers, and the barrier hook of ntt_kernels.hpp is a counting
+// barrier -- the product's own index math, twiddle choice, regrouping and permutations run unchanged (only ds_bpermute,
+// the within-wave form of the exchange, is hardware-only: the GPU tests cover it).
+namespace {
+struct wg_barrier {
+    std::mutex m; std::condition_variable cv;
+    unsigned count = 0, gen = 0, n = 0;
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned g = gen;
+        if (++count == n) { count = 0; gen++; cv.notify_all(); return; }
+        cv.wait(lk, [&] { return gen != g; });
+    }
+} g_bar;
+void run_group(unsigned n, const std::function<void(unsigned)>& body)
+{
+    g_bar.n = n; g_bar.count = 0;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n; t++) th.emplace_back(body, t);
+    for (auto& t : th) t.join();
+}
+} // namespace
+extern "C" void sppark_emu_barrier() { g_bar.wait(); }
+
 // transforms up to this size as ONE work-group (k_ntt_small); as ntt_engine::small_max_lg(); 0 = the general path
-static unsigned g_small_max = NTT_SMALL_MAX_LG;
+static unsigned g_small_max = sizeof(F) > 8 ? ntt_small_cap<F>::value - 1 : ntt_small_cap<F>::value;
 extern "C" void emu_ntt_small(unsigned max_lg) { g_small_max = max_lg; }
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
@@ -166,20 +196,14 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     F two = F::one() + F::one();
     ntt_tables<F> T{lo.data(), hi.data(), inner.data(), lg, h, finv(field_pow(two, lg))}, G{glo.data(), ghi.data(), nullptr, lg, h, F::one()};
 
-    if (lg <= g_small_max) {                                    // k_ntt_small: load | lg stages | store, barriers between
+    if (lg <= g_small_max) {                                    // k_ntt_small: its lanes as host threads (barrier hook below)
         const unsigned flags = ntt_small_flags(order, inverse != 0, type == 1);
         const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
-        std::vector<F> tile(n + n / 2 + 1);
-        for (unsigned tid = 0; tid < lanes; tid++) ntt_small_load<F>(d, tile.data(), T, G, flags, tid, lanes);
-        for (unsigned t = 0; t < lg; t++)
-            for (unsigned tid = 0; tid < lanes; tid++) {
-                if (flags & NTT_SMALL_GS) ntt_small_stage<F, true>(tile.data(), lg, t, tid, lanes);
-                else                      ntt_small_stage<F, false>(tile.data(), lg, t, tid, lanes);
-            }
-        for (unsigned tid = 0; tid < lanes; tid++) {
-            if (inverse) ntt_small_store<F, true>(d, tile.data(), T, G, flags, tid, lanes);
-            else         ntt_small_store<F, false>(d, tile.data(), T, G, flags, tid, lanes);
-        }
+        std::vector<F> lds(2 * (size_t)lanes + 1);
+        run_group(lanes, [&](unsigned tid) {
+            if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true>(d, lds.data(), T, G, flags, tid, lanes); }
+            else                      { if (inverse) ntt_rx_run<F, true, false>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false>(d, lds.data(), T, G, flags, tid, lanes); }
+        });
         return 0;
     }
 

@@ -80,8 +80,8 @@ def test_wire_field_class_equals_the_reference_field(oracle, libs, curve, name):
 
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_bucket_field_class_equals_the_reference_field(oracle, libs, curve, name):
-    """montx_dev<fp, LB> (14 limbs of 28 bits over the 381 / 377-bit fields, 10 over the 255-bit Pasta fields, NINE 29-bit
-    limbs over alt_bn128's 254 bits): from_std -> op -> to_std
+    """montx_dev<fp, LB> (14 limbs of 28 bits over the 381 / 377-bit fields, NINE 29-bit limbs over the 254 / 255-bit
+    alt_bn128 and Pasta fields): from_std -> op -> to_std
     gives the reference's a op b for * sqr + -, bit for bit; from_std followed by to_std is the identity."""
     from sppark_amd import ffi
     O = oracle
@@ -89,7 +89,7 @@ def test_bucket_field_class_equals_the_reference_field(oracle, libs, curve, name
     L = ffi.load_devtest(name)
     NL = L.sppark_devtest_bucket_field_limbs()
     p, nb = O.FP_MODULUS[curve], O.FP_BYTES[curve]
-    assert NL == {"bls12_381": 14, "bls12_377": 14, "bn254": 9, "pallas": 10, "vesta": 10}[name]      # bn254: nine 29-bit limbs
+    assert NL == {"bls12_381": 14, "bls12_377": 14, "bn254": 9, "pallas": 9, "vesta": 9}[name]      # 254 / 255 bits: nine 29-bit limbs
     NW = nb // 4
     n = 4096
     va = _vectors(p, nb, n, 7 * curve + 1)

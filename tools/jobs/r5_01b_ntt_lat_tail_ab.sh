@@ -1,5 +1,6 @@
 #!/bin/bash
-# PREPARED FOR THE NEXT ROUND (never run: round 4's GPU budget was spent when it was written).
+# ROUND 5, job 1b (prepared at the end of round 4; run first in round 5: profiles/r05_ntt_lat_tail_ab.log).  The switch lost at every size
+# and the code behind it is deleted: this script documents what was measured, it no longer runs against the current tree.
 # SPPARK_NTT_LAT_TAIL=2|3: the small-half stages of a one-stage-per-round pass of the 256-bit fields in registers, fused
 # with the store / load (ntt_lat_tail_dif / ntt_lat_head_dit).  Parity with the switch on, then the A/B by size.
 mkdir -p gpurun_out; out=gpurun_out/next_ntt_lat_tail_ab.log; : > $out

@@ -121,9 +121,21 @@ class ntt_engine {
     // LDS: 17.7 against 19.7 us, profiles/r05_ntt_small_*.log).  Tuning builds: SPPARK_NTT_SMALL_MAX, 0 = never.
     static unsigned small_max_lg()
     {
-        constexpr unsigned cap = ntt_small_cap<F>::value, dflt = sizeof(F) > 8 ? cap - 1 : cap;
+        static constexpr unsigned cap = ntt_small_cap<F>::value, dflt = sizeof(F) > 8 ? cap - 1 : cap;
 #ifdef SPPARK_TUNING
         static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_SMALL_MAX"); return e ? std::min((unsigned)atoi(e), cap) : dflt; }();
+        return v;
+#else
+        return dflt;
+#endif
+    }
+    // ... and from this size on with two butterfly pairs per lane (n/4 lanes; ntt_rx_run<Q = 2>): 2^11 for the single-word
+    // fields (7.7 -> 7.0 us Goldilocks, 5.6 -> 4.7 BabyBear; no gain at 2^10), never for the 256-bit ones (their default limit is below it).  Tuning builds: SPPARK_NTT_SMALL_Q2 (99 = never).
+    static unsigned small_two_pairs_lg()
+    {
+        static constexpr unsigned dflt = 11;
+#ifdef SPPARK_TUNING
+        static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_SMALL_Q2"); return e ? std::max(8u, (unsigned)atoi(e)) : dflt; }();
         return v;
 #else
         return dflt;
@@ -235,10 +247,13 @@ public:
         // in one launch (k_ntt_small, ntt_kernels.hpp)
         if (lg <= small_max_lg()) {
             const unsigned flags = ntt_small_flags(order, inverse != 0, type == NTT_COSET);
-            const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
-            const size_t lds = lanes > 64 ? 2 * (size_t)lanes * sizeof(F) : 0;      // the exchanges across waves (ntt_rx_xchg)
-            if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
-            else         hipLaunchKernelGGL((k_ntt_small<F, false>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
+            const bool two = lg >= small_two_pairs_lg();        // two butterfly pairs per lane: n/4 lanes
+            const unsigned lanes = two ? (unsigned)(n / 4) : (unsigned)std::max<size_t>(64, n / 2);
+            const size_t lds = lanes > 64 ? (two ? 4 : 2) * (size_t)lanes * sizeof(F) : 0;      // the exchanges across waves (ntt_rx_regroup)
+            if (two) { if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true, 2>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
+                       else         hipLaunchKernelGGL((k_ntt_small<F, false, 2>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags); }
+            else     { if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true, 1>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
+                       else         hipLaunchKernelGGL((k_ntt_small<F, false, 1>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags); }
             HIP_OK(hipGetLastError());
             return;
         }

@@ -476,123 +476,182 @@ template<unsigned N> struct ntt_static_for<N, N> { template<class Fn> SPPARK_DEV
 //              turn, so that ONE barrier per exchange is enough (a lane can only write a buffer again after the barrier of
 //              the exchange in between, which every lane reaches with its read of that buffer behind it).
 template<class F> SPPARK_DEVFN F ntt_rx_pick(bool first, const F& a, const F& b) { return first ? a : b; }
-template<class F, unsigned D>
-SPPARK_DEVFN void ntt_rx_regroup(F& x0, F& x1, const F& sum, const F& dif, unsigned lane, F* lds, unsigned lanes, unsigned& par)
+// Q pairs per lane (the same exchange for each of them; through LDS they share ONE barrier)
+template<class F, unsigned D, unsigned Q>
+SPPARK_DEVFN void ntt_rx_regroup(F (&x0)[Q], F (&x1)[Q], const F (&sum)[Q], const F (&dif)[Q], unsigned lane, F* lds, unsigned lanes, unsigned& par)
 {
     const bool upper = ((lane >> D) & 1u) != 0;
-    const F send = ntt_rx_pick(upper, sum, dif);
-    F recv;
+    F recv[Q];
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr unsigned W = sizeof(F) / 4;
     static_assert(sizeof(F) % 4 == 0, "whole words");
     if constexpr (D == 5 || D == 4) {
-        u32 s[W], d[W];
-        __builtin_memcpy(s, &sum, sizeof(F)); __builtin_memcpy(d, &dif, sizeof(F));
         #pragma unroll
-        for (unsigned k = 0; k < W; k++) {
-            if constexpr (D == 5) { auto r = __builtin_amdgcn_permlane32_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
-            else                  { auto r = __builtin_amdgcn_permlane16_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
+        for (unsigned q = 0; q < Q; q++) {
+            u32 s[W], d[W];
+            __builtin_memcpy(s, &sum[q], sizeof(F)); __builtin_memcpy(d, &dif[q], sizeof(F));
+            #pragma unroll
+            for (unsigned k = 0; k < W; k++) {
+                if constexpr (D == 5) { auto r = __builtin_amdgcn_permlane32_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
+                else                  { auto r = __builtin_amdgcn_permlane16_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
+            }
+            __builtin_memcpy(&x0[q], s, sizeof(F)); __builtin_memcpy(&x1[q], d, sizeof(F));
         }
-        __builtin_memcpy(&x0, s, sizeof(F)); __builtin_memcpy(&x1, d, sizeof(F));
         return;
     } else if constexpr (D < 6) {
-        u32 w[W];
-        __builtin_memcpy(w, &send, sizeof(F));
         #pragma unroll
-        for (unsigned k = 0; k < W; k++) {
-            if constexpr (D == 3)      w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x128, 0xf, 0xf, false);   // row_ror:8
-            else if constexpr (D == 1) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-            else if constexpr (D == 0) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-            else                       w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)(((lane & 63u) ^ (1u << D)) << 2), (int)w[k]);
+        for (unsigned q = 0; q < Q; q++) {
+            const F send = ntt_rx_pick(upper, sum[q], dif[q]);
+            u32 w[W];
+            __builtin_memcpy(w, &send, sizeof(F));
+            #pragma unroll
+            for (unsigned k = 0; k < W; k++) {
+                if constexpr (D == 3)      w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x128, 0xf, 0xf, false);   // row_ror:8
+                else if constexpr (D == 1) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+                else if constexpr (D == 0) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+                else                       w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)(((lane & 63u) ^ (1u << D)) << 2), (int)w[k]);
+            }
+            __builtin_memcpy(&recv[q], w, sizeof(F));
         }
-        __builtin_memcpy(&recv, w, sizeof(F));
     } else
 #endif
     {
-        F* buf = lds + (size_t)par * lanes;
+        F* buf = lds + (size_t)par * Q * lanes;
         par ^= 1;
-        ntt_lat_put(buf, lane, lanes, send);
+        #pragma unroll
+        for (unsigned q = 0; q < Q; q++) ntt_lat_put(buf + (size_t)q * lanes, lane, lanes, ntt_rx_pick(upper, sum[q], dif[q]));
         ntt_wg_barrier();
-        recv = ntt_lat_get(buf, lane ^ (1u << D), lanes);
+        #pragma unroll
+        for (unsigned q = 0; q < Q; q++) recv[q] = ntt_lat_get(buf + (size_t)q * lanes, lane ^ (1u << D), lanes);
     }
-    x0 = ntt_rx_pick(upper, recv, sum); x1 = ntt_rx_pick(upper, dif, recv);
+    #pragma unroll
+    for (unsigned q = 0; q < Q; q++) { x0[q] = ntt_rx_pick(upper, recv[q], sum[q]); x1[q] = ntt_rx_pick(upper, dif[q], recv[q]); }
 }
 
-// lane |l| of |lanes| = max(n/2, 64) (lanes beyond n/2 carry zeros through the same exchanges and touch no memory)
-template<class F, bool INV, bool GS>
+// Physical lane |l| of |lanes| carries Q butterfly pairs: those of the VIRTUAL lanes L = l + q * lanes of the n/2-lane
+// network above (Q = 1: lanes = max(n/2, 64), lanes beyond n/2 carry zeros through the same exchanges and touch no memory;
+// Q = 2: lanes = n/4 >= 64).  With Q = 2 the exchange at the largest distance, 2^(lg-2) = |lanes|, is between the two pairs
+// of ONE lane -- a register move -- and every other one moves both pairs at once: a 2^10 transform is four waves with two
+// exchanges through LDS instead of eight waves with three.
+template<class F, bool INV, bool GS, unsigned Q>
 SPPARK_DEVFN void ntt_rx_run(F* data, F* lds, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
                              unsigned l, unsigned lanes)
 {
     constexpr unsigned MAXLG = ntt_small_cap<F>::value;
     const unsigned lg = T.lg_n, nh = 1u << (lg - 1);
-    const bool live = l < nh;
+    const bool live = Q > 1 || l < nh;
     const unsigned lq = live ? l : 0;                           // (idle lanes read the tables at valid indices)
-    // positions of the lane's pair in the working array: GS (l, l + n/2) -> (2l, 2l + 1); CT (2l, 2l + 1) -> (l, l + n/2)
-    const unsigned pin0 = GS ? lq : 2 * lq, pin1 = GS ? lq + nh : 2 * lq + 1;
-    const unsigned pout0 = GS ? 2 * lq : lq, pout1 = GS ? 2 * lq + 1 : lq + nh;
-    F x0 = F(), x1 = F(), w[MAXLG - 1], g0 = F(), g1 = F();
+    F x0[Q], x1[Q], sum[Q], dif[Q], g0[Q], g1[Q], wtop[Q], w[MAXLG - 1];
+    unsigned pin0[Q], pin1[Q], pout0[Q], pout1[Q];
     // ---- every load of the transform, issued together ------------------------------------------------------------------
-    if (live) {
-        x0 = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin0, lg) : pin0];
-        x1 = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin1, lg) : pin1];
+    #pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        const unsigned L = lq + q * lanes;                      // the virtual lane
+        // positions of its pair in the working array: GS (L, L + n/2) -> (2L, 2L + 1); CT (2L, 2L + 1) -> (L, L + n/2)
+        pin0[q] = GS ? L : 2 * L; pin1[q] = GS ? L + nh : 2 * L + 1;
+        pout0[q] = GS ? 2 * L : L; pout1[q] = GS ? 2 * L + 1 : L + nh;
+        x0[q] = F(); x1[q] = F(); g0[q] = F(); g1[q] = F();
+        if (live) {
+            x0[q] = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin0[q], lg) : pin0[q]];
+            x1[q] = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin1[q], lg) : pin1[q]];
+        }
+        // the stage with halves of n/2 elements (GS: the first, CT: the last): w^L
+        wtop[q] = T.lo[L & (nh - 1)];
     }
     // w[d] is the twiddle of the stage with halves of 2^(d+1) elements -- GS: stage lg-2-d, followed by the exchange at
-    // distance 2^d; CT: stage d+1, preceded by it -- and in both networks it is w^((l mod 2^(d+1)) 2^(lg-2-d))
+    // distance 2^d; CT: stage d+1, preceded by it -- and in both networks it is w^((L mod 2^(d+1)) 2^(lg-2-d)); below the top
+    // stage that is the same for the Q pairs of a lane
+    // BabyBear: only the stages with halves <= 16 LOAD their twiddle (d < 4: at most 16 distinct table entries per wave); the
+    // others follow from the top one by squaring, w[d] = w[d+1]^2 (-1)^(bit d+1 of l) -- (l mod 2^(d+1)) 2^(lg-2-d) is twice
+    // (l mod 2^(d+2)) 2^(lg-3-d) less bit_(d+1)(l) n/2, and w^(n/2) = -1.  As loads they are gathers of up to 64 cache lines per
+    // wave and stage (2400 lines for a 2^10 transform); a 5-instruction Montgomery squaring per stage rides in the issue slots the
+    // dependent butterfly chain leaves empty: 2^10 3.5 -> 3.2 us, 2^11 4.7 -> 4.4.  Goldilocks, whose squaring is a 64 x 64-bit
+    // product (28 instructions), LOSES 0.2-0.3 us at 2^8 / 2^9 and gains nothing at 2^10, and a 256-bit squaring is ~300
+    // instructions: both keep the loads (profiles/r05_ntt_small_squared_twiddles.log against r05_ntt_small_pairs_per_lane_ab.log).
+    constexpr bool SQUARE = sizeof(F) <= 4;
+    constexpr unsigned DLOAD = SQUARE ? 4 : MAXLG - 1;
     ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
         constexpr unsigned d = decltype(K)::value;
-        if (d + 2 <= lg) w[d] = T.lo[(lq & ((2u << d) - 1)) << (lg - 2 - d)];
+        if (d < DLOAD && d + 2 <= lg) w[d] = T.lo[(lq & ((2u << d) - 1) & (nh - 1)) << (lg - 2 - d)];
     });
-    if (flags & NTT_SMALL_COSET_IN) {
-        g0 = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin0, lg) : pin0];
-        g1 = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin1, lg) : pin1];
-    } else if (flags & NTT_SMALL_COSET_OUT) {
-        g0 = G.lo[(flags & NTT_SMALL_BITREV) ? pout0 : bit_rev32(pout0, lg)];
-        g1 = G.lo[(flags & NTT_SMALL_BITREV) ? pout1 : bit_rev32(pout1, lg)];
+    if constexpr (SQUARE) {
+        F cur = wtop[0];                                        // w[lg-2] of virtual lane l
+        ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
+            constexpr unsigned d = MAXLG - 2 - decltype(K)::value;              // MAXLG - 2, ..., 0
+            if (d >= DLOAD && d + 2 <= lg) {
+                if (d + 2 < lg) { cur = cur * cur; if ((lq >> (d + 1)) & 1u) cur = F() - cur; }
+                w[d] = cur;
+            }
+        });
     }
-    if (flags & NTT_SMALL_COSET_IN) { x0 = x0 * g0; x1 = x1 * g1; }
+    #pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        if (flags & NTT_SMALL_COSET_IN) {
+            g0[q] = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin0[q], lg) : pin0[q]];
+            g1[q] = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin1[q], lg) : pin1[q]];
+        } else if (flags & NTT_SMALL_COSET_OUT) {
+            g0[q] = G.lo[(flags & NTT_SMALL_BITREV) ? pout0[q] : bit_rev32(pout0[q], lg)];
+            g1[q] = G.lo[(flags & NTT_SMALL_BITREV) ? pout1[q] : bit_rev32(pout1[q], lg)];
+        }
+        if (flags & NTT_SMALL_COSET_IN) { x0[q] = x0[q] * g0[q]; x1[q] = x1[q] * g1[q]; }
+    }
     // ---- the stages ----------------------------------------------------------------------------------------------------
+    // the exchange between the pairs of one lane (Q = 2, distance |lanes|): pair 0 keeps the sums, pair 1 the differences
+    auto regroup_in_lane = [&]() {
+        if constexpr (Q == 2) { x0[0] = sum[0]; x1[0] = sum[1]; x0[1] = dif[0]; x1[1] = dif[1]; }
+    };
     unsigned par = 0;
-    F sum, dif;
     if (GS) {
-        // stage lg-2-d: (x0 + x1, (x0 - x1) w), then the lanes l and l ^ 2^d regroup: the lower one keeps the sums, the
+        // stage lg-2-d: (x0 + x1, (x0 - x1) w), then the lanes L and L ^ 2^d regroup: the lower one keeps the sums, the
         // upper one the differences
         ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
             constexpr unsigned d = MAXLG - 2 - decltype(K)::value;              // MAXLG - 2, ..., 1, 0
             if (d + 2 <= lg) {
-                F::bfly(x0, x1, sum, dif);
-                dif = dif * w[d];
-                ntt_rx_regroup<F, d>(x0, x1, sum, dif, l, lds, lanes, par);
+                const bool top = d + 2 == lg;
+                #pragma unroll
+                for (unsigned q = 0; q < Q; q++) { F::bfly(x0[q], x1[q], sum[q], dif[q]); dif[q] = dif[q] * (top ? wtop[q] : w[d]); }
+                if (Q > 1 && top) regroup_in_lane();
+                else              ntt_rx_regroup<F, d, Q>(x0, x1, sum, dif, l, lds, lanes, par);
             }
         });
-        F::bfly(x0, x1, sum, dif);                              // the last stage: halves of 1, w^0
-        x0 = sum; x1 = dif;
+        #pragma unroll
+        for (unsigned q = 0; q < Q; q++) { F::bfly(x0[q], x1[q], sum[q], dif[q]); x0[q] = sum[q]; x1[q] = dif[q]; }      // the last stage: halves of 1, w^0
     } else {
-        F::bfly(x0, x1, sum, dif);                              // stage 0: halves of 1, w^0
+        #pragma unroll
+        for (unsigned q = 0; q < Q; q++) F::bfly(x0[q], x1[q], sum[q], dif[q]);                                        // stage 0: halves of 1, w^0
         ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
             constexpr unsigned d = decltype(K)::value;          // exchange at distance 2^d, then stage d + 1
             if (d + 2 <= lg) {
-                ntt_rx_regroup<F, d>(x0, x1, sum, dif, l, lds, lanes, par);
-                F::bfly(x0, x1 * w[d], sum, dif);
+                const bool top = d + 2 == lg;
+                if (Q > 1 && top) regroup_in_lane();
+                else              ntt_rx_regroup<F, d, Q>(x0, x1, sum, dif, l, lds, lanes, par);
+                #pragma unroll
+                for (unsigned q = 0; q < Q; q++) F::bfly(x0[q], x1[q] * (top ? wtop[q] : w[d]), sum[q], dif[q]);
             }
         });
-        x0 = sum; x1 = dif;
+        #pragma unroll
+        for (unsigned q = 0; q < Q; q++) { x0[q] = sum[q]; x1[q] = dif[q]; }
     }
     // ---- the store -----------------------------------------------------------------------------------------------------
-    if (INV) { x0 = x0 * T.scale; x1 = x1 * T.scale; }
-    if (flags & NTT_SMALL_COSET_OUT) { x0 = x0 * g0; x1 = x1 * g1; }
-    if (live) {
-        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout0, lg) : pout0] = x0;
-        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout1, lg) : pout1] = x1;
+    #pragma unroll
+    for (unsigned q = 0; q < Q; q++) {
+        if (INV) { x0[q] = x0[q] * T.scale; x1[q] = x1[q] * T.scale; }
+        if (flags & NTT_SMALL_COSET_OUT) { x0[q] = x0[q] * g0[q]; x1[q] = x1[q] * g1[q]; }
+        if (live) {
+            data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout0[q], lg) : pout0[q]] = x0[q];
+            data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout1[q], lg) : pout1[q]] = x1[q];
+        }
     }
 }
-template<class F, bool INV>
-__global__ __launch_bounds__(1u << (ntt_small_cap<F>::value - 1))
+// Q = pairs per lane (1: up to n/2 = 2^(cap-1) lanes; 2: n/4 lanes)
+template<class F, bool INV, unsigned Q>
+__global__ __launch_bounds__(1u << (ntt_small_cap<F>::value - Q))
 void k_ntt_small(F* data, ntt_tables<F> T, ntt_tables<F> G, unsigned flags)
 {
     extern __shared__ unsigned char ntt_lds[];
     F* lds = reinterpret_cast<F*>(ntt_lds);
-    if (flags & NTT_SMALL_GS) ntt_rx_run<F, INV, true>(data, lds, T, G, flags, threadIdx.x, blockDim.x);      // (uniform over the launch)
-    else                      ntt_rx_run<F, INV, false>(data, lds, T, G, flags, threadIdx.x, blockDim.x);
+    if (flags & NTT_SMALL_GS) ntt_rx_run<F, INV, true, Q>(data, lds, T, G, flags, threadIdx.x, blockDim.x);      // (uniform over the launch)
+    else                      ntt_rx_run<F, INV, false, Q>(data, lds, T, G, flags, threadIdx.x, blockDim.x);
 }
 // the flags of an (order, direction, type) call -- ntt/ntt.cuh:174-209: NN = bit_rev + CT, NR = GS, RN = CT, RR = GS + bit_rev
 static inline unsigned ntt_small_flags(int order, bool inverse, bool coset)

@@ -175,7 +175,9 @@ extern "C" void sppark_emu_barrier() { g_bar.wait(); }
 
 // transforms up to this size as ONE work-group (k_ntt_small); as ntt_engine::small_max_lg(); 0 = the general path
 static unsigned g_small_max = sizeof(F) > 8 ? ntt_small_cap<F>::value - 1 : ntt_small_cap<F>::value;
+static unsigned g_small_q2 = 11;                           // two pairs per lane from this size on (>= 8)
 extern "C" void emu_ntt_small(unsigned max_lg) { g_small_max = max_lg; }
+extern "C" void emu_ntt_small_q2(unsigned lg) { g_small_q2 = lg; }
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
@@ -198,11 +200,17 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
 
     if (lg <= g_small_max) {                                    // k_ntt_small: its lanes as host threads (barrier hook below)
         const unsigned flags = ntt_small_flags(order, inverse != 0, type == 1);
-        const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
-        std::vector<F> lds(2 * (size_t)lanes + 1);
+        const bool two = lg >= g_small_q2;                      // as ntt_engine::small_two_pairs_lg()
+        const unsigned lanes = two ? (unsigned)(n / 4) : (unsigned)std::max<size_t>(64, n / 2);
+        std::vector<F> lds((two ? 4 : 2) * (size_t)lanes + 1);
         run_group(lanes, [&](unsigned tid) {
-            if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true>(d, lds.data(), T, G, flags, tid, lanes); }
-            else                      { if (inverse) ntt_rx_run<F, true, false>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false>(d, lds.data(), T, G, flags, tid, lanes); }
+            if (two) {
+                if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true, 2>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true, 2>(d, lds.data(), T, G, flags, tid, lanes); }
+                else                      { if (inverse) ntt_rx_run<F, true, false, 2>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false, 2>(d, lds.data(), T, G, flags, tid, lanes); }
+            } else {
+                if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true, 1>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true, 1>(d, lds.data(), T, G, flags, tid, lanes); }
+                else                      { if (inverse) ntt_rx_run<F, true, false, 1>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false, 1>(d, lds.data(), T, G, flags, tid, lanes); }
+            }
         });
         return 0;
     }

@@ -103,7 +103,7 @@ def test_cooperative_kernels_fit_one_work_group_per_cu():
 @pytest.mark.parametrize("obj", ["bls12_381__msm_k_accumulate.hip__SPPARK_G2.o", "bn254__msm_k_accumulate.hip__SPPARK_G2.o",
                                  "bls12_377__msm_k_accumulate.hip__SPPARK_G2.o"])
 def test_g2_one_component_per_wave_kernel_fits_two_waves_per_simd(obj):
-    """k_accumulate_g2c (msm_g2c_kernels.hpp; not the default path): a pair of waves per 64 chunks is only worth having
+    """k_accumulate_g2c (msm_g2c_kernels.hpp; the default G2 accumulation over the 14-limb fields): a pair of waves per 64 chunks is only worth having
     if BOTH fit a SIMD twice over -- at most 256 registers, no scratch (the two earlier attempts at two G2 waves per
     SIMD died of spills), and four 128-lane work-groups' exchange areas within a CU's 160 KB of LDS."""
     meta = _kernels(obj)
@@ -114,3 +114,19 @@ def test_g2_one_component_per_wave_kernel_fits_two_waves_per_simd(obj):
     assert int(md.get("vgpr_count") or 0) <= 256, md
     assert int(md.get("private_segment_fixed_size") or 0) == 0, md
     assert 4 * int(md.get("group_segment_fixed_size") or 0) <= 160 * 1024, md
+
+
+@pytest.mark.parametrize("unit,feature", [("api/ntt_api.hip", "FEATURE_GOLDILOCKS"), ("api/ntt_api.hip", "FEATURE_BLS12_381 -DSPPARK_NTT_WITH_MSM"),
+                                          ("api/msm_api.hip", "FEATURE_BN254")])
+def test_tuning_build_still_compiles(unit, feature):
+    """The experiment knobs live behind -DSPPARK_TUNING (a second set of libraries for A/B jobs, sppark_amd/build.py
+    SPPARK_LIBDIR); nothing in the default build or its tests compiles that code, so it is syntax-checked here -- a tuning
+    build that silently failed once left a job measuring a stale library."""
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "sppark_amd", "csrc", unit)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-duplicate-decl-specifier", "-DSPPARK_TUNING"]
+                       + ("-D" + feature).split() + [src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

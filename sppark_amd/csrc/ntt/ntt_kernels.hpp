@@ -431,14 +431,17 @@ void k_ntt_pass_lat(F* data, ntt_tables<F> T, ntt_pass P)
 // Here n/2 lanes each keep ONE butterfly pair in registers for the whole transform (the shortest dependent chain there
 // is).  After a stage a lane swaps one of its two values with the lane at distance 2^d -- inside a wave by lane-permute
 // instructions (d < 6: no barrier, no LDS round trip; ntt_rx_regroup), through LDS with one barrier across waves (at
-// most three stages of a 2^10 transform) -- which is the layout of the reference's narrow kernels
+// most three stages of a 2^10 transform, three of a 2^11 one with two pairs per lane) -- which is the layout of the reference's narrow kernels
 // (ntt/kernels/gs_mixed_radix_narrow.cu:58-118: shfl_bfly = ds_bpermute inside the wave, shared memory above).
 // What differs: every twiddle of the lane (one per stage, w^k from the root table) is loaded at the top, together with
 // the data and the coset powers, so that the whole transform pays ONE memory latency; and everything the driver would
 // otherwise launch around the stages is folded into the load and the store: the bit-reversal permutations of the four
 // orders (ntt/ntt.cuh:174-209), the coset powers g^k (ntt/kernels.cu:131-153) and 1/n.
 // (First version, one butterfly per lane and stage with the array in LDS and a barrier per stage: 3.9 / 4.4 / 5.2 us
-// against the reference's 3.1 / 3.6 / 4.4 on the same box, profiles/r05_ntt_small_first_version.log.)
+// against the reference's 3.1 / 3.6 / 4.4 on the same box, profiles/r05_ntt_small_first_version.log; this one, Goldilocks
+// 2^8 ... 2^11 in NR order: 2.7 / 3.2 / 4.7 / 7.0 us against 2.9 / 3.5 / 4.4 / 11.5, profiles/r05_ntt_vs_reference_timing.log.
+// At 2^10 a work-group is no longer latency-bound but ISSUE-bound on its one compute unit -- eight waves x ~55 instructions
+// per stage on four SIMDs -- whatever lane layout carries them.)
 // Same function of the array as the driver's general path; the emulation and the GPU tests hold both against the oracle.
 enum { NTT_SMALL_GS = 1,            // GS / DIF stages (natural in -> bit-reversed out); else CT / DIT
        NTT_SMALL_PERM_IN = 2,       // the array is bit-reversed on the way in (NN)

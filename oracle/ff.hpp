@@ -20,6 +20,11 @@
 //  * bb31        : BabyBear p = 0x78000001, Montgomery R = 2^32
 //                  (ff/mont32_t.cuh:19-425, ff/baby_bear.hpp:19).
 //
+// PINNED (round 5): tests/test_oracle.py::test_oracle_field_equals_the_reference_device_field holds mont_t<P> -- base and
+// scalar field of all five curves, + - * sqr to from -- against outputs of the reference's OWN device field classes
+// (fp_t / fr_t over ff/mont_t.hip, ff/bls12-381.hpp:63-83 ...), recorded on an MI355X by tests/golden/make_ref_field_golden.py
+// into tests/golden/ref_field_golden.json.  The layers above the field (ec.hpp, msm.hpp) are pinned as DESIGN.md section 2 says.
+//
 // Constants (modulus, R^2, R, -1/p mod 2^64) are the reference's tables,
 // cited at each definition, and are re-derived from Python big-ints by
 // tests/test_oracle_fields.py.

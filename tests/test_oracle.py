@@ -325,3 +325,37 @@ def test_reference_ntt_build_recipe(oracle):
     assert "oracle/_ref/" in open(os.path.join(root, ".gitignore")).read()
     ignore = os.path.join(root, ".gpurunignore")
     assert not os.path.exists(ignore) or "oracle/_ref" not in open(ignore).read()
+
+
+def test_oracle_field_equals_the_reference_device_field(oracle):
+    """The ORACLE's field (oracle/ff.hpp: SOS Montgomery on 64-bit limbs, CPU) against outputs of the REFERENCE's own device
+    field classes -- fp_t / fr_t over ff/mont_t.hip (ff/bls12-381.hpp:63-83 and the other curves' headers), built for gfx950
+    and run on an MI355X by tests/golden/make_ref_field_golden.py, which recorded operands and results in
+    tests/golden/ref_field_golden.json: + - * sqr to() from() on edge-heavy operands, base and scalar field of five curves.
+    (The DEVICE classes are held against the same reference code live on the GPU: tests/test_field_vs_reference_gpu.py.)"""
+    O = oracle
+    with open(os.path.join(HERE, "golden", "ref_field_golden.json")) as f:
+        gold = json.load(f)
+    curve_id = {"bls12_381": O.BLS12_381, "bn254": O.BN254, "bls12_377": O.BLS12_377, "pallas": O.PALLAS, "vesta": O.VESTA}
+    oracle_op = {"add": 0, "sub": 1, "mul": 2, "sqr": 7, "to": 4, "from": 5}      # oracle_capi.cpp's op numbers
+    assert gold["ops"] == ["add", "sub", "mul", "sqr", "to", "from"] and len(gold["cases"]) == 10
+    for c in gold["cases"]:
+        curve = curve_id[c["curve"]]
+        fid = (O.FP_FIELD_ID if c["field"] == "fp" else O.FR_FIELD_ID)[curve]
+        nb, n = c["bytes"], c["n"]
+        p = int(c["modulus"], 16)
+        assert p == (O.FP_MODULUS if c["field"] == "fp" else O.FR_MODULUS)[curve]
+        a = np.frombuffer(bytes.fromhex(c["a"]), dtype=np.uint8).reshape(n, nb)
+        b = np.frombuffer(bytes.fromhex(c["b"]), dtype=np.uint8).reshape(n, nb)
+        R = 1 << (8 * nb); Rinv = pow(R, p - 2, p)
+        for name, oop in oracle_op.items():
+            exp = np.frombuffer(bytes.fromhex(c["expect"][name]), dtype=np.uint8).reshape(n, nb)
+            for i in range(n):
+                got = O.field_op(fid, oop, a[i].copy().view(np.uint64), b[i].copy().view(np.uint64)).view(np.uint8)
+                assert (got == exp[i]).all(), (c["curve"], c["field"], name, i)
+            # ... and the recorded outputs are what the operation means (big integers): the fixture is not self-referential
+            for i in (0, 3, 5, 14, n - 1):
+                x, y, e = (int.from_bytes(v[i].tobytes(), "little") for v in (a, b, exp))
+                want = {"add": (x + y) % p, "sub": (x - y) % p, "mul": x * y * Rinv % p, "sqr": x * x * Rinv % p,
+                        "to": x * R % p, "from": x * Rinv % p}[name]
+                assert e == want, (c["curve"], c["field"], name, i)

@@ -168,3 +168,21 @@ int main() { return 0; }
     r = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "--cuda-host-only", "-std=c++17", "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_g2_path_switch_validates_its_argument(libs):
+    """sppark_msm_g2_path (which accumulation kernel mult_pippenger_fp2_inf runs; a test hook, process-wide): 0 / 1 / 2 are
+    accepted, anything else is hipErrorInvalidValue with an owned message and leaves the setting alone; the curves
+    without G2 do not export it.  (No device is touched.)"""
+    from sppark_amd import ffi
+    for name in ("bls12_381", "bn254", "bls12_377"):
+        L = ffi.load(name)
+        for mode in (1, 2, 0):
+            err = L.sppark_msm_g2_path(mode)
+            assert err.code == 0 and not err.message
+        err = L.sppark_msm_g2_path(3)
+        assert err.code != 0 and err.message
+        L.drop_error_message(err.message)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", libs["pallas"]], capture_output=True, text=True).stdout
+    assert "sppark_msm_g2_path" not in syms and "mult_pippenger_fp2_inf" not in syms

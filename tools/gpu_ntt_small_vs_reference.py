@@ -15,7 +15,11 @@ from sppark_amd import ffi
 
 REPS = 400
 args = dict(a.split("=") for a in sys.argv[1:])
-loop = ctypes.CDLL(os.path.join(ROOT, "tools", "libntt_loop.so"))
+_so = os.path.join(ROOT, "tools", "libntt_loop.so")
+if not os.path.exists(_so):                                  # (host code only; built once, travels with the snapshot)
+    import subprocess
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-fPIC", "-shared", os.path.join(ROOT, "tools", "ntt_loop.cpp"), "-o", _so])
+loop = ctypes.CDLL(_so)
 loop.ntt_loop.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                           ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
 torch.cuda.set_stream(torch.cuda.Stream())

@@ -496,6 +496,9 @@ def main():
         # the per-GPU shards of the headline MSM at N = 2 / 4 / 8 on THIS GPU (device-resident, same inputs): an upper
         # bound for strong scaling read off a 1-GPU line (t_shard, before the all-gather); each result asserted
         shard = {}
+        # (without the library's phase timers -- an event record per phase, ~20 us per MSM at 2^16, profiles/r05_msm_timing_overhead.log:
+        # they exist for the roofline of the headline above, a caller's context has them off)
+        ctx.enable_timing(False)
         for lgs in (25, 24, 23, 20, 16):
             if lgs >= args.lg:
                 continue
@@ -513,6 +516,7 @@ def main():
             assert ok, "shard-size MSM differs from the oracle"
             shard["msm_ms_at_2^%d" % lgs] = {"ms": ms, "points_per_s": m / (ms * 1e-3), "windows": ctx.plan(m)["windows"], "equals_oracle": ok}
         extras["shard_sizes"] = shard
+        ctx.enable_timing(True)
         sppark_amd.ffi.load("bls12_381").sppark_msm_release_cached()
 
     cpu = None

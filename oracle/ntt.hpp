@@ -18,6 +18,8 @@
 //   CT = decimation-in-time,      bit-reversed in -> natural out
 //
 // ntt_naive() is the O(n^2) textbook DFT used to pin the fast restatement.
+// PINNED by the reference itself: live on the GPU box (tests/test_ntt_vs_reference_gpu.py holds the product against the reference's own
+// HIP build and against this file) and, in the CPU suite, against recorded outputs of that build (tests/golden/ref_ntt_golden.json).
 #pragma once
 #include "ff.hpp"
 #include <vector>

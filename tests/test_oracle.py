@@ -359,3 +359,33 @@ def test_oracle_field_equals_the_reference_device_field(oracle):
                 want = {"add": (x + y) % p, "sub": (x - y) % p, "mul": x * y * Rinv % p, "sqr": x * x * Rinv % p,
                         "to": x * R % p, "from": x * Rinv % p}[name]
                 assert e == want, (c["curve"], c["field"], name, i)
+
+
+def test_oracle_ntt_equals_the_reference_build_vectors(oracle):
+    """The ORACLE's NTT restatement (oracle/ntt.hpp) against outputs of the REFERENCE's own compute_ntt -- its HIP build for gfx950,
+    run on an MI355X by tests/golden/make_ref_ntt_golden.py and recorded in tests/golden/ref_ntt_golden.json: every order x
+    direction x type at 2^1 .. 2^5, nine field libraries incl. both compile-time root conventions.  (The `-m gpu` suite applies
+    the same pin live and at every size: tests/test_ntt_vs_reference_gpu.py.)"""
+    O = oracle
+    with open(os.path.join(HERE, "golden", "ref_ntt_golden.json")) as f:
+        gold = json.load(f)
+    assert len(gold["cases"]) == 31
+    try:
+        for c in gold["cases"]:
+            O.set_root_conventions(goldilocks_plonky2=c["lib"] == "gl64_plonky2", baby_bear_canonical=c["lib"] == "bb31_canonical")
+            x = np.frombuffer(bytes.fromhex(c["input"]), dtype=np.dtype(c["dtype"]))
+            if c["kind"] == "gl64":
+                f = O.ntt_gl64
+            elif c["kind"] == "bb31":
+                f = O.ntt_bb31
+            else:
+                x = x.reshape(-1, 4)
+                f = (lambda curve: (lambda a, o, d, t: O.ntt_fr(curve, a, o, d, t)))(O.CURVE_ID[c["kind"]])
+            assert x.shape[0] == 1 << c["lg"]
+            assert len(c["expect"]) == 16
+            for key, hexed in c["expect"].items():
+                order, direction, typ = (int(ch) for ch in key)
+                exp = np.frombuffer(bytes.fromhex(hexed), dtype=x.dtype).reshape(x.shape)
+                assert (f(x, order, direction, typ) == exp).all(), (c["lib"], c["lg"], key)
+    finally:
+        O.set_root_conventions(False, False)

@@ -6,10 +6,13 @@ namespace sppark_amd {
 #define SPPARK_NTT_EXTERN(DIF, INV, R1, R2) \
     extern template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL(SPPARK_NTT_EXTERN, false)
-extern template __global__ void k_ntt_small<ntt_fr_t, false, 1>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
-extern template __global__ void k_ntt_small<ntt_fr_t, false, 2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
-extern template __global__ void k_ntt_small<ntt_fr_t, true, 1>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
-extern template __global__ void k_ntt_small<ntt_fr_t, true, 2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
+#define SPPARK_NTT_SMALL_EXTERN(INV, LGC) \
+    extern template __global__ void k_ntt_small<ntt_fr_t, INV, LGC>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
+#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)
+SPPARK_NTT_SMALL_ALL_NARROW(SPPARK_NTT_SMALL_EXTERN)
+#else
+SPPARK_NTT_SMALL_ALL_WIDE(SPPARK_NTT_SMALL_EXTERN)
+#endif
 #if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, true) SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_EXTERN, false)
 #else

@@ -9,10 +9,13 @@ namespace sppark_amd {
     template __global__ void k_ntt_pass<ntt_fr_t, DIF, INV, R1, R2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_pass);
 SPPARK_NTT_PASS_ALL(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))
 #if SPPARK_NTT_DIF                                                 // (one of the two units carries the small-transform kernel)
-template __global__ void k_ntt_small<ntt_fr_t, false, 1>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
-template __global__ void k_ntt_small<ntt_fr_t, false, 2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
-template __global__ void k_ntt_small<ntt_fr_t, true, 1>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
-template __global__ void k_ntt_small<ntt_fr_t, true, 2>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
+#define SPPARK_NTT_SMALL_DEFINE(INV, LGC) \
+    template __global__ void k_ntt_small<ntt_fr_t, INV, LGC>(ntt_fr_t*, ntt_tables<ntt_fr_t>, ntt_tables<ntt_fr_t>, unsigned);
+#if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)
+SPPARK_NTT_SMALL_ALL_NARROW(SPPARK_NTT_SMALL_DEFINE)
+#else
+SPPARK_NTT_SMALL_ALL_WIDE(SPPARK_NTT_SMALL_DEFINE)
+#endif
 #endif
 #if defined(FEATURE_GOLDILOCKS) || defined(FEATURE_BABY_BEAR)      // wide fields stop at 4 stages per pass in registers ...
 SPPARK_NTT_PASS_ALL_BIG(SPPARK_NTT_DEFINE, (SPPARK_NTT_DIF != 0))

@@ -117,8 +117,8 @@ class ntt_engine {
 #endif
     }
     // transforms up to this size run as one launch of one work-group: 2^11 for the single-word fields, 2^9 for the 256-bit
-    // ones (at 2^10 their two one-stage-per-round launches are faster than eight waves of 256-bit exchanges through
-    // LDS: 17.7 against 19.7 us, profiles/r05_ntt_small_*.log).  Tuning builds: SPPARK_NTT_SMALL_MAX, 0 = never.
+    // ones (at 2^10 their two one-stage-per-round launches are as fast as eight waves of 256-bit exchanges through
+    // LDS: 17.7 against 17.8 us, profiles/r05_ntt_small_sized_ab.log).  Tuning builds: SPPARK_NTT_SMALL_MAX, 0 = never.
     static unsigned small_max_lg()
     {
         static constexpr unsigned cap = ntt_small_cap<F>::value, dflt = sizeof(F) > 8 ? cap - 1 : cap;
@@ -129,16 +129,14 @@ class ntt_engine {
         return dflt;
 #endif
     }
-    // ... and from this size on with two butterfly pairs per lane (n/4 lanes; ntt_rx_run<Q = 2>): 2^11 for the single-word
-    // fields (7.7 -> 7.0 us Goldilocks, 5.6 -> 4.7 BabyBear; no gain at 2^10), never for the 256-bit ones (their default limit is below it).  Tuning builds: SPPARK_NTT_SMALL_Q2 (99 = never).
-    static unsigned small_two_pairs_lg()
+    // tuning builds: SPPARK_NTT_SMALL_SIZED=0 runs every size through the run-time-size instance
+    static bool small_sized()
     {
-        static constexpr unsigned dflt = 11;
 #ifdef SPPARK_TUNING
-        static const unsigned v = [] { const char* e = getenv("SPPARK_NTT_SMALL_Q2"); return e ? std::max(8u, (unsigned)atoi(e)) : dflt; }();
+        static const bool v = [] { const char* e = getenv("SPPARK_NTT_SMALL_SIZED"); return !e || atoi(e) != 0; }();
         return v;
 #else
-        return dflt;
+        return true;
 #endif
     }
     // the inter-pass twiddle table of a pass on sub-problems of 2^lg_cur elements (built once per
@@ -199,14 +197,14 @@ class ntt_engine {
         table_set t;
         t.h = lg < 12 ? lg : 12;
         size_t nlo = (size_t)1 << t.h, nhi = (size_t)1 << (lg - t.h);
-        HIP_OK(dev_scratch_pool::malloc_or_drain((void**)&t.lo, (2 * (nlo + nhi) + 512) * sizeof(F)));
+        HIP_OK(dev_scratch_pool::malloc_or_drain((void**)&t.lo, (2 * (nlo + nhi) + ntt_inner_entries<F>::value) * sizeof(F)));
         t.hi = t.lo + nlo; t.glo = t.hi + nhi; t.ghi = t.glo + nlo; t.inner = t.ghi + nhi;
         auto w = H::top_root();
         for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = H::mul(w, w);
         auto g = H::gen();
         if (inverse) { w = H::inv(w); g = H::inv(g); }
         t.scale = H::wire(H::inv(H::two_pow(lg)));
-        unsigned grid = (unsigned)((std::max<size_t>(std::max(nlo, nhi), 512) + 255) / 256);
+        unsigned grid = (unsigned)((std::max<size_t>(std::max(nlo, nhi), ntt_inner_entries<F>::value) + 255) / 256);
         hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.lo, t.hi, t.inner, H::wire(w), lg, t.h);
         hipLaunchKernelGGL(k_tables<F>, dim3(grid), dim3(256), 0, stream, t.glo, t.ghi, (F*)nullptr, H::wire(g), lg, t.h);
         HIP_OK(hipGetLastError());
@@ -247,13 +245,23 @@ public:
         // in one launch (k_ntt_small, ntt_kernels.hpp)
         if (lg <= small_max_lg()) {
             const unsigned flags = ntt_small_flags(order, inverse != 0, type == NTT_COSET);
-            const bool two = lg >= small_two_pairs_lg();        // two butterfly pairs per lane: n/4 lanes
-            const unsigned lanes = two ? (unsigned)(n / 4) : (unsigned)std::max<size_t>(64, n / 2);
-            const size_t lds = lanes > 64 ? (two ? 4 : 2) * (size_t)lanes * sizeof(F) : 0;      // the exchanges across waves (ntt_rx_regroup)
-            if (two) { if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true, 2>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
-                       else         hipLaunchKernelGGL((k_ntt_small<F, false, 2>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags); }
-            else     { if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true, 1>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags);
-                       else         hipLaunchKernelGGL((k_ntt_small<F, false, 1>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags); }
+            const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
+            const size_t lds = lanes > 64 ? 2 * (size_t)lanes * sizeof(F) : 0;        // the exchanges across waves (ntt_rx_regroup)
+            // (single-word fields: the sizes 2^8 ... 2^11 have their own instance, compiled for that size)
+#define SPPARK_NTT_SMALL_PICK(LGC) do { \
+                if (inverse) hipLaunchKernelGGL((k_ntt_small<F, true, LGC>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags); \
+                else         hipLaunchKernelGGL((k_ntt_small<F, false, LGC>), dim3(1), dim3(lanes), lds, stream, d, T, G, flags); } while (0)
+            if constexpr (sizeof(F) <= 8) {
+                switch (small_sized() ? lg : 0u) {
+                    case 8:  SPPARK_NTT_SMALL_PICK(8); break;
+                    case 9:  SPPARK_NTT_SMALL_PICK(9); break;
+                    case 10: SPPARK_NTT_SMALL_PICK(10); break;
+                    case 11: SPPARK_NTT_SMALL_PICK(11); break;
+                    default: SPPARK_NTT_SMALL_PICK(0); break;
+                }
+            } else
+                SPPARK_NTT_SMALL_PICK(0);
+#undef SPPARK_NTT_SMALL_PICK
             HIP_OK(hipGetLastError());
             return;
         }

@@ -34,10 +34,17 @@
 
 namespace sppark_amd {
 
+// what k_ntt_small (whole transforms by one work-group, below) is compiled for: 2^11 elements of a single-word field (1024
+// lanes, eleven twiddles in registers), 2^10 of a 256-bit one (512 lanes).  What the driver USES by default is
+// ntt_engine::small_max_lg().
+template<class F> struct ntt_small_cap { static constexpr unsigned value = sizeof(F) > 8 ? 10 : 11; };
+// entries of ntt_tables::inner: the levels R <= 8 of the register radices and, for k_ntt_small, R <= its cap
+template<class F> struct ntt_inner_entries { static constexpr unsigned value = 2u << (ntt_small_cap<F>::value > 8 ? ntt_small_cap<F>::value : 8); };
+
 template<class F> struct ntt_tables {
     const F* lo;        // w^k,            k < 2^h
     const F* hi;        // w^(k << h),     k < 2^(lg_n - h)
-    const F* inner;     // inner[(1 << R) + k] = w_{2^R}^k, R <= 8, k < 2^R
+    const F* inner;     // inner[(1 << R) + k] = w_{2^R}^k, R <= min(lg_n, cap), k < 2^R: every level in consecutive entries
     unsigned lg_n, h;
     F scale;            // 1/n for the inverse transform (Montgomery form where applicable)
     // Inter-pass twiddles of THIS pass as a table, pass_tw[(mid << lgQ) + col] = w_{n_cur}^(col * rev_S(mid)),
@@ -430,18 +437,28 @@ void k_ntt_pass_lat(F* data, ntt_tables<F> T, ntt_pass P)
 // it runs <= 2^10 in one launch too, ntt/ntt.cuh:106-107).
 // Here n/2 lanes each keep ONE butterfly pair in registers for the whole transform (the shortest dependent chain there
 // is).  After a stage a lane swaps one of its two values with the lane at distance 2^d -- inside a wave by lane-permute
-// instructions (d < 6: no barrier, no LDS round trip; ntt_rx_regroup), through LDS with one barrier across waves (at
-// most three stages of a 2^10 transform, three of a 2^11 one with two pairs per lane) -- which is the layout of the reference's narrow kernels
+// instructions (d < 6: no barrier, no LDS round trip; ntt_rx_regroup), through LDS with one barrier across waves (three
+// stages of a 2^10 transform, four of a 2^11 one) -- which is the layout of the reference's narrow kernels
 // (ntt/kernels/gs_mixed_radix_narrow.cu:58-118: shfl_bfly = ds_bpermute inside the wave, shared memory above).
-// What differs: every twiddle of the lane (one per stage, w^k from the root table) is loaded at the top, together with
-// the data and the coset powers, so that the whole transform pays ONE memory latency; and everything the driver would
-// otherwise launch around the stages is folded into the load and the store: the bit-reversal permutations of the four
-// orders (ntt/ntt.cuh:174-209), the coset powers g^k (ntt/kernels.cu:131-153) and 1/n.
-// (First version, one butterfly per lane and stage with the array in LDS and a barrier per stage: 3.9 / 4.4 / 5.2 us
-// against the reference's 3.1 / 3.6 / 4.4 on the same box, profiles/r05_ntt_small_first_version.log; this one, Goldilocks
-// 2^8 ... 2^11 in NR order: 2.7 / 3.2 / 4.7 / 7.0 us against 2.9 / 3.5 / 4.4 / 11.5, profiles/r05_ntt_vs_reference_timing.log.
-// At 2^10 a work-group is no longer latency-bound but ISSUE-bound on its one compute unit -- eight waves x ~55 instructions
-// per stage on four SIMDs -- whatever lane layout carries them.)
+// What differs: every twiddle of the lane (one per stage) is loaded at the top, together with the data and the coset
+// powers, so that the whole transform pays ONE memory latency; the twiddles of a stage are one ROW of ntt_tables::inner
+// (w_{2^R}^k for k < 2^R in consecutive entries), so that the lanes of a wave read consecutive entries; the single-word
+// fields have one instance per size 2^8 ... 2^11, a straight line of stages that waits for each load where it is first
+// used; and everything the driver would otherwise launch around the stages is folded into the load and the store: the
+// bit-reversal permutations of the four orders (ntt/ntt.cuh:174-209), the coset powers g^k (ntt/kernels.cu:131-153), 1/n.
+// The versions on the way, Goldilocks 2^8 ... 2^11, NR order, against the reference's build 2.9-3.1 / 3.5 / 4.4 / 11.2-11.5 us
+// on the same box:
+//   one butterfly per lane and stage, the array in LDS, a barrier per stage     3.9 / 4.4 / 5.2 / --    r05_ntt_small_first_version.log
+//   this layout; twiddles w^(k 2^(lg-2-d)) gathered from the root table (up to 64 lines per wave and load, 2400 for a 2^10
+//   transform), the size a run-time value (a branch and a select per stage, every stage behind ALL the loads)
+//                                                                               2.7 / 3.2 / 4.7 / 7.0   r05_ntt_vs_reference_timing_before_sized.log
+//   ... twiddle rows                                                            2.7 / 3.0 / 4.1 / 6.2   r05_ntt_small_sized_ab.log
+//   ... and an instance per size                                                2.5 / 2.8 / 3.6 / 5.3   (2^8, 2^9: the host's issue rate)
+// Measured on the way and NOT kept (same logs): two pairs per lane (n/4 lanes; gained 0.7 us at 2^11 before the instances per
+// size, nothing after them, and loses 0.3 at 2^10); BabyBear's upper twiddles by squaring instead of loads (gained 0.3 us
+// against the gathers, loses 0.1-0.2 against the rows); the exchanges at distance <= 8 as v_cndmask_b32 with a DPP source
+// (16 instructions fewer per transform, 0-0.2 us slower).
+// At 2^10 a work-group is ISSUE-bound on its one compute unit: eight waves x ~51 vector instructions per stage on four SIMDs.
 // Same function of the array as the driver's general path; the emulation and the GPU tests hold both against the oracle.
 enum { NTT_SMALL_GS = 1,            // GS / DIF stages (natural in -> bit-reversed out); else CT / DIT
        NTT_SMALL_PERM_IN = 2,       // the array is bit-reversed on the way in (NN)
@@ -449,9 +466,6 @@ enum { NTT_SMALL_GS = 1,            // GS / DIF stages (natural in -> bit-revers
        NTT_SMALL_BITREV = 8,        // the reference's |bitrev| flag: which index the coset powers follow
        NTT_SMALL_COSET_IN = 16,     // forward coset: x[p] *= g^(bitrev ? rev(p) : p) before the stages
        NTT_SMALL_COSET_OUT = 32 };  // inverse coset: x[p] *= g^-(bitrev ? p : rev(p)) after them
-// what the kernel is compiled for: 2^11 elements of a single-word field (1024 lanes, eleven twiddles in registers), 2^10
-// of a 256-bit one (512 lanes).  What the driver USES by default is ntt_engine::small_max_lg().
-template<class F> struct ntt_small_cap { static constexpr unsigned value = sizeof(F) > 8 ? 10 : 11; };
 
 #if defined(SPPARK_HOST_EMULATION)
 extern "C" void sppark_emu_barrier();          // (tests/emu: the lanes of a work-group are host threads)
@@ -479,183 +493,132 @@ template<unsigned N> struct ntt_static_for<N, N> { template<class Fn> SPPARK_DEV
 //              turn, so that ONE barrier per exchange is enough (a lane can only write a buffer again after the barrier of
 //              the exchange in between, which every lane reaches with its read of that buffer behind it).
 template<class F> SPPARK_DEVFN F ntt_rx_pick(bool first, const F& a, const F& b) { return first ? a : b; }
-// Q pairs per lane (the same exchange for each of them; through LDS they share ONE barrier)
-template<class F, unsigned D, unsigned Q>
-SPPARK_DEVFN void ntt_rx_regroup(F (&x0)[Q], F (&x1)[Q], const F (&sum)[Q], const F (&dif)[Q], unsigned lane, F* lds, unsigned lanes, unsigned& par)
+template<class F, unsigned D>
+SPPARK_DEVFN void ntt_rx_regroup(F& x0, F& x1, const F& sum, const F& dif, unsigned lane, F* lds, unsigned lanes, unsigned& par)
 {
     const bool upper = ((lane >> D) & 1u) != 0;
-    F recv[Q];
+    F recv;
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr unsigned W = sizeof(F) / 4;
     static_assert(sizeof(F) % 4 == 0, "whole words");
     if constexpr (D == 5 || D == 4) {
+        u32 s[W], d[W];
+        __builtin_memcpy(s, &sum, sizeof(F)); __builtin_memcpy(d, &dif, sizeof(F));
         #pragma unroll
-        for (unsigned q = 0; q < Q; q++) {
-            u32 s[W], d[W];
-            __builtin_memcpy(s, &sum[q], sizeof(F)); __builtin_memcpy(d, &dif[q], sizeof(F));
-            #pragma unroll
-            for (unsigned k = 0; k < W; k++) {
-                if constexpr (D == 5) { auto r = __builtin_amdgcn_permlane32_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
-                else                  { auto r = __builtin_amdgcn_permlane16_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
-            }
-            __builtin_memcpy(&x0[q], s, sizeof(F)); __builtin_memcpy(&x1[q], d, sizeof(F));
+        for (unsigned k = 0; k < W; k++) {
+            if constexpr (D == 5) { auto r = __builtin_amdgcn_permlane32_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
+            else                  { auto r = __builtin_amdgcn_permlane16_swap(s[k], d[k], false, false); s[k] = r[0]; d[k] = r[1]; }
         }
+        __builtin_memcpy(&x0, s, sizeof(F)); __builtin_memcpy(&x1, d, sizeof(F));
         return;
     } else if constexpr (D < 6) {
+        const F send = ntt_rx_pick(upper, sum, dif);
+        u32 w[W];
+        __builtin_memcpy(w, &send, sizeof(F));
         #pragma unroll
-        for (unsigned q = 0; q < Q; q++) {
-            const F send = ntt_rx_pick(upper, sum[q], dif[q]);
-            u32 w[W];
-            __builtin_memcpy(w, &send, sizeof(F));
-            #pragma unroll
-            for (unsigned k = 0; k < W; k++) {
-                if constexpr (D == 3)      w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x128, 0xf, 0xf, false);   // row_ror:8
-                else if constexpr (D == 1) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-                else if constexpr (D == 0) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-                else                       w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)(((lane & 63u) ^ (1u << D)) << 2), (int)w[k]);
-            }
-            __builtin_memcpy(&recv[q], w, sizeof(F));
+        for (unsigned k = 0; k < W; k++) {
+            if constexpr (D == 3)      w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x128, 0xf, 0xf, false);   // row_ror:8
+            else if constexpr (D == 1) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+            else if constexpr (D == 0) w[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)w[k], 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+            else                       w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)(((lane & 63u) ^ (1u << D)) << 2), (int)w[k]);
         }
+        __builtin_memcpy(&recv, w, sizeof(F));
     } else
 #endif
     {
-        F* buf = lds + (size_t)par * Q * lanes;
+        F* buf = lds + (size_t)par * lanes;
         par ^= 1;
-        #pragma unroll
-        for (unsigned q = 0; q < Q; q++) ntt_lat_put(buf + (size_t)q * lanes, lane, lanes, ntt_rx_pick(upper, sum[q], dif[q]));
+        ntt_lat_put(buf, lane, lanes, ntt_rx_pick(upper, sum, dif));
         ntt_wg_barrier();
-        #pragma unroll
-        for (unsigned q = 0; q < Q; q++) recv[q] = ntt_lat_get(buf + (size_t)q * lanes, lane ^ (1u << D), lanes);
+        recv = ntt_lat_get(buf, lane ^ (1u << D), lanes);
     }
-    #pragma unroll
-    for (unsigned q = 0; q < Q; q++) { x0[q] = ntt_rx_pick(upper, recv[q], sum[q]); x1[q] = ntt_rx_pick(upper, dif[q], recv[q]); }
+    x0 = ntt_rx_pick(upper, recv, sum); x1 = ntt_rx_pick(upper, dif, recv);
 }
 
-// Physical lane |l| of |lanes| carries Q butterfly pairs: those of the VIRTUAL lanes L = l + q * lanes of the n/2-lane
-// network above (Q = 1: lanes = max(n/2, 64), lanes beyond n/2 carry zeros through the same exchanges and touch no memory;
-// Q = 2: lanes = n/4 >= 64).  With Q = 2 the exchange at the largest distance, 2^(lg-2) = |lanes|, is between the two pairs
-// of ONE lane -- a register move -- and every other one moves both pairs at once: a 2^10 transform is four waves with two
-// exchanges through LDS instead of eight waves with three.
-template<class F, bool INV, bool GS, unsigned Q>
+// Lane |l| of max(n/2, 64) carries the butterfly pair l of the n/2-lane network above (lanes beyond n/2 carry zeros through the
+// same exchanges and touch no memory).
+// LGC: the size the body is compiled for (0: any size up to the cap, read from the tables at run time).  With the size
+// known, the stages are one straight line -- no per-stage branch, no select between the top twiddle and the others, and
+// each stage waits for ITS twiddle instead of all the loads.
+template<class F, bool INV, bool GS, unsigned LGC = 0>
 SPPARK_DEVFN void ntt_rx_run(F* data, F* lds, const ntt_tables<F>& T, const ntt_tables<F>& G, unsigned flags,
                              unsigned l, unsigned lanes)
 {
     constexpr unsigned MAXLG = ntt_small_cap<F>::value;
-    const unsigned lg = T.lg_n, nh = 1u << (lg - 1);
-    const bool live = Q > 1 || l < nh;
+    static_assert(LGC <= MAXLG && (LGC == 0 || LGC >= 7), "a compiled-in size fills at least one wave");
+    const unsigned lg = LGC ? LGC : T.lg_n, nh = 1u << (lg - 1);
+    const bool live = l < nh;
     const unsigned lq = live ? l : 0;                           // (idle lanes read the tables at valid indices)
-    F x0[Q], x1[Q], sum[Q], dif[Q], g0[Q], g1[Q], wtop[Q], w[MAXLG - 1];
-    unsigned pin0[Q], pin1[Q], pout0[Q], pout1[Q];
+    F x0 = F(), x1 = F(), sum, dif, g0 = F(), g1 = F(), w[MAXLG];
     // ---- every load of the transform, issued together ------------------------------------------------------------------
-    #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        const unsigned L = lq + q * lanes;                      // the virtual lane
-        // positions of its pair in the working array: GS (L, L + n/2) -> (2L, 2L + 1); CT (2L, 2L + 1) -> (L, L + n/2)
-        pin0[q] = GS ? L : 2 * L; pin1[q] = GS ? L + nh : 2 * L + 1;
-        pout0[q] = GS ? 2 * L : L; pout1[q] = GS ? 2 * L + 1 : L + nh;
-        x0[q] = F(); x1[q] = F(); g0[q] = F(); g1[q] = F();
-        if (live) {
-            x0[q] = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin0[q], lg) : pin0[q]];
-            x1[q] = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin1[q], lg) : pin1[q]];
-        }
-        // the stage with halves of n/2 elements (GS: the first, CT: the last): w^L
-        wtop[q] = T.lo[L & (nh - 1)];
+    // positions of the pair in the working array: GS (l, l + n/2) -> (2l, 2l + 1); CT (2l, 2l + 1) -> (l, l + n/2)
+    const unsigned pin0 = GS ? lq : 2 * lq, pin1 = GS ? lq + nh : 2 * lq + 1;
+    const unsigned pout0 = GS ? 2 * lq : lq, pout1 = GS ? 2 * lq + 1 : lq + nh;
+    if (live) {
+        x0 = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin0, lg) : pin0];
+        x1 = data[(flags & NTT_SMALL_PERM_IN) ? bit_rev32(pin1, lg) : pin1];
     }
-    // w[d] is the twiddle of the stage with halves of 2^(d+1) elements -- GS: stage lg-2-d, followed by the exchange at
-    // distance 2^d; CT: stage d+1, preceded by it -- and in both networks it is w^((L mod 2^(d+1)) 2^(lg-2-d)); below the top
-    // stage that is the same for the Q pairs of a lane
-    // BabyBear: only the stages with halves <= 16 LOAD their twiddle (d < 4: at most 16 distinct table entries per wave); the
-    // others follow from the top one by squaring, w[d] = w[d+1]^2 (-1)^(bit d+1 of l) -- (l mod 2^(d+1)) 2^(lg-2-d) is twice
-    // (l mod 2^(d+2)) 2^(lg-3-d) less bit_(d+1)(l) n/2, and w^(n/2) = -1.  As loads they are gathers of up to 64 cache lines per
-    // wave and stage (2400 lines for a 2^10 transform); a 5-instruction Montgomery squaring per stage rides in the issue slots the
-    // dependent butterfly chain leaves empty: 2^10 3.5 -> 3.2 us, 2^11 4.7 -> 4.4.  Goldilocks, whose squaring is a 64 x 64-bit
-    // product (28 instructions), LOSES 0.2-0.3 us at 2^8 / 2^9 and gains nothing at 2^10, and a 256-bit squaring is ~300
-    // instructions: both keep the loads (profiles/r05_ntt_small_squared_twiddles.log against r05_ntt_small_pairs_per_lane_ab.log).
-    constexpr bool SQUARE = sizeof(F) <= 4;
-    constexpr unsigned DLOAD = SQUARE ? 4 : MAXLG - 1;
-    ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
-        constexpr unsigned d = decltype(K)::value;
-        if (d < DLOAD && d + 2 <= lg) w[d] = T.lo[(lq & ((2u << d) - 1) & (nh - 1)) << (lg - 2 - d)];
+    // w[d] is the twiddle of the stage with halves of 2^d elements, d >= 1 -- GS: stage lg-1-d, followed by the exchange at
+    // distance 2^(d-1); CT: stage d, preceded by it -- and in both networks it is w_{2^(d+1)}^(l mod 2^d): entry l mod 2^d of
+    // row d+1 of T.inner.  Issued in the order the stages use them.
+    ntt_static_for<1, MAXLG>::run([&](auto K) {
+        constexpr unsigned d = GS ? MAXLG - decltype(K)::value : decltype(K)::value;
+        if (d < lg) w[d] = T.inner[(2u << d) + (lq & ((1u << d) - 1))];
     });
-    if constexpr (SQUARE) {
-        F cur = wtop[0];                                        // w[lg-2] of virtual lane l
-        ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
-            constexpr unsigned d = MAXLG - 2 - decltype(K)::value;              // MAXLG - 2, ..., 0
-            if (d >= DLOAD && d + 2 <= lg) {
-                if (d + 2 < lg) { cur = cur * cur; if ((lq >> (d + 1)) & 1u) cur = F() - cur; }
-                w[d] = cur;
-            }
-        });
-    }
-    #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        if (flags & NTT_SMALL_COSET_IN) {
-            g0[q] = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin0[q], lg) : pin0[q]];
-            g1[q] = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin1[q], lg) : pin1[q]];
-        } else if (flags & NTT_SMALL_COSET_OUT) {
-            g0[q] = G.lo[(flags & NTT_SMALL_BITREV) ? pout0[q] : bit_rev32(pout0[q], lg)];
-            g1[q] = G.lo[(flags & NTT_SMALL_BITREV) ? pout1[q] : bit_rev32(pout1[q], lg)];
-        }
-        if (flags & NTT_SMALL_COSET_IN) { x0[q] = x0[q] * g0[q]; x1[q] = x1[q] * g1[q]; }
+    if (flags & NTT_SMALL_COSET_IN) {
+        g0 = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin0, lg) : pin0];
+        g1 = G.lo[(flags & NTT_SMALL_BITREV) ? bit_rev32(pin1, lg) : pin1];
+        x0 = x0 * g0; x1 = x1 * g1;
+    } else if (flags & NTT_SMALL_COSET_OUT) {
+        g0 = G.lo[(flags & NTT_SMALL_BITREV) ? pout0 : bit_rev32(pout0, lg)];
+        g1 = G.lo[(flags & NTT_SMALL_BITREV) ? pout1 : bit_rev32(pout1, lg)];
     }
     // ---- the stages ----------------------------------------------------------------------------------------------------
-    // the exchange between the pairs of one lane (Q = 2, distance |lanes|): pair 0 keeps the sums, pair 1 the differences
-    auto regroup_in_lane = [&]() {
-        if constexpr (Q == 2) { x0[0] = sum[0]; x1[0] = sum[1]; x0[1] = dif[0]; x1[1] = dif[1]; }
-    };
     unsigned par = 0;
     if (GS) {
-        // stage lg-2-d: (x0 + x1, (x0 - x1) w), then the lanes L and L ^ 2^d regroup: the lower one keeps the sums, the
+        // halves of 2^d: (x0 + x1, (x0 - x1) w), then the lanes l and l ^ 2^(d-1) regroup: the lower one keeps the sums, the
         // upper one the differences
-        ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
-            constexpr unsigned d = MAXLG - 2 - decltype(K)::value;              // MAXLG - 2, ..., 1, 0
-            if (d + 2 <= lg) {
-                const bool top = d + 2 == lg;
-                #pragma unroll
-                for (unsigned q = 0; q < Q; q++) { F::bfly(x0[q], x1[q], sum[q], dif[q]); dif[q] = dif[q] * (top ? wtop[q] : w[d]); }
-                if (Q > 1 && top) regroup_in_lane();
-                else              ntt_rx_regroup<F, d, Q>(x0, x1, sum, dif, l, lds, lanes, par);
+        ntt_static_for<1, MAXLG>::run([&](auto K) {
+            constexpr unsigned d = MAXLG - decltype(K)::value;                  // MAXLG - 1, ..., 1
+            if (d < lg) {
+                F::bfly(x0, x1, sum, dif); dif = dif * w[d];
+                ntt_rx_regroup<F, d - 1>(x0, x1, sum, dif, l, lds, lanes, par);
             }
         });
-        #pragma unroll
-        for (unsigned q = 0; q < Q; q++) { F::bfly(x0[q], x1[q], sum[q], dif[q]); x0[q] = sum[q]; x1[q] = dif[q]; }      // the last stage: halves of 1, w^0
+        F::bfly(x0, x1, sum, dif);                              // the last stage: halves of 1, w^0
     } else {
-        #pragma unroll
-        for (unsigned q = 0; q < Q; q++) F::bfly(x0[q], x1[q], sum[q], dif[q]);                                        // stage 0: halves of 1, w^0
-        ntt_static_for<0, MAXLG - 1>::run([&](auto K) {
-            constexpr unsigned d = decltype(K)::value;          // exchange at distance 2^d, then stage d + 1
-            if (d + 2 <= lg) {
-                const bool top = d + 2 == lg;
-                if (Q > 1 && top) regroup_in_lane();
-                else              ntt_rx_regroup<F, d, Q>(x0, x1, sum, dif, l, lds, lanes, par);
-                #pragma unroll
-                for (unsigned q = 0; q < Q; q++) F::bfly(x0[q], x1[q] * (top ? wtop[q] : w[d]), sum[q], dif[q]);
+        F::bfly(x0, x1, sum, dif);                              // stage 0: halves of 1, w^0
+        ntt_static_for<1, MAXLG>::run([&](auto K) {
+            constexpr unsigned d = decltype(K)::value;          // the exchange at distance 2^(d-1), then halves of 2^d
+            if (d < lg) {
+                ntt_rx_regroup<F, d - 1>(x0, x1, sum, dif, l, lds, lanes, par);
+                F::bfly(x0, x1 * w[d], sum, dif);
             }
         });
-        #pragma unroll
-        for (unsigned q = 0; q < Q; q++) { x0[q] = sum[q]; x1[q] = dif[q]; }
     }
+    x0 = sum; x1 = dif;
     // ---- the store -----------------------------------------------------------------------------------------------------
-    #pragma unroll
-    for (unsigned q = 0; q < Q; q++) {
-        if (INV) { x0[q] = x0[q] * T.scale; x1[q] = x1[q] * T.scale; }
-        if (flags & NTT_SMALL_COSET_OUT) { x0[q] = x0[q] * g0[q]; x1[q] = x1[q] * g1[q]; }
-        if (live) {
-            data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout0[q], lg) : pout0[q]] = x0[q];
-            data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout1[q], lg) : pout1[q]] = x1[q];
-        }
+    if (INV) { x0 = x0 * T.scale; x1 = x1 * T.scale; }
+    if (flags & NTT_SMALL_COSET_OUT) { x0 = x0 * g0; x1 = x1 * g1; }
+    if (live) {
+        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout0, lg) : pout0] = x0;
+        data[(flags & NTT_SMALL_PERM_OUT) ? bit_rev32(pout1, lg) : pout1] = x1;
     }
 }
-// Q = pairs per lane (1: up to n/2 = 2^(cap-1) lanes; 2: n/4 lanes)
-template<class F, bool INV, unsigned Q>
-__global__ __launch_bounds__(1u << (ntt_small_cap<F>::value - Q))
+template<class F, bool INV, unsigned LGC = 0>
+__global__ __launch_bounds__(1u << ((LGC ? LGC : ntt_small_cap<F>::value) - 1))
 void k_ntt_small(F* data, ntt_tables<F> T, ntt_tables<F> G, unsigned flags)
 {
     extern __shared__ unsigned char ntt_lds[];
     F* lds = reinterpret_cast<F*>(ntt_lds);
-    if (flags & NTT_SMALL_GS) ntt_rx_run<F, INV, true, Q>(data, lds, T, G, flags, threadIdx.x, blockDim.x);      // (uniform over the launch)
-    else                      ntt_rx_run<F, INV, false, Q>(data, lds, T, G, flags, threadIdx.x, blockDim.x);
+    if (flags & NTT_SMALL_GS) ntt_rx_run<F, INV, true, LGC>(data, lds, T, G, flags, threadIdx.x, blockDim.x);    // (uniform over the launch)
+    else                      ntt_rx_run<F, INV, false, LGC>(data, lds, T, G, flags, threadIdx.x, blockDim.x);
 }
+// the instances: X(INV, LGC).  Single-word fields: sizes 2^8 ... 2^11 compiled in, one kernel for everything below; the
+// 256-bit fields (a stage is ~350 instructions, the branches are noise): the run-time form only.
+#define SPPARK_NTT_SMALL_ALL_NARROW(X) X(false, 0) X(false, 8) X(false, 9) X(false, 10) X(false, 11) \
+                                       X(true, 0) X(true, 8) X(true, 9) X(true, 10) X(true, 11)
+#define SPPARK_NTT_SMALL_ALL_WIDE(X)   X(false, 0) X(true, 0)
 // the flags of an (order, direction, type) call -- ntt/ntt.cuh:174-209: NN = bit_rev + CT, NR = GS, RN = CT, RR = GS + bit_rev
 static inline unsigned ntt_small_flags(int order, bool inverse, bool coset)
 {
@@ -875,13 +838,13 @@ __global__ __launch_bounds__(256) void k_bitrev_copy(F* out, const F* in, unsign
 }
 
 // table generation: lo[k] = base^k (k < 2^h), hi[k] = (base^(2^h))^k (k < 2^(lg_n-h)),
-// inner[(1 << R) + k] = w_{2^R}^k = base^(k << (lg_n - R)) for R <= min(8, lg_n)
+// inner[(1 << R) + k] = w_{2^R}^k = base^(k << (lg_n - R)) for R <= min(cap, lg_n) (ntt_inner_entries)
 template<class F>
 SPPARK_DEVFN void table_item(F* lo, F* hi, F* inner, F base, unsigned lg_n, unsigned h, size_t k)
 {
     if (k < ((size_t)1 << h)) lo[k] = field_pow(base, k);
     if (k < ((size_t)1 << (lg_n - h))) { F b = base; for (unsigned s = 0; s < h; s++) b = b * b; hi[k] = field_pow(b, k); }
-    if (inner && k >= 2 && k < 512) {
+    if (inner && k >= 2 && k < ntt_inner_entries<F>::value) {
         unsigned R = 31 - __builtin_clz((unsigned)k), e = (unsigned)k - (1u << R);
         inner[k] = R <= lg_n ? field_pow(base, (u64)e << (lg_n - R)) : F::one();
     }

@@ -175,9 +175,9 @@ extern "C" void sppark_emu_barrier() { g_bar.wait(); }
 
 // transforms up to this size as ONE work-group (k_ntt_small); as ntt_engine::small_max_lg(); 0 = the general path
 static unsigned g_small_max = sizeof(F) > 8 ? ntt_small_cap<F>::value - 1 : ntt_small_cap<F>::value;
-static unsigned g_small_q2 = 11;                           // two pairs per lane from this size on (>= 8)
+static unsigned g_small_sized = 1;                          // as ntt_engine::small_sized()
 extern "C" void emu_ntt_small(unsigned max_lg) { g_small_max = max_lg; }
-extern "C" void emu_ntt_small_q2(unsigned lg) { g_small_q2 = lg; }
+extern "C" void emu_ntt_small_sized(unsigned on) { g_small_sized = on; }      // 0: the run-time-size instance at every size
 
 extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int type, unsigned nt)
 {
@@ -186,12 +186,12 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     const size_t n = (size_t)1 << lg;
     const int inverse = direction == 1;
     unsigned h = lg < 12 ? lg : 12;
-    std::vector<F> lo(1u << h), hi((size_t)1 << (lg - h)), glo(1u << h), ghi((size_t)1 << (lg - h)), inner(512);
+    std::vector<F> lo(1u << h), hi((size_t)1 << (lg - h)), glo(1u << h), ghi((size_t)1 << (lg - h)), inner(ntt_inner_entries<F>::value);
     F w = top_root();
     for (unsigned k = F::TWO_ADICITY; k > lg; k--) w = w * w;
     F g = group_gen();
     if (inverse) { w = finv(w); g = finv(g); }
-    for (size_t k = 0; k < std::max<size_t>(std::max(lo.size(), hi.size()), 512); k++) {
+    for (size_t k = 0; k < std::max<size_t>(std::max(lo.size(), hi.size()), inner.size()); k++) {
         table_item(lo.data(), hi.data(), inner.data(), w, lg, h, k);
         table_item(glo.data(), ghi.data(), (F*)nullptr, g, lg, h, k);
     }
@@ -200,16 +200,22 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
 
     if (lg <= g_small_max) {                                    // k_ntt_small: its lanes as host threads (barrier hook below)
         const unsigned flags = ntt_small_flags(order, inverse != 0, type == 1);
-        const bool two = lg >= g_small_q2;                      // as ntt_engine::small_two_pairs_lg()
-        const unsigned lanes = two ? (unsigned)(n / 4) : (unsigned)std::max<size_t>(64, n / 2);
-        std::vector<F> lds((two ? 4 : 2) * (size_t)lanes + 1);
+        const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
+        std::vector<F> lds(2 * (size_t)lanes + 1);
+        // as ntt_engine::run(): the single-word fields have an instance compiled for each of the sizes 2^8 ... 2^11
+        auto lane = [&](unsigned tid, auto LGC) {
+            constexpr unsigned C = sizeof(F) <= 8 ? decltype(LGC)::value : 0;      // (256-bit fields: the run-time form only)
+            if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true, C>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true, C>(d, lds.data(), T, G, flags, tid, lanes); }
+            else                      { if (inverse) ntt_rx_run<F, true, false, C>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false, C>(d, lds.data(), T, G, flags, tid, lanes); }
+        };
+        const unsigned sized = (sizeof(F) <= 8 && g_small_sized) ? lg : 0;
         run_group(lanes, [&](unsigned tid) {
-            if (two) {
-                if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true, 2>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true, 2>(d, lds.data(), T, G, flags, tid, lanes); }
-                else                      { if (inverse) ntt_rx_run<F, true, false, 2>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false, 2>(d, lds.data(), T, G, flags, tid, lanes); }
-            } else {
-                if (flags & NTT_SMALL_GS) { if (inverse) ntt_rx_run<F, true, true, 1>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, true, 1>(d, lds.data(), T, G, flags, tid, lanes); }
-                else                      { if (inverse) ntt_rx_run<F, true, false, 1>(d, lds.data(), T, G, flags, tid, lanes); else ntt_rx_run<F, false, false, 1>(d, lds.data(), T, G, flags, tid, lanes); }
+            switch (sized) {
+                case 8:  lane(tid, std::integral_constant<unsigned, 8>()); break;
+                case 9:  lane(tid, std::integral_constant<unsigned, 9>()); break;
+                case 10: lane(tid, std::integral_constant<unsigned, 10>()); break;
+                case 11: lane(tid, std::integral_constant<unsigned, 11>()); break;
+                default: lane(tid, std::integral_constant<unsigned, 0>()); break;
             }
         });
         return 0;

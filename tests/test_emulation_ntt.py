@@ -33,8 +33,8 @@ def _emu(feature):
     L.emu_ntt_lat_plan.restype = ctypes.c_uint
     L.emu_ntt_small.argtypes = [ctypes.c_uint]
     L.emu_ntt_small.restype = None
-    L.emu_ntt_small_q2.argtypes = [ctypes.c_uint]
-    L.emu_ntt_small_q2.restype = None
+    L.emu_ntt_small_sized.argtypes = [ctypes.c_uint]
+    L.emu_ntt_small_sized.restype = None
     return L
 
 
@@ -58,22 +58,24 @@ def test_small_transforms_in_one_work_group_on_host(oracle, field, feature):
     f = _oracle_ntt(oracle, field)
     cap = 10 if field in ("bls12_381", "bn254") else 11         # ntt_small_cap<F>: what the kernel is compiled for
     L.emu_ntt_small(cap)
-    # one pair per lane at every size; then two pairs per lane (n/4 lanes: the largest exchange inside a lane) from 2^8 on
-    for q2 in (99, 8):
-        L.emu_ntt_small_q2(q2)
-        for lg in range(1 if q2 == 99 else 8, cap + 1):
+    # single-word fields: the instances compiled for one size (2^8 ... 2^11, what the driver launches there) and the
+    # run-time-size instance below them; then the run-time-size instance at those sizes too
+    wide = field in ("bls12_381", "bn254")
+    for sized in (1,) if wide else (1, 0):
+        L.emu_ntt_small_sized(sized)
+        for lg in range(1 if sized else 8, cap + 1):
             x = recipe.ntt_input(field, lg, 900 + lg)
             for order in range(4):
                 for direction in range(2):
                     for typ in range(2):
                         y = x.copy()
                         L.emu_ntt(y.ctypes.data, lg, order, direction, typ, 64)
-                        assert (y == f(x, order, direction, typ)).all(), (field, q2, lg, order, direction, typ)
+                        assert (y == f(x, order, direction, typ)).all(), (field, sized, lg, order, direction, typ)
             # forward then inverse is the identity in every order pairing the reference's tests use (poc/ntt-cuda/tests/ntt.rs)
             y = x.copy()
             L.emu_ntt(y.ctypes.data, lg, 1, 0, 1, 64); L.emu_ntt(y.ctypes.data, lg, 2, 1, 1, 64)
             assert (y == x).all()
-    L.emu_ntt_small_q2(11)
+    L.emu_ntt_small_sized(1)
     L.emu_ntt_small(9 if field in ("bls12_381", "bn254") else 11)  # the engine's defaults
 
 

@@ -4,7 +4,7 @@ reference: ref_ntt_dev_timed of oracle/ref_ntt_shim.cu).  Next to it the latency
 NULL stream, where both libraries return only when the result is in place (ours: sppark_ntt(stream = NULL); the
 reference: ref_ntt_dev, which synchronises): wall clock per call from a Python loop, the same loop for both.
 
-    python tools/gpu_ntt_small_vs_reference.py [field=gl64] [lg=8] [order=1] [only=ours|ref]
+    python tools/gpu_ntt_small_vs_reference.py [field=gl64 | fields=gl64,bb31] [lg=8 | lgs=8-11] [order=1] [only=ours|ref]
 """
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,11 +27,12 @@ stream = torch.cuda.current_stream().cuda_stream
 order = int(args.get("order", 1))
 behind = []
 for field, dt, eb in (("gl64", torch.int64, 8), ("bb31", torch.int32, 4), ("bls12_381", torch.int64, 32), ("bn254", torch.int64, 32)):
-    if args.get("field", field) != field:
+    if field not in args.get("fields", args.get("field", field)).split(","):
         continue
     L = ffi.load(field)
     fn = ctypes.cast(L.sppark_ntt, ctypes.c_void_p)
-    for lg in ([int(args["lg"])] if "lg" in args else range(8, 21)):
+    lo_hi = [int(v) for v in args.get("lgs", "8-20").split("-")]
+    for lg in ([int(args["lg"])] if "lg" in args else range(lo_hi[0], lo_hi[1] + 1)):
         n = 1 << lg
         x = torch.randint(0, 2**30, (n * (eb // 8 if eb >= 8 else 1),), dtype=dt, device="cuda")
         p = ctypes.c_void_p(x.data_ptr())

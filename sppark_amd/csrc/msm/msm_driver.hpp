@@ -115,7 +115,7 @@ private:
             }
             l.digits[b] = take(wg * p.n * 4);
             l.sorted[b] = take(wg * p.n * 4);
-            l.partA[b]  = take(wg * p.n * 8);
+            l.partA[b]  = take(wg * p.n * (p.IB ? 4 : 8));                         // level-A records: packed / wide
             l.H[b]      = take(wg * p.nslabs * p.NA * 4);
             l.tot[b]    = take(wg * p.NA * 4);
             l.offA[b]   = take(wg * (p.NA + 1) * 4);
@@ -469,8 +469,12 @@ private:
         u32* H = (u32*)(blob + l.H[b]);
         u32* tot = (u32*)(blob + l.tot[b]);
         u32* off = (u32*)(blob + l.off[b]);
-        uint2* partA = (uint2*)(blob + l.partA[b]);
+        void* partA = blob + l.partA[b];
         u32* offA = (u32*)(blob + l.offA[b]);
+        // level-A records: 4 bytes where the plan allows it (msm_sort_kernels.hpp), PK = packed
+        const bool packed = p.IB != 0;
+        unsigned ngp = 1; while (ngp < p.NG) ngp <<= 1;
+        const partA_fmt fmt{H, p.IB, p.SH, ngp, p.nslabs};
         // local index of the first short window of this group (window_len: the first nbits % nwins are long)
         const unsigned nlong = p.nbits % p.nwins, sf = nlong == 0 ? wn : (nlong > w0 ? std::min(wn, nlong - w0) : 0u);
         if (fb_n) {
@@ -483,11 +487,11 @@ private:
                                digits, d_scalars, p.n, p.nwins, p.nbits, (int)mont, w0, wn);
         }
         HIP_OK(hipGetLastError());
-        size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + SORT_NT * 4 + (size_t)SORTB_STAGE * 4;
+        size_t ldsA = (size_t)p.NA * 4, ldsB = ((size_t)1 << p.LB) * 4 + SORT_NT * 4 + (size_t)SORTB_STAGE * 4 + PARTA_MAX_GROUPS * 4;
         // (the attribute is per device and sticky: raised once to the largest size asked for so far,
         // not on every MSM -- lds_attr())
-        if (ldsA > 65536) { lds_attr((const void*)k_histA, ldsA); lds_attr((const void*)k_scatterA, ldsA); }
-        if (ldsB > 65536) lds_attr((const void*)k_sortB, ldsB);
+        if (ldsA > 65536) { lds_attr((const void*)k_histA, ldsA); lds_attr(packed ? (const void*)k_scatterA<true> : (const void*)k_scatterA<false>, ldsA); }
+        if (ldsB > 65536) lds_attr(packed ? (const void*)k_sortB<true> : (const void*)k_sortB<false>, ldsB);
         hipLaunchKernelGGL(k_histA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
                            H, digits, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
         HIP_OK(hipGetLastError());
@@ -499,12 +503,17 @@ private:
         HIP_OK(hipGetLastError());
         if (p.NA <= SCATA_MAX_NA && p.LB < 16) {      // (always, with the automatic split: HB <= 12)
             const size_t ldsS = scatterA_staged_lds(p.NA);
-            lds_attr((const void*)k_scatterA_staged, ldsS);
-            hipLaunchKernelGGL(k_scatterA_staged, dim3(p.nslabs, wn), dim3(SORT_NT), ldsS, ss,
-                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
-        } else
-            hipLaunchKernelGGL(k_scatterA, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
-                               partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf);
+            lds_attr(packed ? (const void*)k_scatterA_staged<true> : (const void*)k_scatterA_staged<false>, ldsS);
+            if (packed) hipLaunchKernelGGL(k_scatterA_staged<true>, dim3(p.nslabs, wn), dim3(SORT_NT), ldsS, ss,
+                                           (u32*)partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf, p.IB);
+            else        hipLaunchKernelGGL(k_scatterA_staged<false>, dim3(p.nslabs, wn), dim3(SORT_NT), ldsS, ss,
+                                           (uint2*)partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf, p.IB);
+        } else {
+            if (packed) hipLaunchKernelGGL(k_scatterA<true>, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                                           (u32*)partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf, p.IB);
+            else        hipLaunchKernelGGL(k_scatterA<false>, dim3(p.nslabs, wn), dim3(SORT_NT), ldsA, ss,
+                                           (uint2*)partA, digits, H, offA, p.n, p.nslabs, p.slab_sz, p.NA, p.LB, sf, p.IB);
+        }
         HIP_OK(hipGetLastError());
         const unsigned big = tune.big ? tune.big : p.big ? p.big : (1u << 18);
         u32* nbig = (u32*)(blob + l.bigl[b]); u32* blist = nbig + 1; u32* curB = (u32*)(blob + l.curB[b]);
@@ -513,8 +522,10 @@ private:
         // MSM up to 2^18 points)
         const bool may_be_big = p.n > big;
         if (may_be_big) HIP_OK(hipMemsetAsync(nbig, 0, 4, ss));
-        hipLaunchKernelGGL(k_sortB, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
-                           sorted, off, partA, offA, p.n, p.NA, p.LB, sf, big);
+        if (packed) hipLaunchKernelGGL(k_sortB<true>, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
+                                       sorted, off, (const u32*)partA, offA, p.n, p.NA, p.LB, sf, big, fmt);
+        else        hipLaunchKernelGGL(k_sortB<false>, dim3(p.NA, wn), dim3(SORT_NT), ldsB, ss,
+                                       sorted, off, (const uint2*)partA, offA, p.n, p.NA, p.LB, sf, big, fmt);
         HIP_OK(hipGetLastError());
         if (!may_be_big) return;
         // oversized partitions (skewed scalars); empty list and immediate return otherwise
@@ -526,11 +537,13 @@ private:
         // whose partitions differ by a factor of two)
         const size_t avg = (size_t)p.n / p.NA;
         const unsigned split = avg > big / 2 ? (unsigned)std::min<size_t>(SORTB_SPLIT, avg / (BIG_STAGE / 2) + 1) : SORTB_SPLIT;
-        hipLaunchKernelGGL(k_big_hist, dim3(1024), dim3(1024), ldsBig, ss, off, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split);
+        if (packed) hipLaunchKernelGGL(k_big_hist<true>, dim3(1024), dim3(1024), ldsBig, ss, off, (const u32*)partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split);
+        else        hipLaunchKernelGGL(k_big_hist<false>, dim3(1024), dim3(1024), ldsBig, ss, off, (const uint2*)partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split);
         hipLaunchKernelGGL(k_big_scan, dim3(p.NA > 64 && avg > big / 2 ? 1024 : 64), dim3(1024), 0, ss, off, curB, offA, nbig, blist, p.NA, p.LB, sf);
         const size_t ldsSc = big_scatter_lds(p.LB);
-        if (ldsSc > 65536) lds_attr((const void*)k_big_scatter, ldsSc);
-        hipLaunchKernelGGL(k_big_scatter, dim3(1024), dim3(1024), ldsSc, ss, sorted, curB, partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split);
+        if (ldsSc > 65536) lds_attr(packed ? (const void*)k_big_scatter<true> : (const void*)k_big_scatter<false>, ldsSc);
+        if (packed) hipLaunchKernelGGL(k_big_scatter<true>, dim3(1024), dim3(1024), ldsSc, ss, sorted, curB, (const u32*)partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split, fmt);
+        else        hipLaunchKernelGGL(k_big_scatter<false>, dim3(1024), dim3(1024), ldsSc, ss, sorted, curB, (const uint2*)partA, offA, nbig, blist, p.n, p.NA, p.LB, sf, split, fmt);
         HIP_OK(hipGetLastError());
     }
 

@@ -18,6 +18,9 @@ struct msm_plan {
     unsigned K1;                        // ... of the first level (buckets per work item)
     unsigned G, wpg;                    // window groups, windows per group (the last group may be shorter)
     unsigned big;                       // level-A partitions above this many entries go to the cooperative level B (0 = the tunable / 2^18)
+    // level-A records in 4 bytes (msm_sort_kernels.hpp): index bits kept in the record (0 = 8-byte records), log2 of the
+    // slabs per index group, index groups (boundaries level B searches)
+    unsigned IB, SH, NG;
 };
 
 struct msm_tunables {                   // 0 = automatic
@@ -27,6 +30,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
+    unsigned pack = 0;                  // level-A sort records: 0 = 4 bytes where the plan allows it, 2 = always 8 bytes
     unsigned g2_coop = 0;               // G2 only: the accumulation with one Fp2 component per wave (msm_g2c_kernels.hpp): 0 = for the 14-limb base fields, 1 = always, 2 = never
     size_t resident_lanes = 0;          // lanes of k_accumulate the device holds at once (set by the driver from the occupancy query; 0 = unknown)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
@@ -119,6 +123,17 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.nslabs = t.nslabs ? t.nslabs
              : (unsigned)std::min<size_t>(64, std::max<size_t>(npoints / 131072, std::min<size_t>(8, std::max<size_t>(1, npoints / 2048))));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
+    // 4-byte level-A records: sign | index mod 2^IB | k_lo, IB = 31 - LB; the index bits above IB follow from the position of
+    // a record in its partition, which needs slabs of a power of two <= 2^IB points (so that an index group is a whole
+    // number of slabs) and at most 128 groups.  Not with an explicit slab count (the tunable means what it says).
+    p.IB = p.SH = 0; p.NG = 1;
+    if (t.pack != 2 && !t.nslabs && p.LB < 16) {
+        const unsigned IB = 31 - p.LB;
+        unsigned lgs = lg2_floor(p.slab_sz) + ((p.slab_sz & (p.slab_sz - 1)) ? 1 : 0);
+        lgs = std::min(lgs, IB);
+        const size_t ss = (size_t)1 << lgs, ns = (npoints + ss - 1) / ss, ng = (((ns ? ns : 1) - 1) >> (IB - lgs)) + 1;
+        if (ng <= 128 && ns <= 4096) { p.slab_sz = (unsigned)ss; p.nslabs = (unsigned)std::max<size_t>(1, ns); p.IB = IB; p.SH = IB - lgs; p.NG = (unsigned)ng; }
+    }
     // fan-in of the record tree (< 3 would never shrink the list): 4 up to 2^20 points, where the buckets are longer
     // than the join's walk and the tree does the work -- one addition per work item and level instead of three
     // (above 2^18 the join leaves the tree nothing to do and every level is an empty launch of ~6 us: fewer, wider ones)
@@ -177,6 +192,7 @@ static inline msm_plan make_fixed_plan(size_t n, unsigned fb_wbits, unsigned fb_
     // partitions are ALL of one size class here, and one work-group walking 50..300 K entries twice is the slower way
     // (2^25 points: digits + sort 9.1 -> 6.4 ms, 2^24: 4.2 -> 3.3 ms)
     p.big = register_stage;
+    p.IB = p.SH = 0; p.NG = 1;          // 8-byte level-A records (the entry index is fb_nwins x the point index)
     return p;
 }
 

@@ -17,6 +17,7 @@
 // grid-synchronised passes sized for <= 32 blocks (msm/sort.cuh:120-357).
 #pragma once
 #include "../ff/mont_dev.hpp"
+#include "msm_sort_records.hpp"
 
 namespace sppark_amd {
 
@@ -129,11 +130,12 @@ void k_scan_parts(u32* __restrict__ offA, const u32* __restrict__ tot, unsigned 
     if (tid == 1023) o[NA] = part[1023];
 }
 
-// level-A scatter: partA[w*n + pos] = { point index | sign<<31, k_lo }
+// level-A scatter: partA[w*n + pos] = the record of (point index, sign, k_lo)
+template<bool PK>
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(SORT_VGPRS)))
-void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
+void k_scatterA(typename recA<PK>::type* __restrict__ partA, const u32* __restrict__ digits,
                 const u32* __restrict__ H, const u32* __restrict__ offA,
-                unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from)
+                unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from, unsigned IB)
 {
     extern __shared__ u32 lds_cur[];
     const unsigned slab = blockIdx.x, w = blockIdx.y, LB = window_lb(LBL, w, short_from);
@@ -144,7 +146,7 @@ void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
 
     const unsigned lo = slab * slab_sz, hi = min(n, lo + slab_sz);
     const u32* dig = digits + (size_t)w * n;
-    uint2* dst = partA + (size_t)w * n;
+    typename recA<PK>::type* dst = partA + (size_t)w * n;
     const u32 lomask = (1u << LB) - 1;
     for (unsigned i = lo + threadIdx.x; i < hi; i += 4 * blockDim.x) {
         u32 d[4];
@@ -155,7 +157,7 @@ void k_scatterA(uint2* __restrict__ partA, const u32* __restrict__ digits,
             if (d[u]) {
                 u32 k = (d[u] & 0x7fffffffu) - 1;
                 u32 pos = atomicAdd(&lds_cur[k >> LB], 1u);
-                dst[pos] = make_uint2((i + u * blockDim.x) | (d[u] & 0x80000000u), k & lomask);
+                dst[pos] = recA<PK>::make((i + u * blockDim.x) | (d[u] & 0x80000000u), k & lomask, LBL, IB);
             }
         }
     }
@@ -187,10 +189,11 @@ SPPARK_DEVFN void lds_barrier()
 #endif
 }
 
+template<bool PK>
 __global__ __launch_bounds__(SORT_NT)
-void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits,
+void k_scatterA_staged(typename recA<PK>::type* __restrict__ partA, const u32* __restrict__ digits,
                        const u32* __restrict__ H, const u32* __restrict__ offA,
-                       unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from)
+                       unsigned n, unsigned nslabs, unsigned slab_sz, unsigned NA, unsigned LBL, unsigned short_from, unsigned IB)
 {
     extern __shared__ u32 lds_sa[];
     constexpr unsigned NT = SORT_NT;
@@ -208,7 +211,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
 
     const unsigned lo = slab * slab_sz, hi = min(n, lo + slab_sz);
     const u32* dig = digits + (size_t)w * n;
-    uint2* dst = partA + (size_t)w * n;
+    typename recA<PK>::type* dst = partA + (size_t)w * n;
     const u32 lomask = (1u << LB) - 1;
     u32 d[SCATA_PER], dn[SCATA_PER];
     #pragma unroll
@@ -261,7 +264,7 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
         #pragma unroll
         for (int u = 0; u < SCATA_PER; u++) {
             unsigned e = u * NT + tid;
-            if (e < total) { uint2 v = stage[e]; dst[G[v.y >> 16] + e] = make_uint2(v.x, v.y & 0xffffu); }
+            if (e < total) { uint2 v = stage[e]; dst[G[v.y >> 16] + e] = recA<PK>::make(v.x, v.y & 0xffffu, LBL, IB); }
         }
         lds_barrier();
     }
@@ -270,22 +273,26 @@ void k_scatterA_staged(uint2* __restrict__ partA, const u32* __restrict__ digits
 // level B: block (k_hi, w) groups its partition by k_lo.
 //   off[w*(NB+1) + k_hi*2^LB + j] = first position of bucket (k_hi, j) in window w's list
 //   sorted[w*n + pos] = point index | sign<<31
+template<bool PK>
 __global__ __launch_bounds__(SORT_NT) __attribute__((amdgpu_num_vgpr(64)))
-void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __restrict__ partA,
-             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LBL, unsigned short_from, unsigned big)
+void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const typename recA<PK>::type* __restrict__ partA,
+             const u32* __restrict__ offA, unsigned n, unsigned NA, unsigned LBL, unsigned short_from, unsigned big, partA_fmt fmt)
 {
-    extern __shared__ u32 lds[];            // 2^LB counters, SORT_NT scan words, SORTB_STAGE staged entries
+    extern __shared__ u32 lds[];            // 2^LB counters, SORT_NT scan words, SORTB_STAGE staged entries, the group boundaries
+    typedef typename recA<PK>::type rec_t;
     constexpr unsigned NT = SORT_NT;
     const unsigned LB = window_lb(LBL, blockIdx.y, short_from);
     const size_t NB = (size_t)NA << LBL;    // buckets per window (stride of off[]); this window uses NA << LB of them
     const unsigned NL = 1u << LB;
+    const u32 kmask = (1u << LBL) - 1;
     u32* cnt = lds;
     u32* part = lds + NL;
     u32* stage = part + NT;
+    u32* bnd = stage + SORTB_STAGE;
     const unsigned khi = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
     const u32* oA = offA + (size_t)w * (NA + 1);
     const unsigned begin = oA[khi], end = oA[khi + 1];
-    const uint2* src = partA + (size_t)w * n;
+    const rec_t* src = partA + (size_t)w * n;
     if (end - begin > big) {                // oversized partition: the cooperative kernels below sort it
         if (khi == NA - 1 && tid == 0) off[(size_t)w * (NB + 1) + NB] = end;
         if (LB != LBL) for (unsigned b = tid; b < NL; b += NT) off[(size_t)w * (NB + 1) + ((size_t)(NA + khi) << LB) + b] = oA[NA];
@@ -295,25 +302,25 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     if (LB != LBL) for (unsigned b = tid; b < NL; b += NT) off[(size_t)w * (NB + 1) + ((size_t)(NA + khi) << LB) + b] = oA[NA];
 
     const bool in_regs = end - begin <= SORTB_STAGE;        // uniform over the work-group
-    u32 rx[SORTB_PER], rk[SORTB_PER];
+    rec_t rr[SORTB_PER];
     for (unsigned b = tid; b < NL; b += NT) cnt[b] = 0;
+    if (PK) partA_bounds(bnd, fmt, w, khi, NA, tid);
     __syncthreads();
     if (in_regs) {
         #pragma unroll
         for (int u = 0; u < SORTB_PER; u++) {
             unsigned j = begin + tid + u * NT;
-            uint2 v = j < end ? src[j] : make_uint2(0, 0xffffffffu);
-            rx[u] = v.x; rk[u] = v.y;
+            if (j < end) rr[u] = src[j];
         }
         #pragma unroll
-        for (int u = 0; u < SORTB_PER; u++) if (rk[u] != 0xffffffffu) atomicAdd(&cnt[rk[u]], 1u);
+        for (int u = 0; u < SORTB_PER; u++) if (begin + tid + u * NT < end) atomicAdd(&cnt[recA<PK>::key(rr[u], kmask)], 1u);
     } else {
         for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
-            u32 k[SORTB_UNROLL];
+            rec_t r[SORTB_UNROLL];
             #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; k[u] = j < end ? src[j].y : 0xffffffffu; }
+            for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; if (j < end) r[u] = src[j]; }
             #pragma unroll
-            for (int u = 0; u < SORTB_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&cnt[k[u]], 1u);
+            for (int u = 0; u < SORTB_UNROLL; u++) if (i + u * NT < end) atomicAdd(&cnt[recA<PK>::key(r[u], kmask)], 1u);
         }
     }
     __syncthreads();
@@ -336,20 +343,21 @@ void k_sortB(u32* __restrict__ sorted, u32* __restrict__ off, const uint2* __res
     if (in_regs) {
         #pragma unroll
         for (int u = 0; u < SORTB_PER; u++)
-            if (rk[u] != 0xffffffffu) stage[atomicAdd(&cnt[rk[u]], 1u) - begin] = rx[u];
+            if (begin + tid + u * NT < end)
+                stage[atomicAdd(&cnt[recA<PK>::key(rr[u], kmask)], 1u) - begin] = recA<PK>::entry(rr[u], tid + u * NT, LBL, fmt, bnd);
         __syncthreads();
         for (unsigned i = tid; i < end - begin; i += NT) dst[begin + i] = stage[i];
         return;
     }
     for (unsigned i = begin + tid; i < end; i += SORTB_UNROLL * NT) {
-        uint2 r[SORTB_UNROLL];
+        rec_t r[SORTB_UNROLL];
         #pragma unroll
-        for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; r[u] = j < end ? src[j] : make_uint2(0, 0xffffffffu); }
+        for (int u = 0; u < SORTB_UNROLL; u++) { unsigned j = i + u * NT; if (j < end) r[u] = src[j]; }
         #pragma unroll
         for (int u = 0; u < SORTB_UNROLL; u++) {
-            if (r[u].y != 0xffffffffu) {
-                u32 pos = atomicAdd(&cnt[r[u].y], 1u);
-                dst[pos] = r[u].x;
+            if (i + u * NT < end) {
+                u32 pos = atomicAdd(&cnt[recA<PK>::key(r[u], kmask)], 1u);
+                dst[pos] = recA<PK>::entry(r[u], i + u * NT - begin, LBL, fmt, bnd);
             }
         }
     }
@@ -396,36 +404,39 @@ void k_big_find(u32* __restrict__ nbig, u32* __restrict__ list, u32* __restrict_
 
 // slice s of listed partition b; returns false when the work item does not exist
 __device__ inline bool big_slice(const u32* nbig, const u32* list, const u32* offA, unsigned NA, unsigned item, unsigned split,
-                                 unsigned& w, unsigned& khi, unsigned& lo, unsigned& hi)
+                                 unsigned& w, unsigned& khi, unsigned& lo, unsigned& hi, unsigned& begin)
 {
     const unsigned b = item / split, s = item % split;
     if (b >= *nbig) return false;
     w = list[b] / NA; khi = list[b] % NA;
     const u32* oA = offA + (size_t)w * (NA + 1);
-    const unsigned begin = oA[khi], end = oA[khi + 1];
+    begin = oA[khi];
+    const unsigned end = oA[khi + 1];
     const unsigned per = (end - begin + split - 1) / split;
     lo = min(end, begin + s * per); hi = min(end, lo + per);
     return true;
 }
 
+template<bool PK>
 __global__ __launch_bounds__(1024)
-void k_big_hist(u32* __restrict__ off, const uint2* __restrict__ partA, const u32* __restrict__ offA,
+void k_big_hist(u32* __restrict__ off, const typename recA<PK>::type* __restrict__ partA, const u32* __restrict__ offA,
                 const u32* __restrict__ nbig, const u32* __restrict__ list, unsigned n, unsigned NA, unsigned LBL, unsigned short_from,
                 unsigned split)
 {
     extern __shared__ u32 lds[];
     const unsigned tid = threadIdx.x;
+    const u32 kmask = (1u << LBL) - 1;
     for (unsigned item = blockIdx.x; ; item += gridDim.x) {
-        unsigned w, khi, lo, hi;
-        if (!big_slice(nbig, list, offA, NA, item, split, w, khi, lo, hi)) return;
+        unsigned w, khi, lo, hi, begin;
+        if (!big_slice(nbig, list, offA, NA, item, split, w, khi, lo, hi, begin)) return;
         const unsigned LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
         __syncthreads();
-        const uint2* src = partA + (size_t)w * n;
+        const typename recA<PK>::type* src = partA + (size_t)w * n;
         for (unsigned i = lo + tid; i < hi; i += BIG_UNROLL * 1024) {
             u32 k[BIG_UNROLL];
             #pragma unroll
-            for (int u = 0; u < BIG_UNROLL; u++) { unsigned j = i + u * 1024; k[u] = j < hi ? src[j].y : 0xffffffffu; }
+            for (int u = 0; u < BIG_UNROLL; u++) { unsigned j = i + u * 1024; k[u] = j < hi ? recA<PK>::key(src[j], kmask) : 0xffffffffu; }
             #pragma unroll
             for (int u = 0; u < BIG_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&lds[k[u]], 1u);
         }
@@ -470,34 +481,39 @@ void k_big_scan(u32* __restrict__ off, u32* __restrict__ cur, const u32* __restr
 // + 16 scan words + BIG_STAGE (index, destination) pairs.
 static constexpr int BIG_PER = 8;
 static constexpr unsigned BIG_STAGE = BIG_PER * 1024;
-static inline size_t big_scatter_lds(unsigned LB) { return ((size_t)2 << LB) * 4 + 64 + (size_t)BIG_STAGE * 8; }
+static inline size_t big_scatter_lds(unsigned LB) { return ((size_t)2 << LB) * 4 + 64 + (size_t)BIG_STAGE * 8 + PARTA_MAX_GROUPS * 4; }
 
+template<bool PK>
 __global__ __launch_bounds__(1024)
-void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2* __restrict__ partA,
+void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const typename recA<PK>::type* __restrict__ partA,
                    const u32* __restrict__ offA, const u32* __restrict__ nbig, const u32* __restrict__ list,
-                   unsigned n, unsigned NA, unsigned LBL, unsigned short_from, unsigned split)
+                   unsigned n, unsigned NA, unsigned LBL, unsigned short_from, unsigned split, partA_fmt fmt)
 {
     extern __shared__ u32 lds[];
+    typedef typename recA<PK>::type rec_t;
     const unsigned tid = threadIdx.x;
+    const u32 kmask = (1u << LBL) - 1;
     u32* const gdl = lds + ((size_t)1 << LBL);              // (global - local) start of the slice's run of bucket j
     u32* const wsum = gdl + ((size_t)1 << LBL);
     u32* const st_idx = wsum + 16;
     u32* const st_dst = st_idx + BIG_STAGE;
+    u32* const bnd = st_dst + BIG_STAGE;                    // the index-group boundaries of the slice's partition
     for (unsigned item = blockIdx.x; ; item += gridDim.x) {
-        unsigned w, khi, lo, hi;
-        if (!big_slice(nbig, list, offA, NA, item, split, w, khi, lo, hi)) return;
+        unsigned w, khi, lo, hi, begin;
+        if (!big_slice(nbig, list, offA, NA, item, split, w, khi, lo, hi, begin)) return;
         const unsigned LB = window_lb(LBL, w, short_from), NL = 1u << LB;
         for (unsigned j = tid; j < NL; j += 1024) lds[j] = 0;
+        if (PK) partA_bounds(bnd, fmt, w, khi, NA, tid);
         __syncthreads();
-        const uint2* src = partA + (size_t)w * n;
+        const rec_t* src = partA + (size_t)w * n;
         u32* c = cur + (size_t)w * (((size_t)NA << LBL) + 1) + ((size_t)khi << LB);
         u32* dst = sorted + (size_t)w * n;
         if (hi - lo <= BIG_STAGE) {                         // uniform over the work-group
-            uint2 r[BIG_PER];
+            rec_t r[BIG_PER];
             #pragma unroll
-            for (int u = 0; u < BIG_PER; u++) { unsigned jx = lo + u * 1024 + tid; r[u] = jx < hi ? src[jx] : make_uint2(0, 0xffffffffu); }
+            for (int u = 0; u < BIG_PER; u++) { unsigned jx = lo + u * 1024 + tid; if (jx < hi) r[u] = src[jx]; }
             #pragma unroll
-            for (int u = 0; u < BIG_PER; u++) if (r[u].y != 0xffffffffu) atomicAdd(&lds[r[u].y], 1u);
+            for (int u = 0; u < BIG_PER; u++) if (lo + u * 1024 + tid < hi) atomicAdd(&lds[recA<PK>::key(r[u], kmask)], 1u);
             __syncthreads();
             // local exclusive scan of the bucket counts; one global reservation per occupied bucket
             const unsigned per = (NL + 1023) / 1024, b0 = min(NL, tid * per), b1 = min(NL, b0 + per);
@@ -515,9 +531,9 @@ void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2*
             __syncthreads();
             #pragma unroll
             for (int u = 0; u < BIG_PER; u++)
-                if (r[u].y != 0xffffffffu) {
-                    const u32 pos = atomicAdd(&lds[r[u].y], 1u);
-                    st_idx[pos] = r[u].x; st_dst[pos] = pos + gdl[r[u].y];
+                if (lo + u * 1024 + tid < hi) {
+                    const u32 k = recA<PK>::key(r[u], kmask), pos = atomicAdd(&lds[k], 1u);
+                    st_idx[pos] = recA<PK>::entry(r[u], lo + u * 1024 + tid - begin, LBL, fmt, bnd); st_dst[pos] = pos + gdl[k];
                 }
             __syncthreads();
             for (unsigned i = tid; i < hi - lo; i += 1024) dst[st_dst[i]] = st_idx[i];
@@ -527,7 +543,7 @@ void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2*
         for (unsigned i = lo + tid; i < hi; i += BIG_UNROLL * 1024) {
             u32 k[BIG_UNROLL];
             #pragma unroll
-            for (int u = 0; u < BIG_UNROLL; u++) { unsigned jx = i + u * 1024; k[u] = jx < hi ? src[jx].y : 0xffffffffu; }
+            for (int u = 0; u < BIG_UNROLL; u++) { unsigned jx = i + u * 1024; k[u] = jx < hi ? recA<PK>::key(src[jx], kmask) : 0xffffffffu; }
             #pragma unroll
             for (int u = 0; u < BIG_UNROLL; u++) if (k[u] != 0xffffffffu) atomicAdd(&lds[k[u]], 1u);
         }
@@ -535,11 +551,12 @@ void k_big_scatter(u32* __restrict__ sorted, u32* __restrict__ cur, const uint2*
         for (unsigned jx = tid; jx < NL; jx += 1024) if (lds[jx]) lds[jx] = atomicAdd(&c[jx], lds[jx]);   // reserve a range
         __syncthreads();
         for (unsigned i = lo + tid; i < hi; i += BIG_UNROLL * 1024) {
-            uint2 r[BIG_UNROLL];
+            rec_t r[BIG_UNROLL];
             #pragma unroll
-            for (int u = 0; u < BIG_UNROLL; u++) { unsigned jx = i + u * 1024; r[u] = jx < hi ? src[jx] : make_uint2(0, 0xffffffffu); }
+            for (int u = 0; u < BIG_UNROLL; u++) { unsigned jx = i + u * 1024; if (jx < hi) r[u] = src[jx]; }
             #pragma unroll
-            for (int u = 0; u < BIG_UNROLL; u++) if (r[u].y != 0xffffffffu) dst[atomicAdd(&lds[r[u].y], 1u)] = r[u].x;
+            for (int u = 0; u < BIG_UNROLL; u++)
+                if (i + u * 1024 < hi) dst[atomicAdd(&lds[recA<PK>::key(r[u], kmask)], 1u)] = recA<PK>::entry(r[u], i + u * 1024 - begin, LBL, fmt, bnd);
         }
         __syncthreads();
     }

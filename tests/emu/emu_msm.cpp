@@ -25,6 +25,7 @@
 #define SPPARK_HOST_EMULATION 1
 #include "../../sppark_amd/csrc/msm/curve_select.hpp"
 #include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
+#include "../../sppark_amd/csrc/msm/msm_sort_records.hpp"
 #include "../../sppark_amd/csrc/ec/jacobian_host.hpp"
 #include "../../sppark_amd/csrc/ff/fp2_host.hpp"
 #ifdef SPPARK_G2
@@ -73,7 +74,7 @@ extern "C" int sppark_emu_barrier_or(int v) { return g_bar.wait(v); }
 extern "C" void emu_g2c(int on) { g_g2c = on; }
 
 // plan/tunables only (no HIP runtime needed)
-struct msm_plan { unsigned n, wbits, nwins, nbits, NB, HB, LB, NA, L, chunks_per_win, nslabs, slab_sz, F, K; };
+struct msm_plan { unsigned n, wbits, nwins, nbits, NB, HB, LB, NA, L, chunks_per_win, nslabs, slab_sz, F, K, IB, SH, NG; };
 
 static unsigned lg2_floor(size_t x) { unsigned r = 0; while (x >>= 1) r++; return r; }
 
@@ -171,6 +172,9 @@ static void finalize_sum(M* out, const xyzz_mem<F::N>* in)
     else memcpy(out, in, sizeof(*out));
 }
 
+static unsigned g_pack = 0;
+extern "C" void emu_msm_pack(unsigned mode) { g_pack = mode; }       // 0: 8-byte level-A records
+
 extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                        const unsigned char* scalars, int mont,
                        unsigned wbits, unsigned L, unsigned F, unsigned K, unsigned nslabs, int join, unsigned* join_stats,
@@ -199,6 +203,16 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     p.chunks_per_win = (p.n + p.L - 1) / p.L;
     p.nslabs = nslabs ? nslabs : (unsigned)std::min<size_t>(64, std::max<size_t>(1, npoints / 262144));
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
+    // 4-byte level-A records (msm_plan.hpp: IB = 31 - LB, groups of 2^SH slabs).  Here with the SMALLEST index field the slabs
+    // allow, so that a few hundred points already spread over several index groups: g_pack = 1: every slab is a group,
+    // 2: every pair of slabs
+    p.IB = p.SH = 0; p.NG = 1;
+    if (g_pack) {
+        unsigned lgs = 0; while ((1u << lgs) < p.slab_sz) lgs++;
+        p.slab_sz = 1u << lgs; p.nslabs = (p.n + p.slab_sz - 1) / p.slab_sz;
+        p.SH = g_pack - 1; p.IB = lgs + p.SH; p.NG = ((p.nslabs - 1) >> p.SH) + 1;
+        if (p.IB + p.LB > 31 || p.NG > PARTA_MAX_GROUPS) return -7;
+    }
     p.F = std::max(4u, F ? F : 32u);
     p.K = std::min(K ? K : 8u, p.NB);
     const bool flagged = stride > 2 * sizeof(fp_h);
@@ -218,7 +232,14 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     // ---- two-level counting sort (translation of msm_sort_kernels.hpp) ----
     std::vector<u32> H((size_t)p.nwins * p.nslabs * p.NA, 0), tot((size_t)p.nwins * p.NA), offA((size_t)p.nwins * (p.NA + 1));
     std::vector<u32> off((size_t)p.nwins * (p.NB + 1));
+    // level-A records through the product's own pack / unpack (msm_sort_records.hpp): 4 bytes where the plan says so, the
+    // index bits above IB recovered from the record's position in its partition
     std::vector<uint2> partA((size_t)p.nwins * p.n);
+    std::vector<u32> partP((size_t)p.nwins * p.n);
+    const bool packed = p.IB != 0;
+    unsigned ngp = 1; while (ngp < p.NG) ngp <<= 1;
+    if (ngp > PARTA_MAX_GROUPS) return -7;
+    const partA_fmt fmt{H.data(), p.IB, p.SH, ngp, p.nslabs};
     const u32 lomask = (1u << p.LB) - 1;
     for (unsigned w = 0; w < p.nwins; w++)                              // k_histA
         for (unsigned slab = 0; slab < p.nslabs; slab++) {
@@ -243,18 +264,27 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
             unsigned lo = slab * p.slab_sz, hi = std::min(p.n, lo + p.slab_sz);
             for (unsigned i = hi; i-- > lo;) {                          // reverse: any order inside a partition must work
                 u32 d = digits[(size_t)w * p.n + i];
-                if (d) { u32 k = (d & 0x7fffffffu) - 1; partA[(size_t)w * p.n + cur[k >> p.LB]++] = make_uint2(i | (d & 0x80000000u), k & lomask); }
+                if (d) {
+                    u32 k = (d & 0x7fffffffu) - 1; const size_t at = (size_t)w * p.n + cur[k >> p.LB]++;
+                    if (packed) partP[at] = recA<true>::make(i | (d & 0x80000000u), k & lomask, p.LB, p.IB);
+                    else        partA[at] = recA<false>::make(i | (d & 0x80000000u), k & lomask, p.LB, p.IB);
+                }
             }
         }
     for (unsigned w = 0; w < p.nwins; w++)                              // k_sortB
         for (unsigned khi = 0; khi < p.NA; khi++) {
             unsigned begin = offA[(size_t)w * (p.NA + 1) + khi], end = offA[(size_t)w * (p.NA + 1) + khi + 1];
             std::vector<u32> cnt(1u << p.LB, 0);
-            for (unsigned i = begin; i < end; i++) cnt[partA[(size_t)w * p.n + i].y]++;
+            u32 bnd[PARTA_MAX_GROUPS];
+            if (packed) for (unsigned t = 0; t < ngp; t++) partA_bounds(bnd, fmt, w, khi, p.NA, t);
+            auto key = [&](unsigned i) { return packed ? recA<true>::key(partP[(size_t)w * p.n + i], lomask) : recA<false>::key(partA[(size_t)w * p.n + i], lomask); };
+            auto ent = [&](unsigned i) { return packed ? recA<true>::entry(partP[(size_t)w * p.n + i], i - begin, p.LB, fmt, bnd)
+                                                       : recA<false>::entry(partA[(size_t)w * p.n + i], i - begin, p.LB, fmt, bnd); };
+            for (unsigned i = begin; i < end; i++) cnt[key(i)]++;
             u32 run = begin;
             for (unsigned b = 0; b < (1u << p.LB); b++) { u32 c = cnt[b]; cnt[b] = run; off[(size_t)w * (p.NB + 1) + ((size_t)khi << p.LB) + b] = run; run += c; }
             if (khi == p.NA - 1) off[(size_t)w * (p.NB + 1) + p.NB] = end;
-            for (unsigned i = end; i-- > begin;) { uint2 r = partA[(size_t)w * p.n + i]; sorted[(size_t)w * p.n + cnt[r.y]++] = r.x; }
+            for (unsigned i = end; i-- > begin;) sorted[(size_t)w * p.n + cnt[key(i)]++] = ent(i);
         }
 
     // ---- accumulate + record levels ----

@@ -85,6 +85,38 @@ def test_msm_pipeline_on_host(oracle, curve):
         assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (n, wb, LL, F, K, ns)
 
 
+def test_msm_pipeline_with_packed_sort_records_on_host(oracle):
+    """Level-A sort records of 4 bytes (sign | index mod 2^IB | k_lo; csrc/msm/msm_sort_records.hpp): the index bits above IB
+    are not stored, level B finds them from the POSITION of a record in its partition (the records lie in slab order; a
+    binary search over the index groups' first positions).  The pipeline packs and unpacks with the product's own code, with
+    an index field so short that a few hundred points spread over up to 8 index groups (every slab, resp. every pair of
+    slabs, is one): skewed scalars leave groups EMPTY in a partition (equal boundaries), a ragged size a short last slab."""
+    O = oracle
+    curve = 1
+    L = _emu("BN254")
+    L.emu_msm_pack.argtypes = [ctypes.c_uint]; L.emu_msm_pack.restype = None
+    fb = O.FP_BYTES[curve]
+    try:
+        for mode in (1, 2):
+            L.emu_msm_pack(mode)
+            for n, wb, LL, F, K, ns in ((1, 0, 0, 0, 0, 0), (33, 0, 0, 0, 0, 3), (1000, 7, 4, 4, 2, 7), (700, 9, 16, 8, 4, 5),
+                                        (2048, 10, 8, 32, 8, 8), (300, 2, 4, 4, 2, 4), (500, 19, 8, 8, 8, 6)):
+                pts, sc = recipe.msm_inputs(curve, n, 99 + n + wb, flagged=True)
+                out = np.zeros(3 * fb, dtype=np.uint8)
+                assert L.emu_msm(P(out), P(pts), pts.shape[1], n, P(sc), 0, wb, LL, F, K, ns, 1, None, 0) == 0
+                assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, sc, algo=0, param=4)).all(), (mode, n, wb, ns)
+            # all scalars equal: one bucket per window holds everything; and half of the scalars zero
+            pts, sc = recipe.msm_inputs(curve, 600, 7, edge=False, flagged=True)
+            s_eq = sc.copy(); s_eq[:] = sc[0]
+            s_half = sc.copy(); s_half[::2] = 0
+            for s_ in (s_eq, s_half):
+                out = np.zeros(3 * fb, dtype=np.uint8)
+                assert L.emu_msm(P(out), P(pts), pts.shape[1], 600, P(s_), 0, 8, 8, 4, 4, 6, 1, None, 0) == 0
+                assert (O.jac_to_affine(curve, out) == O.msm_affine(curve, pts, s_, algo=0, param=4)).all(), mode
+    finally:
+        L.emu_msm_pack(0)
+
+
 @pytest.mark.parametrize("curve", [2, 3, 5])
 def test_msm_g2_pipeline_on_host(oracle, curve):
     """the same kernel bodies instantiated over Fp2 (ff/fp2x_dev.hpp + ec/xyzzx2_dev.hpp: the loosely-reduced

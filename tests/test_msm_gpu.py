@@ -718,6 +718,30 @@ def test_msm_sort_partition_paths(oracle, libs):
     ctx.close()
 
 
+def test_msm_packed_sort_records_index_groups(oracle, libs):
+    """4-byte level-A sort records (csrc/msm/msm_sort_records.hpp): the index bits above IB = 31 - LB are not stored, level B
+    finds them from the position of a record in its partition.  With the widest k_lo (LB = 13: 18 index bits) 600 000
+    points are three index groups, in every form of level B: the register path (2^8 partitions of ~2300 entries), the
+    two-pass path (2^3 partitions of ~75 000), the cooperative kernels (most scalars equal: one partition holds nearly the
+    whole window; staged slices and, with the threshold at 30 000, direct ones) -- against the oracle, and the same calls
+    with 8-byte records (an explicit slab count keeps them)."""
+    import sppark_amd
+    O = oracle
+    n = 600000
+    pts, sc = recipe.msm_inputs(O.BLS12_381, n, 7171, ndistinct=500, flagged=False)
+    s_mix = sc.copy(); s_mix[3000: n - 40000] = sc[0]           # uniform at both ends, 557 000 equal scalars between
+    s_half = sc.copy(); s_half[::2] = 0                         # zero digits: records thin out, the groups' first positions move
+    ctx = sppark_amd.MsmContext("bls12_381")
+    for s_ in (sc, s_mix, s_half):
+        exp = O.msm_affine(O.BLS12_381, pts, s_, algo=0, param=8)
+        for wb, lb, big in ((22, 13, 0), (17, 13, 0), (17, 13, 30000), (0, 0, 0)):
+            ctx.tune_split(big); ctx.tune_sort(lb)
+            for ns in (0, 5):                                   # 0: the automatic slabs, 4-byte records; explicit: 8-byte records
+                ctx.tune(wbits=wb, nslabs=ns)
+                assert (sppark_amd.to_affine(ctx.invoke(pts, s_, ffi_affine_sz=96)) == exp).all(), (wb, lb, big, ns)
+    ctx.close()
+
+
 @pytest.mark.parametrize("curve,name", CURVES)
 def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     """BASELINE size (2^26 points; configs[2] BLS12-381 G1 and configs[4] alt_bn128 G1) against the

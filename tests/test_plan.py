@@ -8,7 +8,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "emu")
-KEYS = ("n", "wbits", "nwins", "NB", "nbits", "HB", "LB", "NA", "L", "chunks_per_win", "nslabs", "slab_sz", "F", "K", "K1", "G", "wpg", "big")
+KEYS = ("n", "wbits", "nwins", "NB", "nbits", "HB", "LB", "NA", "L", "chunks_per_win", "nslabs", "slab_sz", "F", "K", "K1", "G", "wpg", "big", "IB", "SH", "NG")
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +25,7 @@ def plan_lib():
 
 
 def _plan(lib, n, bits=255, **kw):
-    out = (ctypes.c_uint * 18)()
+    out = (ctypes.c_uint * 21)()
     lib.emu_make_plan(n, bits, kw.get("wbits", 0), kw.get("L", 0), kw.get("F", 0), kw.get("K", 0), kw.get("nslabs", 0),
                     kw.get("LB", 0), kw.get("groups", 0), kw.get("K1", 0), out)
     return dict(zip(KEYS, out))
@@ -41,6 +41,14 @@ def _check(p, n, bits):
     assert p["LB"] <= 13 and p["HB"] <= 15                                            # LDS counters of level B / of the level-A histogram
     assert p["L"] >= 1 and p["chunks_per_win"] * p["L"] >= n > (p["chunks_per_win"] - 1) * p["L"]
     assert p["nslabs"] >= 1 and p["slab_sz"] * p["nslabs"] >= n
+    # 4-byte level-A records (msm_sort_records.hpp): sign | index mod 2^IB | k_lo fills 32 bits; an index group is a whole
+    # number (2^SH) of power-of-two slabs; every index is below NG groups; level B keeps at most 128 boundaries; no empty slab
+    if p["IB"]:
+        assert p["IB"] + p["LB"] == 31 and p["slab_sz"] & (p["slab_sz"] - 1) == 0 and p["slab_sz"] << p["SH"] == 1 << p["IB"]
+        assert p["NG"] == ((p["nslabs"] - 1) >> p["SH"]) + 1 and 1 <= p["NG"] <= 128 and n <= p["NG"] << p["IB"]
+        assert (p["nslabs"] - 1) * p["slab_sz"] < n and p["nslabs"] <= 4096
+    else:
+        assert p["SH"] == 0 and p["NG"] == 1
     assert p["F"] >= 4                                                                # (< 3 would never shrink the record list)
     for k in ("K", "K1"):
         assert p[k] >= 1 and p[k] & (p[k] - 1) == 0 and p[k] <= p["NB"] and p["NB"] % p[k] == 0
@@ -69,7 +77,7 @@ def test_run_length_fits_whole_rounds_of_resident_waves(plan_lib):
         for bits in (255, 254):
             for lg in range(12, 29):
                 for n in {1 << lg, (1 << lg) + 1, (1 << lg) * 3 // 2 + 7, (1 << lg) - 1, (1 << lg) * 5 // 4}:
-                    out = (ctypes.c_uint * 18)()
+                    out = (ctypes.c_uint * 21)()
                     plan_lib.emu_make_plan_resident(n, bits, R, out)
                     p = dict(zip(KEYS, out))
                     _check(p, n, bits)
@@ -84,7 +92,7 @@ def test_run_length_fits_whole_rounds_of_resident_waves(plan_lib):
                         assert groups(p) <= rounds(p) * (R // 256), (n, R, p)
                         if p["L"] > 4:                                                # ... tightly: one entry less per run would not fit
                             assert p["nwins"] * -(-(-(-n // (p["L"] - 1))) // 256) > rounds(p) * (R // 256), (n, R, p)
-    out = (ctypes.c_uint * 18)()
+    out = (ctypes.c_uint * 21)()
     for n, L in ((1 << 17, 20), (1 << 18, 35), (300000, 40), (1 << 22, 128), (12000000, 129), (1 << 13, 8), (1 << 16, 16), (1 << 20, 64), (1 << 26, 256)):
         plan_lib.emu_make_plan_resident(n, 255, 131072, out)
         assert dict(zip(KEYS, out))["L"] == L, (n, dict(zip(KEYS, out)))
@@ -111,7 +119,7 @@ def test_fixed_base_plans(plan_lib):
                 n = (1 << lgn) + (lgn % 3)
                 if W * n >= 1 << 31:
                     continue
-                out = (ctypes.c_uint * 18)()
+                out = (ctypes.c_uint * 21)()
                 plan_lib.emu_make_fixed_plan(n, cc, W, STAGE, out)
                 p = dict(zip(KEYS, out))
                 assert p["n"] == W * n and p["nwins"] == 1 and p["wbits"] == cc and p["NB"] == 1 << (cc - 1)

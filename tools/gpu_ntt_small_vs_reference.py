@@ -26,6 +26,15 @@ torch.cuda.set_stream(torch.cuda.Stream())
 stream = torch.cuda.current_stream().cuda_stream
 order = int(args.get("order", 1))
 behind = []
+# warm-up: the first ~10 ms of synchronous calls of a process run at about half speed on these boxes (whichever library makes
+# them: the first row of every earlier log shows 27 us where every later row shows 14); 1500 untimed calls of either side first
+_w = torch.zeros(256, dtype=torch.int64, device="cuda")
+for _ in range(1500):
+    ffi.load("gl64").sppark_ntt(0, ctypes.c_void_p(_w.data_ptr()), 8, 1, 0, 0, None)
+if args.get("only", "ref") == "ref":
+    for _ in range(1500):
+        O.ref_ntt_lib("gl64").ref_ntt_dev(ctypes.c_void_p(_w.data_ptr()), 8, 1, 0, 0)
+torch.cuda.synchronize()
 for field, dt, eb in (("gl64", torch.int64, 8), ("bb31", torch.int32, 4), ("bls12_381", torch.int64, 32), ("bn254", torch.int64, 32)):
     if field not in args.get("fields", args.get("field", field)).split(","):
         continue

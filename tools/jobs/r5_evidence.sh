@@ -37,5 +37,8 @@ timeout 600 python tools/gpu_msm_fixed.py 22:20 24 26 > $R/gpurun_out/r5e_msm_fi
 for lg in 26 24 22 20 16; do timeout 200 python tools/gpu_msm_bn254.py $lg 2>&1 | grep -v amdgpu | tail -1 >> $R/gpurun_out/r5e_msm_bn254.log; done; cat $R/gpurun_out/r5e_msm_bn254.log
 for spec in "gl64 22 2" "gl64 20 3" "bb31 22 2" "bls12_381 20 2"; do timeout 120 python tools/gpu_lde_one.py $spec 2>&1 | grep LDE >> $R/gpurun_out/r5e_ntt_lde.log; done; timeout 120 python tools/gpu_poly_one.py 2>&1 | grep -v amdgpu >> $R/gpurun_out/r5e_ntt_lde.log; cat $R/gpurun_out/r5e_ntt_lde.log
 timeout 200 python tools/gpu_g2_bench.py 2>&1 | grep -v amdgpu > $R/gpurun_out/r5e_msm_g2.log; cat $R/gpurun_out/r5e_msm_g2.log
+: > $R/gpurun_out/r5e_ntt_small.log
+for o in 1 0 2 3; do echo "== order $o (0 NN, 1 NR, 2 RN, 3 RR)" >> $R/gpurun_out/r5e_ntt_small.log; timeout 300 python tools/gpu_ntt_small_vs_reference.py order=$o 2>&1 | grep "^gl64\|^bb31\|^bls12_381\|^bn254\|rows" | grep "2^8 \|2^9 \|2^10 \|2^11 \|2^12 \|2^16 \|2^20 \|rows" >> $R/gpurun_out/r5e_ntt_small.log; done; grep "rows" $R/gpurun_out/r5e_ntt_small.log
+timeout 300 python tools/gpu_msm_records_ab.py 26 24 22 2>&1 | grep "^2\^" > $R/gpurun_out/r5e_sort_records_ab.log; cat $R/gpurun_out/r5e_sort_records_ab.log
 rm -rf gpurun_out/prof_r5e gpurun_out/prof_r5e_fetch gpurun_out/prof_r5e_write gpurun_out/prof_tl gpurun_out/prof_r5e_nf gpurun_out/prof_r5e_nw
 du -sh gpurun_out

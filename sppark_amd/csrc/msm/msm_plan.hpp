@@ -129,8 +129,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.IB = p.SH = 0; p.NG = 1;
     if (t.pack != 2 && !t.nslabs && p.LB < 16) {
         const unsigned IB = 31 - p.LB;
-        unsigned lgs = lg2_floor(p.slab_sz) + ((p.slab_sz & (p.slab_sz - 1)) ? 1 : 0);
-        lgs = std::min(lgs, IB);
+        // (rounded DOWN: a size just above a power of two keeps its work-group count -- 2^26 + 1 points are 65 slabs of 2^20,
+        // not 33 of 2^21, which would be two rounds of twice the work on 256 compute units instead of three)
+        const unsigned lgs = std::min(lg2_floor(p.slab_sz ? p.slab_sz : 1), IB);
         const size_t ss = (size_t)1 << lgs, ns = (npoints + ss - 1) / ss, ng = (((ns ? ns : 1) - 1) >> (IB - lgs)) + 1;
         if (ng <= 128 && ns <= 4096) { p.slab_sz = (unsigned)ss; p.nslabs = (unsigned)std::max<size_t>(1, ns); p.IB = IB; p.SH = IB - lgs; p.NG = (unsigned)ng; }
     }

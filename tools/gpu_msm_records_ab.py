@@ -2,18 +2,18 @@
 msm_plan.hpp; the slab counts asked for are the automatic ones), alternating on one box.  Per size: the median of REPS
 calls of the time before the first accumulation (digits + sort + point conversion) and of the whole device part.
 
-    python tools/gpu_msm_records_ab.py [lg ...]            (default 26 24 22 20)
+    python tools/gpu_msm_records_ab.py [lg | lg+extra ...]            (default 26 24 22 20; "26+4096" = 2^26 + 4096 points)
 """
 import os, statistics, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sppark_amd
 import oracle as O                   # (Jacobian -> affine for the comparison of the two results only)
 REPS = 7
-lgs = [int(a) for a in sys.argv[1:]] or [26, 24, 22, 20]
+sizes = [(lambda t: (1 << int(t[0])) + (int(t[1]) if len(t) > 1 else 0))(a.split("+")) for a in sys.argv[1:]] or [1 << 26, 1 << 24, 1 << 22, 1 << 20]
 base = torch.zeros((2048, 96), dtype=torch.uint8, device="cuda")
 sppark_amd.generate_points(base, 2048, 0x5eed5eed0001, 96)
-for lg in lgs:
-    n = 1 << lg
+for n in sizes:
+    lg = n.bit_length() - 1
     pts = base[torch.arange(n, device="cuda") % 2048].contiguous()
     g = torch.Generator(device="cuda"); g.manual_seed(lg)
     sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g); sc[:, 31] &= 0x3f
@@ -31,6 +31,6 @@ for lg in lgs:
             if rep:
                 res[name][0].append(ctx.kernel_ms(0)); res[name][1].append(ctx.kernel_ms(2))
     m = {k: (statistics.median(v[0]), statistics.median(v[1])) for k, v in res.items()}
-    print("2^%d: before the accumulation %.2f ms with 8-byte records -> %.2f with 4-byte ones; device part %.2f -> %.2f ms"
-          % (lg, m["wide"][0], m["packed"][0], m["wide"][1], m["packed"][1]), flush=True)
+    print("%s: before the accumulation %.2f ms with 8-byte records -> %.2f with 4-byte ones; device part %.2f -> %.2f ms"
+          % ("2^%d" % lg if n == 1 << lg else "2^%d + %d" % (lg, n - (1 << lg)), m["wide"][0], m["packed"][0], m["wide"][1], m["packed"][1]), flush=True)
     del ctx, pts, sc

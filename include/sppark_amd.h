@@ -177,7 +177,8 @@ typedef struct sppark_msm_ctx sppark_msm_ctx;
 SppError sppark_msm_create(sppark_msm_ctx **ctx, int device_id, void *stream);
 void     sppark_msm_destroy(sppark_msm_ctx *ctx);
 SppError sppark_msm_set_stream(sppark_msm_ctx *ctx, void *stream);
-/* wbits/L/F/K/nslabs = 0 keeps the automatic choice */
+/* wbits/L/F/K/nslabs = 0 keeps the automatic choice (an explicit nslabs also keeps the sort's level-A records at 8 bytes:
+ * the 4-byte form needs point slabs of a power of two, which the automatic choice provides) */
 SppError sppark_msm_tune(sppark_msm_ctx *ctx, unsigned wbits, unsigned L, unsigned F,
                          unsigned K, unsigned nslabs);
 /* low_bits of the bucket index sorted by the second LDS level (0 = automatic) */

@@ -30,7 +30,6 @@ struct msm_tunables {                   // 0 = automatic
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
-    unsigned pack = 0;                  // level-A sort records: 0 = 4 bytes where the plan allows it, 2 = always 8 bytes
     unsigned g2_coop = 0;               // G2 only: the accumulation with one Fp2 component per wave (msm_g2c_kernels.hpp): 0 = for the 14-limb base fields, 1 = always, 2 = never
     size_t resident_lanes = 0;          // lanes of k_accumulate the device holds at once (set by the driver from the occupancy query; 0 = unknown)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
@@ -127,7 +126,7 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // a record in its partition, which needs slabs of a power of two <= 2^IB points (so that an index group is a whole
     // number of slabs) and at most 128 groups.  Not with an explicit slab count (the tunable means what it says).
     p.IB = p.SH = 0; p.NG = 1;
-    if (t.pack != 2 && !t.nslabs && p.LB < 16) {
+    if (!t.nslabs && p.LB < 16) {
         const unsigned IB = 31 - p.LB;
         // (rounded DOWN: a size just above a power of two keeps its work-group count -- 2^26 + 1 points are 65 slabs of 2^20,
         // not 33 of 2^21, which would be two rounds of twice the work on 256 compute units instead of three)

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Kept as the record of how profiles/r05_ntt_small_sized_ab.log was produced: the variant libraries lib_old / lib_b / lib_nosq / lib_tuning were
+# built from switches of the tree of that moment -- two pairs per lane, squared twiddles, DPP selects -- which the job's result removed.)
 # Round 5, job 11: k_ntt_small with (a) its twiddles from the level rows of ntt_tables::inner (consecutive lanes read
 # consecutive entries), (b) instances compiled for one size (2^8 ... 2^11), (c) the in-wave exchanges at distance <= 8 as
 # selects with a DPP source.  One box: parity first (the NTT GPU tests), then ours only for the library of the commit before

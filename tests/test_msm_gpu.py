@@ -808,6 +808,44 @@ def test_msm_above_2p28_vs_oracle(oracle, libs):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("lg", [23, 26])
+def test_msm_skewed_scalars_full_size_vs_oracle(oracle, libs, lg):
+    """Skewed scalars at the sizes where the 4-byte sort records need their upper index bits back (2^23: two index groups,
+    2^26: sixteen, four slabs each): ALL scalars equal -- every window is ONE level-A partition of n entries, sorted by the
+    cooperative kernels in 64 slices that cross the group boundaries --, every second scalar zero (the groups' first
+    positions are no longer multiples of anything), 16-bit scalars (every window but one empty) and a mix; not a power of
+    two at 2^23.  Against the oracle through the period fold (oracle/fold.py)."""
+    import torch
+    import sppark_amd
+    from sppark_amd import synth
+    from oracle import fold
+    O = oracle
+    per = 2048
+    n = (1 << lg) + (5 * per if lg == 23 else 0)
+    r = O.FR_MODULUS[O.BLS12_381]
+    pts, base = synth.replicated_points(n, "bls12_381", per, 0x5eed5eed0002)
+    sc = synth.uniform_scalars(n, "bls12_381", 230 + lg)
+    ctx = sppark_amd.MsmContext("bls12_381", stream=torch.cuda.current_stream().cuda_stream)
+    base_np = base.cpu().numpy()
+
+    def check(s_, what):
+        got = sppark_amd.to_affine(ctx.invoke(pts, s_))
+        assert (got == O.msm_affine(O.BLS12_381, base_np, fold.fold_scalars(s_, per, r), algo=0, param=8)).all(), (lg, what)
+
+    eq = sc.clone(); eq[:] = sc[0]
+    check(eq, "all equal")
+    if lg == 23:
+        half = sc.clone(); half[::2] = 0
+        check(half, "every second scalar zero")
+        s16 = torch.zeros_like(sc); s16[:, :2] = sc[:, :2]
+        check(s16, "16-bit scalars")
+        mix = sc.clone(); mix[n // 16: n - n // 8] = sc[1]
+        check(mix, "13/16 equal, uniform at both ends")
+    ctx.close()
+    del pts, sc, eq
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("curve,name,lg", [(0, "bls12_381", 23), (1, "bn254", 24), (0, "bls12_381", 26)])
 def test_msm_fixed_base_full_size_vs_oracle(oracle, libs, curve, name, lg):
     """the fixed-base mode at the sizes it builds its tables by itself (>= 2^23 points: automatic window, 2^12

@@ -258,6 +258,12 @@ void sppark_g2_to_affine(void *out_xy, const void *jacobian);
  * out: affine, stride bytes apart (flag byte written when stride > 2*sizeof(fp)).
  * out may be a host or device pointer.  Synthetic-input generator for benches. */
 SppError sppark_g1_generate(void *out, size_t stride, size_t n, uint64_t seed);
+/* ALL-DISTINCT synthetic inputs with known discrete logarithms: P_i = (a + i*b) * G for i < n, affine, written on the
+ * device (out: DEVICE pointer, stride a multiple of 8; bytes above the coordinates cleared).  a, b: 128-bit little-endian
+ * word pairs, a >= 1, b < 2^96, a < 2^126, n < 2^30 (every a + i*b is distinct and non-zero modulo the group order).
+ * The arbitrary-point oracle of the reference's MSM test (poc/msm-cuda/tests/msm.rs:19-39) does not reach 2^26 points;
+ * on this vector sum s_i P_i = (sum s_i (a + i b) mod r) * G needs one scalar multiplication. */
+SppError sppark_g1_generate_progression(void *out, size_t stride, size_t n, const uint64_t a[2], const uint64_t b[2]);
 
 /* gpu_ptr_t<void> handles for C callers (the reference creates them from C++ only):
  * allocate `bytes` of device memory behind a ref-counted handle / read its device pointer.

@@ -598,3 +598,146 @@ SPPARK_FFI RustError sppark_g1_generate(void* out, size_t stride, size_t n, uint
         else                        memcpy(out, host.data(), host.size());
     });
 }
+
+// ---- all-distinct synthetic inputs: P_i = (a + i*b) * G, affine, written on the device -------
+// The reference's own MSM test holds the result against an oracle on ARBITRARY points
+// (poc/msm-cuda/tests/msm.rs:19-39); at 2^26 points no CPU oracle finishes, but a vector whose discrete
+// logarithms are known needs none: sum s_i P_i = (sum s_i (a + i b) mod r) * G.  T lanes; lane t walks
+// i = t, t + T, t + 2T, ... by mixed additions of the affine step (T b) G, so that the lanes of a wave
+// touch adjacent points; the XYZZ chain is normalised by ONE inversion per lane (Montgomery's trick
+// over the lane's ZZ * ZZZ), second walk backwards.  a >= 1 and a + n b < 2^127 < r: no point at infinity.
+struct prog_par { u64 a_lo, a_hi, b_lo, b_hi; };
+
+__device__ __forceinline__ fp_d fp_inverse(const fp_d& x)
+{                                                       // x^(p-2), left to right
+    u32 e[fp_d::N];
+    u32 bw = 2;
+    #pragma unroll
+    for (int i = 0; i < fp_d::N; i++) {
+        u32 m = (u32)curve_p::fp::MOD[i];
+        e[i] = m - bw; bw = m < bw ? 1u : 0u;
+    }
+    fp_d r = fp_d::one();
+    for (int i = fp_d::N - 1; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            r = r.sqr();
+            if ((e[i] >> b) & 1) r = r * x;
+        }
+    return r;
+}
+
+__device__ __forceinline__ void g1_mul_u128(wire_bucket_d& acc, const affine_dev<fp_d>& g, u64 lo, u64 hi)
+{
+    acc.set_inf();
+    for (int w = 1; w >= 0; w--) {
+        u64 word = w ? hi : lo;
+        for (int b = 63; b >= 0; b--) {
+            acc.dbl();
+            if ((word >> b) & 1) acc.madd(g, false);
+        }
+    }
+}
+
+__device__ __forceinline__ affine_dev<fp_d> g1_generator_dev()
+{
+    affine_dev<fp_d> g;
+    u32 gx[fp_d::N], gy[fp_d::N];
+    #pragma unroll
+    for (int k = 0; k < fp_d::N / 2; k++) {
+        gx[2*k] = (u32)curve_p::GX64[k]; gx[2*k+1] = (u32)(curve_p::GX64[k] >> 32);
+        gy[2*k] = (u32)curve_p::GY64[k]; gy[2*k+1] = (u32)(curve_p::GY64[k] >> 32);
+    }
+    g.X = fp_d::from_wire(gx); g.Y = fp_d::from_wire(gy); g.inf = false;
+    return g;
+}
+
+__device__ __forceinline__ void fp_store8(unsigned char* p, const fp_d& x)      // 8-byte aligned destinations (stride 104)
+{
+    u32 w[fp_d::N]; x.to_wire(w);
+    uint2* d = reinterpret_cast<uint2*>(p);
+    #pragma unroll
+    for (int i = 0; i < fp_d::N / 2; i++) d[i] = make_uint2(w[2*i], w[2*i+1]);
+}
+__device__ __forceinline__ fp_d fp_load8(const unsigned char* p)
+{
+    u32 w[fp_d::N];
+    const uint2* d = reinterpret_cast<const uint2*>(p);
+    #pragma unroll
+    for (int i = 0; i < fp_d::N / 2; i++) { uint2 v = d[i]; w[2*i] = v.x; w[2*i+1] = v.y; }
+    return fp_d::from_wire(w);
+}
+
+// step = (T b) G as an affine point (one lane; 128 doublings and one inversion)
+__global__ void k_progression_step(unsigned char* step_xy, u64 s_lo, u64 s_hi)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    wire_bucket_d acc;
+    g1_mul_u128(acc, g1_generator_dev(), s_lo, s_hi);
+    fp_d iz = fp_inverse(acc.ZZZ);                      // 1/ZZZ; 1/ZZ = ZZ^2 / ZZZ^2
+    fp_d izz = (acc.ZZ * iz).sqr();
+    fp_store8(step_xy, acc.X * izz);
+    fp_store8(step_xy + sizeof(fp_d), acc.Y * iz);
+}
+
+__global__ __launch_bounds__(64)
+void k_progression(unsigned char* out, unsigned stride, size_t n, unsigned T, prog_par par,
+                   const unsigned char* step_xy, unsigned step_inf, unsigned char* tmp /* n x 3 field elements: ZZZ | ZZ | prefix */)
+{
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T || t >= n) return;
+    constexpr size_t FB = sizeof(fp_d);
+    affine_dev<fp_d> step; step.X = fp_load8(step_xy); step.Y = fp_load8(step_xy + FB); step.inf = step_inf != 0;
+    // k_t = a + t b (128-bit)
+    unsigned __int128 k = ((unsigned __int128)par.a_hi << 64 | par.a_lo) + ((unsigned __int128)par.b_hi << 64 | par.b_lo) * t;
+    wire_bucket_d acc;
+    g1_mul_u128(acc, g1_generator_dev(), (u64)k, (u64)(k >> 64));
+    fp_d pref = fp_d::one();
+    for (size_t i = t; i < n; i += T) {                 // forward: X | Y into the output slot, ZZZ | ZZ | prefix aside
+        unsigned char* o = out + i * stride;
+        unsigned char* s = tmp + i * 3 * FB;
+        fp_store8(o, acc.X); fp_store8(o + FB, acc.Y);
+        fp_store8(s, acc.ZZZ); fp_store8(s + FB, acc.ZZ); fp_store8(s + 2 * FB, pref);
+        pref = pref * (acc.ZZZ * acc.ZZ);
+        acc.madd(step, false);
+    }
+    fp_d inv = fp_inverse(pref);
+    size_t cnt = (n - t + T - 1) / T;
+    for (size_t j = cnt; j--;) {                        // backward
+        size_t i = t + j * (size_t)T;
+        unsigned char* o = out + i * stride;
+        const unsigned char* s = tmp + i * 3 * FB;
+        fp_d zzz = fp_load8(s), zz = fp_load8(s + FB), pre = fp_load8(s + 2 * FB);
+        fp_d id = inv * pre;                            // 1 / (ZZZ ZZ) of point i
+        inv = inv * (zzz * zz);
+        fp_d x = fp_load8(o) * (zzz * id), y = fp_load8(o + FB) * (zz * id);
+        fp_store8(o, x); fp_store8(o + FB, y);
+        for (unsigned b = 2 * FB; b < stride; b++) o[b] = 0;     // Affine_inf_t: flag byte and padding clear
+    }
+}
+
+SPPARK_FFI RustError sppark_g1_generate_progression(void* out, size_t stride, size_t n, const uint64_t a[2], const uint64_t b[2])
+{
+    return guarded([&] {
+        if (n == 0) return;
+        constexpr size_t FB = sizeof(fp_h);
+        if (stride < 2 * FB || (stride & 7)) throw hip_error(-(int)hipErrorInvalidValue, "generate_progression: stride");
+        if (!is_device_pointer(out)) throw hip_error(-(int)hipErrorInvalidValue, "generate_progression: out must be a device pointer");
+        unsigned __int128 A = (unsigned __int128)a[1] << 64 | a[0], B = (unsigned __int128)b[1] << 64 | b[0];
+        // a >= 1, a + n b < 2^127 (below every scalar-field modulus here): all k_i distinct and non-zero mod r
+        if (A == 0 || (B >> 96) != 0 || (A >> 126) != 0 || (n >> 30) != 0) throw hip_error(-(int)hipErrorInvalidValue, "generate_progression: range");
+        (void)select_gpu(-1);
+        unsigned T = (unsigned)std::min<size_t>(n, (size_t)1 << 18);
+        unsigned __int128 S = B * T;
+        unsigned char *tmp, *step;
+        HIP_OK(hipMalloc((void**)&tmp, n * 3 * FB));
+        if (hipError_t e = hipMalloc((void**)&step, 2 * FB)) { (void)hipFree(tmp); HIP_OK(e); }
+        (void)hipMemset(step, 0, 2 * FB);
+        prog_par par = { a[0], a[1], b[0], b[1] };
+        if (S != 0)
+            hipLaunchKernelGGL(k_progression_step, dim3(1), dim3(64), 0, 0, step, (u64)S, (u64)(S >> 64));
+        hipLaunchKernelGGL(k_progression, dim3((T + 63) / 64), dim3(64), 0, 0, (unsigned char*)out, (unsigned)stride, n, T, par, step, S == 0 ? 1u : 0u, tmp);
+        hipError_t e = hipDeviceSynchronize();
+        (void)hipFree(tmp); (void)hipFree(step);
+        HIP_OK(e);
+    });
+}

@@ -139,6 +139,8 @@ def load(name):
         L.sppark_g1_to_affine.argtypes = [vp, vp]
         L.sppark_g1_generate.argtypes = [vp, sz, sz, ctypes.c_uint64]
         L.sppark_g1_generate.restype = _Error
+        L.sppark_g1_generate_progression.argtypes = [vp, sz, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+        L.sppark_g1_generate_progression.restype = _Error
     if name in NTT_FIELDS or name in CURVES:
         L.compute_ntt.argtypes = [sz, vp, ctypes.c_uint32, ci, ci, ci]
         L.compute_ntt.restype = _Error

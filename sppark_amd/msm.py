@@ -306,3 +306,17 @@ def generate_points(out, n, seed, stride, curve="bls12_381"):
     p, _k = ffi.as_pointer(out)
     ffi.check(L, L.sppark_g1_generate(p, stride, n, seed))
     return out
+
+
+def generate_progression(out, n, a, b, stride, curve="bls12_381"):
+    """Fill the DEVICE tensor |out| with the n DISTINCT points P_i = (a + i*b)*G (affine, |stride| bytes apart),
+    computed and normalised on the GPU: an MSM over them equals (sum s_i (a + i b) mod r)*G, which is how a
+    2^26-point result on points that do not repeat is checked (poc/msm-cuda/tests/msm.rs:19-39 uses an
+    arbitrary-point oracle; none finishes at that size)."""
+    import ctypes
+    L = ffi.load(curve)
+    p, _k = ffi.as_pointer(out)
+    A = (ctypes.c_uint64 * 2)(a & (2**64 - 1), a >> 64)
+    B = (ctypes.c_uint64 * 2)(b & (2**64 - 1), b >> 64)
+    ffi.check(L, L.sppark_g1_generate_progression(p, stride, n, A, B))
+    return out

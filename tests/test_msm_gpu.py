@@ -215,6 +215,37 @@ def test_generate_points_matches_oracle(oracle, libs, curve, name):
     assert (flagged[:, :2 * fb] == O.g1_gen_points(curve, 5, 7)).all() and (flagged[:, 2 * fb:] == 0).all()
 
 
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_generate_progression_matches_oracle(oracle, libs, curve, name):
+    """sppark_g1_generate_progression: P_i = (a + i b) G, all distinct, normalised on the device.  3 * 2^18 + 5 points (every
+    lane walks three or four steps of (T b) G), sampled indices against the oracle's scalar multiplication, plain and
+    flagged strides; one lane per point below 2^18; b = 0 (the step is the point at infinity)."""
+    import torch
+    import sppark_amd
+    O = oracle
+    fb = O.FP_BYTES[curve]
+    G = O.g1_generator(curve)
+    a, b = 0x1d2c3b4a59687766554433221100ffee, 0xc0ffee11d00dfeedbeef0123
+    n = 3 * (1 << 18) + 5
+    rng = np.random.default_rng(curve)
+    for stride in (2 * fb, 2 * fb + 8):
+        out = torch.full((n, stride), 0xa5, dtype=torch.uint8, device="cuda")
+        sppark_amd.generate_progression(out, n, a, b, stride, name)
+        idx = sorted(set([0, 1, 63, 64, (1 << 18) - 1, 1 << 18, (1 << 18) + 1, 2 << 18, 3 << 18, n - 1] + list(rng.integers(0, n, 40))))
+        got = out[torch.tensor(idx, device="cuda")].cpu().numpy()
+        for row, i in zip(got, idx):
+            assert (row[:2 * fb] == O.g1_mul(curve, G, a + int(i) * b)).all(), (name, stride, i)
+            assert (row[2 * fb:] == 0).all()
+    small = torch.zeros((100, 2 * fb), dtype=torch.uint8, device="cuda")
+    sppark_amd.generate_progression(small, 100, 5, 3, 2 * fb, name)
+    for i in (0, 1, 99):
+        assert (small[i].cpu().numpy() == O.g1_mul(curve, G, 5 + 3 * i)).all()
+    sppark_amd.generate_progression(small, 100, 7, 0, 2 * fb, name)
+    assert (small.cpu().numpy() == O.g1_mul(curve, G, 7)).all()
+    with pytest.raises(sppark_amd.SpparkError):
+        sppark_amd.generate_progression(small, 100, 0, 3, 2 * fb, name)          # a = 0 would be the point at infinity
+
+
 def test_msm_golden_vectors(oracle, libs):
     """Golden vectors produced by the reference's own msm/pippenger.hpp."""
     import sppark_amd
@@ -750,7 +781,12 @@ def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     the sum of the scalars of class j mod r (oracle/fold.py).  Checked for
       (i)  periodic scalars with the recipe's edge rows (0, r-1, (r+-1)/2, duplicates, P and -P),
       (ii) INDEPENDENT UNIFORM scalars on [0, r) -- the bench's headline workload --
-    and (iii) whole == half + half on the uniform run."""
+    and (iii) whole == half + half on the uniform run.
+    What these can and cannot see: a gather-index error that is a multiple of the period reads the SAME point -- with
+    2048 that is every power-of-two slip from 2^11 on (a wrong index group of the 4-byte sort records, +-k 2^22 here; a
+    32-bit wrap of an index or of index * 128).  So (iv): the uniform run again on the same 2^26 scalars with the points
+    replicated with the odd prime period 2039 (ragged: 2^26 = 32912 * 2039 + 432), where k 2^m = 0 mod 2039 only for
+    k = 0 mod 2039 -- any index slip below 2039 * 2^m lands on a different point."""
     import torch
     import sppark_amd
     from sppark_amd import synth
@@ -775,6 +811,51 @@ def test_msm_full_size_vs_oracle(oracle, libs, curve, name):
     h = n // 2
     parts = np.stack([ctx.invoke(pts[:h], rnd[:h]), ctx.invoke(pts[h:], rnd[h:])])
     assert (sppark_amd.to_affine(sppark_amd.jacobian_sum(parts, name), name) == sppark_amd.to_affine(whole, name)).all()
+    del pts
+    odd = 2039
+    pts = d_base[torch.arange(n, device="cuda") % odd].contiguous()
+    got = sppark_amd.to_affine(ctx.invoke(pts, rnd), name)
+    assert (got == O.msm_affine(curve, base[:odd], fold.fold_scalars(rnd, odd, r), algo=0, param=8)).all()
+    assert not (got == sppark_amd.to_affine(whole, name)).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("curve,name", [(0, "bls12_381"), (1, "bn254")])
+def test_msm_all_distinct_points_full_size(oracle, libs, curve, name):
+    """2^26 points that do NOT repeat (the reference's test holds its result against an oracle on arbitrary points,
+    poc/msm-cuda/tests/msm.rs:19-39; no CPU oracle finishes 2^26): P_i = (a + i b) G generated and normalised on the
+    device (sppark_g1_generate_progression; sampled against the oracle's scalar multiplication here and in
+    test_generate_progression_matches_oracle), independent uniform scalars, expected result (sum s_i (a + i b) mod r) G
+    from integer arithmetic on the scalars and ONE oracle scalar multiplication.  ANY wrong gather index i' changes the
+    sum by s_i b (i' - i) G != 0.  Also all scalars equal (sum = s (n a + b n (n - 1) / 2) G: every window one level-A
+    partition) and the first 2^25 + 12345 points (a ragged prefix: other plan, other index groups)."""
+    import torch
+    import sppark_amd
+    from sppark_amd import synth
+    from oracle import fold
+    O = oracle
+    fb = O.FP_BYTES[curve]
+    r = O.FR_MODULUS[curve]
+    n = 1 << 26
+    a, b = 0x243f6a8885a308d313198a2e03707344, 0xa4093822299f31d0082efa99       # < 2^126, < 2^96
+    G = O.g1_generator(curve)
+    pts = torch.empty((n, 2 * fb), dtype=torch.uint8, device="cuda")
+    sppark_amd.generate_progression(pts, n, a, b, 2 * fb, name)
+    for i in (0, 12345678, n - 1):
+        assert (pts[i].cpu().numpy() == O.g1_mul(curve, G, a + i * b)).all()
+    sc = synth.uniform_scalars(n, name, seed=2600 + curve)
+    ctx = sppark_amd.MsmContext(name, stream=torch.cuda.current_stream().cuda_stream)
+
+    def check(p_, s_, what):
+        s0, s1 = fold.weighted_sums(s_)
+        exp = O.g1_mul(curve, G, (a * s0 + b * s1) % r)
+        assert (sppark_amd.to_affine(ctx.invoke(p_, s_), name) == exp).all(), (name, what)
+
+    check(pts, sc, "uniform")
+    m = (1 << 25) + 12345
+    check(pts[:m], sc[:m], "ragged prefix")
+    eq = sc.clone(); eq[:] = sc[0]
+    check(pts, eq, "all equal")
     ctx.close()
 
 
@@ -803,24 +884,36 @@ def test_msm_above_2p28_vs_oracle(oracle, libs):
     assert ctx.last_chunks() == 1
     exp = O.msm_affine(O.BLS12_381, base.cpu().numpy(), fold.fold_scalars(sc, per, O.FR_MODULUS[O.BLS12_381]), algo=0, param=8)
     assert (sppark_amd.to_affine(out) == exp).all()
+    del pts
+    # the same scalars over points of the odd prime period 2039 (see test_msm_full_size_vs_oracle: 2048 cannot see an index
+    # slip of k 2^m, m >= 11 -- at this size that includes index bit 28, the bit no other test sets)
+    odd = 2039
+    pts = base[torch.arange(n, device="cuda") % odd].contiguous()
+    out2 = ctx.invoke(pts, sc)
+    exp2 = O.msm_affine(O.BLS12_381, base[:odd].cpu().numpy(), fold.fold_scalars(sc, odd, O.FR_MODULUS[O.BLS12_381]), algo=0, param=8)
+    assert (sppark_amd.to_affine(out2) == exp2).all() and not (exp2 == exp).all()
     ctx.close()
     del pts, sc
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("per", [2048, 2039])
 @pytest.mark.parametrize("lg", [23, 26])
-def test_msm_skewed_scalars_full_size_vs_oracle(oracle, libs, lg):
+def test_msm_skewed_scalars_full_size_vs_oracle(oracle, libs, lg, per):
     """Skewed scalars at the sizes where the 4-byte sort records need their upper index bits back (2^23: two index groups,
     2^26: sixteen, four slabs each): ALL scalars equal -- every window is ONE level-A partition of n entries, sorted by the
     cooperative kernels in 64 slices that cross the group boundaries --, every second scalar zero (the groups' first
     positions are no longer multiples of anything), 16-bit scalars (every window but one empty) and a mix; not a power of
-    two at 2^23.  Against the oracle through the period fold (oracle/fold.py)."""
+    two at 2^23.  Against the oracle through the period fold (oracle/fold.py).
+    What each period detects: with 2048 distinct points (the reference's shape) the test sees a lost or duplicated ENTRY,
+    a wrong sign, a wrong bucket -- but NOT a wrong index group, which moves an index by a multiple of 2^IB >= 2^18 and
+    gathers the same point.  The period 2039 (odd prime; the sizes are then ragged) is the leg that fails on a wrong
+    group, on any k 2^m index slip, on a 32-bit wrap of index * stride."""
     import torch
     import sppark_amd
     from sppark_amd import synth
     from oracle import fold
     O = oracle
-    per = 2048
     n = (1 << lg) + (5 * per if lg == 23 else 0)
     r = O.FR_MODULUS[O.BLS12_381]
     pts, base = synth.replicated_points(n, "bls12_381", per, 0x5eed5eed0002)
@@ -846,19 +939,21 @@ def test_msm_skewed_scalars_full_size_vs_oracle(oracle, libs, lg):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("curve,name,lg", [(0, "bls12_381", 23), (1, "bn254", 24), (0, "bls12_381", 26)])
-def test_msm_fixed_base_full_size_vs_oracle(oracle, libs, curve, name, lg):
+@pytest.mark.parametrize("curve,name,lg,per", [(0, "bls12_381", 23, 2048), (1, "bn254", 24, 2048), (0, "bls12_381", 26, 2048),
+                                                (0, "bls12_381", 23, 2039), (0, "bls12_381", 26, 2039)])
+def test_msm_fixed_base_full_size_vs_oracle(oracle, libs, curve, name, lg, per):
     """the fixed-base mode at the sizes it builds its tables by itself (>= 2^23 points: automatic window, 2^12
     staged level-A partitions, the cooperative level B in LDS-staged slices on ALL partitions), against the ORACLE
     through the period of the inputs: periodic scalars with the recipe's edge rows, then independent uniform scalars;
-    the size is NOT a power of two (ragged last slab / slice / run), and a prefix falls back to the plain path."""
+    the size is NOT a power of two (ragged last slab / slice / run), and a prefix falls back to the plain path.
+    per = 2039 (odd prime): the legs that can see an index slip of k 2^m in the (digit, multiple) pairs and the table
+    gathers (2048 gathers the same point for every m >= 11)."""
     import torch
     import sppark_amd
     from sppark_amd import synth
     from oracle import fold
     O = oracle
-    per = 2048
-    n = (1 << lg) + 3 * per
+    n = (1 << lg) + 3 * 2048
     r = O.FR_MODULUS[curve]
     base, sc = recipe.msm_inputs(curve, per, 2323 + lg, ndistinct=per, edge=True)
     d_base = torch.from_numpy(base).cuda(); d_sc = torch.from_numpy(sc).cuda()
@@ -874,7 +969,7 @@ def test_msm_fixed_base_full_size_vs_oracle(oracle, libs, curve, name, lg):
     rnd = synth.uniform_scalars(n, name, seed=5)
     whole = sppark_amd.to_affine(ctx.invoke(None, rnd), name)
     assert (whole == O.msm_affine(curve, base, fold.fold_scalars(rnd, per, r), algo=0, param=8)).all()
-    m = (n // 2 // per) * per                                    # a prefix: the plain path on the tables' first level
+    m = (n // 2 // 2048) * 2048                                  # a prefix: the plain path on the tables' first level
     assert (sppark_amd.to_affine(ctx.invoke(None, rnd[:m].contiguous(), npoints=m), name)
             == O.msm_affine(curve, base, fold.fold_scalars(rnd[:m].contiguous(), per, r), algo=0, param=8)).all()
     ctx.close()
@@ -951,16 +1046,18 @@ def test_msm_window_groups_and_chunks(oracle, libs, curve, name):
     ctx.close(); ctx2.close()
 
 
-def test_msm_pipeline_medium_size(oracle, libs):
+@pytest.mark.parametrize("per", [512, 509])
+def test_msm_pipeline_medium_size(oracle, libs, per):
     """2^22 points (4 window groups on two streams forced; host inputs: 4 chunks) against
     the oracle through the period fold, device- and host-resident, repeated back to back so that a
-    missing event between the streams would show."""
+    missing event between the streams would show.  Period 512 and the odd prime 509 (a chunk offset or an
+    index slip of k 2^m is a different point only under the latter)."""
     import torch
     import sppark_amd
     from sppark_amd import synth
     from oracle import fold
     O = oracle
-    n, per = 1 << 22, 512
+    n = 1 << 22
     base, _ = recipe.msm_inputs(O.BLS12_381, per, 99, ndistinct=per, edge=True)
     d_base = torch.from_numpy(base).cuda()
     pts = d_base[torch.arange(n, device="cuda") % per].contiguous()

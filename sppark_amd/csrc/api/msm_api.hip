@@ -21,6 +21,10 @@ extern template __global__ void k_reduce_runs<msm_fp_d>(bucket_m*, u32*, bucket_
                                                     unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<msm_fp_d>(bucket_m*, u32*, const u32*, const bucket_m*, unsigned, u32*);
 extern template __global__ void k_reduce_tail<msm_fp_d>(bucket_m*, u32*, bucket_m*, u32*, bucket_m*, unsigned, unsigned, const u32*);
+extern template __global__ void k_piece_level<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
+                                                        unsigned, unsigned, unsigned, u32*);
+extern template __global__ void k_piece_level_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
+                                                             unsigned, unsigned, unsigned, u32*);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);
@@ -51,6 +55,8 @@ extern template __global__ void k_reduce_runs<fp2_d>(bucket2_m*, u32*, bucket2_m
                                                      unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_join_runs<fp2_d>(bucket2_m*, u32*, const u32*, const bucket2_m*, unsigned, u32*);
 extern template __global__ void k_reduce_tail<fp2_d>(bucket2_m*, u32*, bucket2_m*, u32*, bucket2_m*, unsigned, unsigned, const u32*);
+extern template __global__ void k_piece_level<fp2_d>(bucket2_m*, u32*, bucket2_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
+                                                     unsigned, unsigned, unsigned, u32*);
 extern template __global__ void k_bucket_level1<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<fp2_d>(bucket2_m*, bucket2_m*, const bucket2_m*, const bucket2_m*,
                                                        unsigned, unsigned, unsigned, unsigned);

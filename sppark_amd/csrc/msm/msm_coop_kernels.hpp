@@ -11,6 +11,7 @@
 // critical path each.
 #pragma once
 #include "msm_kernels.hpp"
+#include "msm_piece_kernels.hpp"
 #include "../ec/xyzz_coop.hpp"
 
 namespace sppark_amd {
@@ -273,6 +274,30 @@ void k_bucket_levelN_coop(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __r
     for (unsigned k = 0; k < lgG; k++) coop_dbl<FP>(r, c);
     coop_add<FP>(sw, r, c);
     if (live && c.role == 0) { acc.store(&A2[id]); sw.store(&Wt2[id]); }
+}
+
+} // namespace sppark_amd
+
+namespace sppark_amd {
+
+// A level of the piece tree (msm_piece_kernels.hpp) with four waves per addition: the levels of at most COOP_LEVEL_MAX work
+// items (one work-group per CU).  The four copies of a work item take the same decisions and write the same keys; wave 0
+// stores the point.  (The in-place update is safe: every wave has loaded both operands before coop_add's first barrier.)
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_piece_level_coop(xyzz_mem<FP::N>* __restrict__ buckets, u32* __restrict__ rec_key, xyzz_mem<FP::N>* rec_pt,
+                        const u32* __restrict__ off, unsigned NB, unsigned L, unsigned chunks_per_win, unsigned nwins,
+                        unsigned cmax, unsigned t, unsigned last, u32* __restrict__ any_long)
+{
+    __shared__ coop_lds<FP> ex;
+    coop_ctx<FP> c{&ex, threadIdx.x >> 6, threadIdx.x & 63, 0};
+    const piece_job j = piece_job_of(rec_key, off, NB, L, chunks_per_win, nwins, cmax, t, last, any_long, (size_t)blockIdx.x * 64 + c.lane);
+    const bool work = j.live && (j.add || j.finish), add = j.live && j.add;
+    xyzz_dev<FP> x, y;
+    if (work) x = xyzz_dev<FP>::load(&rec_pt[j.dst]); else x.set_inf();
+    if (add)  y = xyzz_dev<FP>::load(&rec_pt[j.src]); else y.set_inf();
+    if (coop_any(add)) coop_add<FP>(x, y, c);
+    if (work && c.role == 0) x.store(j.finish ? &buckets[j.B] : &rec_pt[j.dst]);
 }
 
 } // namespace sppark_amd

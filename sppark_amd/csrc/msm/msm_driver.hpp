@@ -83,12 +83,15 @@ private:
     size_t stage_sz = 0;
     std_bucket_t* h_sums = nullptr;     // pinned: window sums of every chunk in flight
     size_t h_sums_cap = 0;
+    u32* h_flag = nullptr;              // pinned: "a bucket had more pieces than the piece tree takes" of the last MSM (enqueue)
+    bool piece_pending = false;         // the last enqueue ran the piece tree and left the fan-in tree out
     std::vector<hipEvent_t> tev;        // timing events: [0] start, [1] end, [2+2g], [3+2g] around k_accumulate of group g
     unsigned char* pre_points = nullptr;    // points kept on the device by preload() (msm_t ctor with points, pippenger.cuh:351-385)
     size_t pre_n = 0, pre_stride = 0;
     unsigned pre_fb_wbits = 0, pre_fb_nwins = 0;    // fixed-base tables: window bits / windows they were built for (0: none)
     float last_ms[4] = {0, 0, 0, 0};    // [0] before the first accumulation, [1] accumulation kernels, [2] whole device part, [3] accumulate launches
     unsigned last_chunks = 0;
+    unsigned last_redo = 0;             // invocations whose tail ran twice (the piece tree met a bucket beyond its limit)
     bool timing = false;
 
     struct layout {
@@ -250,6 +253,7 @@ public:
         if (blob) (void)hipFree(blob);
         if (stage) (void)hipFree(stage);
         if (h_sums) (void)hipHostFree(h_sums);
+        if (h_flag) (void)hipHostFree(h_flag);
         if (pre_points) (void)hipFree(pre_points);
         for (auto& e : tev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_sorted[0], ev_sorted[1], ev_accdone[0], ev_accdone[1],
@@ -278,6 +282,7 @@ public:
     void enable_timing(bool on) { timing = on; }
     float kernel_ms(int which) const { return which >= 0 && which < 4 ? last_ms[which] : -1.f; }
     unsigned chunks_of_last_invoke() const { return last_chunks; }
+    unsigned tail_redone() const { return last_redo; }
     size_t scratch_bytes() const { return blob_sz + stage_sz; }
     void release_scratch()
     {
@@ -547,13 +552,16 @@ private:
         HIP_OK(hipGetLastError());
     }
 
+    // |redo|: only the fan-in tree over the records the piece tree left, and everything after it (invoke(), when the flag of
+    // the first pass says that a bucket had more pieces than the piece tree was sized for)
     void enqueue(const msm_plan& p, const layout& l, const unsigned char* d_points, size_t stride, bool preconverted,
-                 const u32* d_scalars, bool mont, std_bucket_t* h_out, bool first_timed, unsigned fb_n = 0, unsigned fb_nwins = 0)
+                 const u32* d_scalars, bool mont, std_bucket_t* h_out, bool first_timed, unsigned fb_n = 0, unsigned fb_nwins = 0,
+                 bool redo = false, bool may_defer = false)
     {
         const bool flagged = !preconverted && stride > 2 * FP_BYTES;
         const bool multi = p.G > 1;
         if (multi) need_aux();
-        if (timing && first_timed) { need_tev(2 + 2 * p.G); HIP_OK(hipEventRecord(tev[0], stream)); }
+        if (timing && first_timed && !redo) { need_tev(2 + 2 * p.G); HIP_OK(hipEventRecord(tev[0], stream)); }
         if (multi) {                                // the inputs are ready at this point of the main stream
             HIP_OK(hipEventRecord(ev_fork, stream));
             HIP_OK(hipStreamWaitEvent(aux, ev_fork, 0));
@@ -564,9 +572,9 @@ private:
         // With ONE window group the bucket offsets of every window are still there when the bucket sums run:
         // empty buckets are recognised from them and never read (k_bucket_level1), so no memset.  With several
         // groups the two offset sets are reused, and the buckets are cleared instead.
-        if (multi) HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
+        if (multi && !redo) HIP_OK(hipMemsetAsync(buckets, 0, (size_t)p.nwins * p.NB * sizeof(bucket_t), stream));
 
-        for (unsigned g = 0; g < p.G; g++, gseq++) {
+        for (unsigned g = 0; g < p.G && !redo; g++, gseq++) {
             // sort sets by the parity of a counter that keeps running across MSMs (chunks): the
             // events of set b then always refer to the previous user of set b
             const unsigned b = multi ? (gseq & 1) : 0, w0 = g * p.wpg, wn = std::min(p.wpg, p.nwins - w0);
@@ -621,8 +629,38 @@ private:
             if (multi) HIP_OK(hipEventRecord(ev_accdone[b], stream));
         }
 
+        // ---- small MSMs: the pieces of every bucket by a tree over the bucket's own pieces (msm_piece_kernels.hpp) ----
+        // Where a bucket is cut into MORE runs than k_join_runs walks (n / NB > 4 L: up to 2^16 points), log2(cmax) launches of
+        // one addition each replace the fan-in tree's eleven of up to three (2^16: 0.29 -> 0.09 ms, 2^12: 0.20 -> 0.08).  A
+        // bucket with more than cmax pieces (skewed scalars) keeps its records and raises the flag; the fan-in tree is NOT
+        // queued behind it -- ten launches that find nothing to do are 50 us -- but run afterwards by invoke() when the flag,
+        // which comes back with the window sums, is set.  (One window group, whose offsets are all still there.)
+        // (|may_defer|: the caller looks at the flag after this MSM -- invoke() with one chunk)
+        const unsigned piece_cm = may_defer ? piece_tree_cmax(p, multi, fb_n) : 0;
+        piece_pending = false;
+        if (piece_cm && !redo) {
+            u32* flag = (u32*)(blob + l.flag);
+            HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
+            const u32* off = (const u32*)(blob + l.off[0]);
+            for (unsigned t = 0; (piece_cm >> (t + 1)) >= 1; t++) {
+                const unsigned last = (piece_cm >> (t + 2)) == 0;
+                const size_t nthr = (size_t)p.nwins * p.NB * (piece_cm >> (t + 1));
+                bool coop = false;
+                if constexpr (MONTX) coop = nthr <= COOP_LEVEL_MAX && tune.join != 4;
+                if constexpr (MONTX) {
+                    if (coop) hipLaunchKernelGGL(k_piece_level_coop<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(COOP_NT), 0, stream,
+                                                 buckets, keyA, ptA, off, p.NB, p.L, p.chunks_per_win, p.nwins, piece_cm, t, last, flag);
+                }
+                if (!coop) hipLaunchKernelGGL(k_piece_level<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                                              buckets, keyA, ptA, off, p.NB, p.L, p.chunks_per_win, p.nwins, piece_cm, t, last, flag);
+                HIP_OK(hipGetLastError());
+            }
+            if (!h_flag) HIP_OK(hipHostMalloc((void**)&h_flag, 64, hipHostMallocDefault));
+            HIP_OK(hipMemcpyAsync(h_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+            piece_pending = true;
+        }
         // ---- segmented record tree over the records of all windows -----------------------------
-        {
+        if (!piece_pending) {
             size_t nrec = (size_t)2 * p.nwins * p.chunks_per_win;
             u32* ik = keyA; bucket_t* ip = ptA; u32* ok = keyB; bucket_t* op = ptB;
             // segments of <= JOIN_WALK records (with uniform scalars: all of them) in one launch; the tree
@@ -630,7 +668,7 @@ private:
             const u32* skip = nullptr;
             // (not when the average bucket is longer than four runs: every segment is then longer than the join's walk
             // and the launch finds nothing to do -- below ~2^19 points)
-            if (tune.join != 1 && (size_t)p.n / p.NB <= (size_t)4 * p.L) {
+            if (tune.join != 1 && !redo && (size_t)p.n / p.NB <= (size_t)4 * p.L) {
                 u32* keyC = (u32*)(blob + l.keyC); u32* flag = (u32*)(blob + l.flag);
                 HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
                 const size_t nthr = nrec / 2 + 1;
@@ -752,7 +790,7 @@ private:
             }
             result = iw;
         }
-        if (timing && first_timed) HIP_OK(hipEventRecord(tev[1], stream));
+        if (timing && first_timed && !redo) HIP_OK(hipEventRecord(tev[1], stream));
         // ---- device -> host: one XYZZ per window (wire image); Horner on the host ------------------
         if constexpr (INTERNAL) {
             std_bucket_t* fin = (std_bucket_t*)(blob + l.sums);
@@ -762,6 +800,17 @@ private:
         } else {
             HIP_OK(hipMemcpyAsync(h_out, result, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
         }
+    }
+
+    // pieces per bucket the piece tree of a small MSM takes, 0 = the record list goes through k_join_runs / the fan-in tree:
+    // one window group, not the fixed-base window, buckets longer than the join's walk, at most 2^10 pieces
+    // (tune.join 5: never -- the A/B switch)
+    unsigned piece_tree_cmax(const msm_plan& p, bool multi, unsigned fb_n) const
+    {
+        if (multi || fb_n || tune.join == 5 || tune.join == 1) return 0;
+        if ((size_t)p.n / p.NB <= (size_t)4 * p.L) return 0;
+        const unsigned c = piece_cmax((size_t)p.n / p.NB / p.L + 1);
+        return c <= 1024 ? c : 0;
     }
 
     // Horner over the window sums (the reference's host-side collect, pippenger.cuh:627-727, is O(256 * windows))
@@ -970,11 +1019,19 @@ public:
             }
             // (chunks of different lengths have layouts of their own: harmless, every sort set of an MSM is
             // either written on the main stream or behind an event recorded on it after the previous MSM)
-            enqueue(p, l, d_points, in_stride, preconverted, d_scalars, mont, h_sums + c * MAX_WINS, c == 0);
+            enqueue(p, l, d_points, in_stride, preconverted, d_scalars, mont, h_sums + c * MAX_WINS, c == 0, 0, 0, false, nchunks == 1);
             if (host && nchunks > 1) HIP_OK(hipEventRecord(ev_chunkdone[sb], stream));
         }
         HIP_OK(hipStreamSynchronize(stream));
         last_chunks = (unsigned)nchunks;
+        // the piece tree left a bucket with more pieces than it takes (skewed scalars): the fan-in tree over the records it
+        // left, the bucket sums again (single chunk: the piece tree is for sizes far below a chunk)
+        if (piece_pending && *h_flag != 0) {
+            enqueue(plans[0], layouts[0], nullptr, in_stride, preconverted, nullptr, mont, h_sums, false, 0, 0, true);
+            HIP_OK(hipStreamSynchronize(stream));
+            last_redo++;
+        }
+        piece_pending = false;
 
         if (timing) {
             const msm_plan& p = plans[0];

@@ -177,13 +177,24 @@ class ntt_engine {
         });
     }
 
-    // a table of the radix-64 plan (r64_table_item)
+    // a table of the radix-64 plan (r64_table_item); |cmode|: with the coset powers folded in (G: the powers of g), which
+    // ties it to the transform size
     const F* r64_table(int hip_dev, unsigned lg, int inverse, unsigned kind, unsigned lg_cur, int scaled,
-                       const ntt_tables<F>& T, hipStream_t stream)
+                       const ntt_tables<F>& T, hipStream_t stream, unsigned cmode, const ntt_tables<F>& G)
     {
+        if (cmode == 2 && kind == 2) cmode = 0;                     // (no row-only part: the plain table)
         const size_t count = kind == 0 ? (size_t)1 << lg_cur : kind == 1 ? (size_t)1 << (lg_cur - 6) : 4096;
-        return cached_table(tw_key(hip_dev, inverse, 1, kind, lg_cur, scaled ? lg : 0u), count, stream, [&](F* tw) {
-            hipLaunchKernelGGL(k_r64_table<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tw, T, kind, lg_cur, scaled);
+        const tw_key key = cmode ? tw_key(hip_dev, inverse, 1 + 10 * (int)cmode, kind, lg_cur, lg | (scaled ? 256u : 0u))
+                                 : tw_key(hip_dev, inverse, 1, kind, lg_cur, scaled ? lg : 0u);
+        return cached_table(key, count, stream, [&](F* tw) {
+            hipLaunchKernelGGL(k_r64_table<F>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, tw, T, kind, lg_cur, scaled, cmode, G);
+        });
+    }
+    // the 64 constants of a folded coset transform (r64_cz_item)
+    const F* r64_cz(int hip_dev, unsigned lg, int inverse, unsigned cmode, const ntt_tables<F>& G, hipStream_t stream)
+    {
+        return cached_table(tw_key(hip_dev, inverse, 2, cmode, 0u, lg), 64, stream, [&](F* cz) {
+            hipLaunchKernelGGL(k_r64_cz<F>, dim3(1), dim3(64), 0, stream, cz, G, cmode);
         });
     }
 
@@ -274,23 +285,21 @@ public:
             case NTT_RN: bitrev = true;  gs = false; break;
             default:     bitrev = true;  gs = true;  break;
         }
-        if (!inverse && type == NTT_COSET)
-            hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
-
         // The plan's shape parameters.  A shipped library uses the constants; a tuning build (-DSPPARK_TUNING, e.g.
         // SPPARK_EXTRA_FLAGS=-DSPPARK_TUNING python -m sppark_amd.build; tools/gpu_ntt_sweep.py) reads them from the
         // environment once per process.  The LDS tile is clamped to what the element size allows (160 KB per
         // work-group: 2^14 eight-byte elements, 2^12 32-byte ones; the one-stage-per-round passes stay within the
         // 64 KB a launch gets without raising the kernel's limit).
-        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; };
+        struct knobs_t { unsigned smax, lgc, lgt, r64_min, r64_direct, lat_smax; int lat_lgc, lat_lgt; unsigned coset_fold; };
         static const knobs_t knobs = [] {
-            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1};
+            knobs_t k{S_MAX, LG_LINE, LG_TILE, 12, R64_DIRECT_MAX_LG, LAT_SMAX, -1, -1, 1};
 #ifdef SPPARK_TUNING
             // 256-bit fields: stages per one-stage-per-round pass (0: the register passes), columns per tile row and tile
             // elements (log2; default: by size, lat_shape())
             if (const char* e = getenv("SPPARK_NTT_LAT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v <= 8) k.lat_smax = R64 ? 0 : v; }
             if (const char* e = getenv("SPPARK_NTT_LAT_LGC")) { int v = atoi(e); if (v >= 0 && v <= 3) k.lat_lgc = v; }
             if (const char* e = getenv("SPPARK_NTT_LAT_LGTILE")) { int v = atoi(e); if (v >= 6 && v <= 11) k.lat_lgt = v; }
+            if (const char* e = getenv("SPPARK_NTT_COSET_FOLD")) k.coset_fold = (unsigned)atoi(e);    // 0: the separate scaling launch
             if (const char* e = getenv("SPPARK_NTT_R64_MIN")) k.r64_min = (unsigned)atoi(e);          // 99: the 8-stage plan only
             if (const char* e = getenv("SPPARK_NTT_R64_DIRECT")) k.r64_direct = (unsigned)atoi(e);    // largest single inter-pass table (log2)
             if (const char* e = getenv("SPPARK_NTT_SMAX")) { unsigned v = (unsigned)atoi(e); if (v >= 1 && v <= S_MAX) k.smax = v; }
@@ -310,21 +319,30 @@ public:
         // the tables of the radix-64 plan, fetched (first call: built) BEFORE anything is launched: if the device has no
         // room for one of them the transform runs the 8-stage plan, whose passes can generate their twiddles
         const F* r64_tabs[8][2] = {};
+        // a coset transform on a plan of k_ntt6 / k_ntt12 steps carries the powers of the coset generator in its tables and 64
+        // constants (r64_coset_mode, ntt_r64_kernels.hpp): no separate scaling launch (2^24: 0.217 -> 0.19 ms)
+        unsigned cmode = 0;
+        const F* r64_czp = nullptr;
         if (R64 && lg >= 12 && lg >= knobs.r64_min) {
             rp = make_r64_plan(lg);
+            cmode = knobs.coset_fold ? r64_coset_mode(rp, gs, inverse != 0, type == NTT_COSET && order != NTT_RR) : 0;
             bool ok = true;
             for (unsigned i = 0; i < rp.nsteps && ok; i++) {
                 const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
                 if (st.kind == 0) continue;
                 const int scaled = inverse && i == rp.nsteps - 1;
+                const unsigned cm = cmode == 1 && st.lg_cur != lg ? 0 : cmode;     // natural exponents: the step on the whole transform only
                 if (st.kind == 2 || st.lg_cur <= knobs.r64_direct)
-                    ok = (r64_tabs[i][0] = r64_table(gpu.hip_id, lg, inverse, 0, st.lg_cur, scaled, T, stream)) != nullptr;
+                    ok = (r64_tabs[i][0] = r64_table(gpu.hip_id, lg, inverse, 0, st.lg_cur, scaled, T, stream, cm, G)) != nullptr;
                 else
-                    ok = (r64_tabs[i][0] = r64_table(gpu.hip_id, lg, inverse, 1, st.lg_cur, scaled, T, stream)) != nullptr
-                      && (r64_tabs[i][1] = r64_table(gpu.hip_id, lg, inverse, 2, st.lg_cur, 0, T, stream)) != nullptr;
+                    ok = (r64_tabs[i][0] = r64_table(gpu.hip_id, lg, inverse, 1, st.lg_cur, scaled, T, stream, cm, G)) != nullptr
+                      && (r64_tabs[i][1] = r64_table(gpu.hip_id, lg, inverse, 2, st.lg_cur, 0, T, stream, cm, G)) != nullptr;
             }
-            if (!ok) rp.nsteps = 0;
+            if (ok && cmode) ok = (r64_czp = r64_cz(gpu.hip_id, lg, inverse, cmode, G, stream)) != nullptr;
+            if (!ok) { rp.nsteps = 0; cmode = 0; }
         }
+        if (!inverse && type == NTT_COSET && !cmode)
+            hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
         const bool lat = !R64 && knobs.lat_smax != 0;
         if (rp.nsteps) pl.npass = rp.nsteps;
         else if (lat)  pl = make_ntt_lat_plan(lg, knobs.lat_smax, knobs.lat_lgc, knobs.lat_lgt);
@@ -344,7 +362,8 @@ public:
                 const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
                 if constexpr (R64) {
                     if (st.kind != 0) {
-                        ntt_r64_args<F> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur};
+                        ntt_r64_args<F> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur, nullptr};
+                        if (cmode == 2 ? st.kind == 2 : (cmode == 1 && st.lg_cur == lg)) A.cz = r64_czp;
                         if (st.kind == 2 || st.lg_cur <= knobs.r64_direct) A.tw = r64_tabs[i][0];
                         else { A.t1 = r64_tabs[i][0]; A.t2 = r64_tabs[i][1]; }
                         const unsigned tiles = (unsigned)(n >> 12);
@@ -409,7 +428,7 @@ public:
             else                      { SPPARK_NTT_DISPATCH_S4(P.S, SPPARK_NTT_LAUNCH); }
 #undef SPPARK_NTT_LAUNCH
         }
-        if (inverse && type == NTT_COSET)
+        if (inverse && type == NTT_COSET && !cmode)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)!bitrev);
         if (order == NTT_RR)
             bit_reverse(d, lg, stream);

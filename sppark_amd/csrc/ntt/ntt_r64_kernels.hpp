@@ -45,6 +45,10 @@ template<class F> struct ntt_r64_args {
     const F* t1;        // k_ntt6 without tw: t1[c0 + row] = W^(c0 * rev6(row)), c0 = col & ~63
     const F* t2;        //                    t2[(row << 6) + c] = W^(c * rev6(row)), c = col & 63
     unsigned lg_cur;    // k_ntt6: log2 of the sub-problem size (>= 12)
+    // coset transforms folded into the passes (r64_coset_mode below), or null: 64 constants g^(x << (lg_n - 6)).
+    // k_ntt6 (the step on the whole transform): cz[row], applied to the rows when they are loaded (DIF) / stored (DIT);
+    // k_ntt12: cz[lo] = g^(rev6(lo) << (lg_n - 6)), lo = position & 63, applied when the block is stored (DIF) / loaded (DIT).
+    const F* cz;
 };
 
 SPPARK_DEVFN unsigned wave_uniform(unsigned v)
@@ -104,6 +108,11 @@ SPPARK_DEVFN void ntt6_high(F* data, F* tile, const ntt_r64_args<F>& A, size_t t
     #pragma unroll
     for (unsigned a = 0; a < 8; a++) x[a] = DIF ? base[a * stride] : tile[(((a << 3) + b) << 6) + c];
     if (DIF) {
+        if (A.cz != nullptr) {                                      // coset: row (8a + b) times g^(row * Q); b is wave-uniform: scalar loads
+            const F* cz = A.cz + b;
+            #pragma unroll
+            for (unsigned a = 0; a < 8; a++) x[a] = x[a] * cz[a << 3];
+        }
         radix_dif<F, INV, 3>(x, A.inner);
         tw64_layer<F, INV>(x, b, A.inner);
         #pragma unroll
@@ -111,6 +120,11 @@ SPPARK_DEVFN void ntt6_high(F* data, F* tile, const ntt_r64_args<F>& A, size_t t
     } else {
         tw64_layer<F, INV>(x, b, A.inner);
         radix_dit<F, INV, 3>(x, A.inner);
+        if (A.cz != nullptr) {
+            const F* cz = A.cz + b;
+            #pragma unroll
+            for (unsigned a = 0; a < 8; a++) x[a] = x[a] * cz[a << 3];
+        }
         #pragma unroll
         for (unsigned a = 0; a < 8; a++) base[a * stride] = x[a];
     }
@@ -213,6 +227,11 @@ SPPARK_DEVFN void ntt12_round(F* sub, F* tile, const ntt_r64_args<F>& A, unsigne
             x[r] = from_hbm ? sub[p] : tile[ntt12_phys(p)];
         }
     }
+    if (D == R12_B2 && from_hbm && A.cz != nullptr) {               // coset, DIT: the block's input times g^(rev6(lo) << (lg_n - 6))
+        const F* cz = A.cz + (ntt12_pos<D>(lane, 0) & 63u);
+        #pragma unroll
+        for (unsigned r = 0; r < 8; r++) x[r] = x[r] * cz[r];
+    }
     if (!DIF) {
         if (D == R12_A1 || D == R12_A2) tw64_layer<F, INV>(x, u, A.inner);
         if (D == R12_B1) {
@@ -227,6 +246,11 @@ SPPARK_DEVFN void ntt12_round(F* sub, F* tile, const ntt_r64_args<F>& A, unsigne
             #pragma unroll
             for (unsigned r = 0; r < 8; r++) x[r] = x[r] * A.tw[ntt12_pos<D>(lane, r)];
         }
+    }
+    if (D == R12_B2 && to_hbm && A.cz != nullptr) {                 // coset, DIF: the block's output likewise
+        const F* cz = A.cz + (ntt12_pos<D>(lane, 0) & 63u);
+        #pragma unroll
+        for (unsigned r = 0; r < 8; r++) x[r] = x[r] * cz[r];
     }
     if (D == R12_B2 && to_hbm) {
         ntt_vec16<F>* dst = reinterpret_cast<ntt_vec16<F>*>(sub + ntt12_pos<D>(lane, 0));
@@ -272,8 +296,24 @@ void k_ntt12(F* data, ntt_r64_args<F> A)
 // kind 1: t1[c0 + row]           = W^(c0 * rev6(row)), c0 = 64-aligned column   (2^(lg_cur - 6) entries)
 // kind 2: t2[(row << 6) + c]     = W^(c * rev6(row))                            (4096 entries)
 // W = w_n^(n / n_cur); |scaled|: times 1/n (the inverse transform's last executed pass).
+//
+// Coset transforms (ntt/ntt.cuh:197-207: the powers of the coset generator as a separate kernel before a forward / after an
+// inverse transform, LDE_distribute_powers ntt/kernels.cu:131-153) are FOLDED into the passes where the plan is made of k_ntt6 /
+// k_ntt12 steps only.  The exponent of g splits along the index digits the passes work on, and all but 64 constants of it
+// land in twiddle tables that are multiplied anyway:
+//   cmode 1, "natural exponents" -- forward DIF (x_i g^i on the natural input) and inverse DIT (X_k g^-k on the natural
+//     output): with i = row Q + col on the step over the whole transform, g^(row Q) is one of 64 constants per ROW (cz, the
+//     one product per element this costs) and g^col joins that step's inter-pass twiddle W^(col rev6(row)): kind 0 times
+//     g^col, kind 1 times g^c0, kind 2 times g^c.  The later steps are plain transforms.
+//   cmode 2, "bit-reversed exponents" -- inverse DIF (the output position p holds index rev(p)) and forward DIT (the input
+//     position likewise): rev(p) = sum over the steps of rev6(row_s) << (lg_n - lg_cur_s) plus, inside a 4096-block,
+//     rev6(hi) << (lg_n - 12) and rev6(lo) << (lg_n - 6): every step's table (kind 0 and 1; kind 2 has no row-only part)
+//     takes g^(rev6(row) << (lg_n - lg_cur)), k_ntt12's table the same with row = hi, and the lo part is 64 constants per
+//     block position (cz), one product per element in k_ntt12.
+// G: the powers of g (of 1/g for an inverse transform), as k_coset uses them.
 template<class F>
-SPPARK_DEVFN void r64_table_item(F* out, const ntt_tables<F>& T, unsigned kind, unsigned lg_cur, int scaled, size_t i)
+SPPARK_DEVFN void r64_table_item(F* out, const ntt_tables<F>& T, unsigned kind, unsigned lg_cur, int scaled, size_t i,
+                                 unsigned cmode = 0, const ntt_tables<F>* G = nullptr)
 {
     const unsigned lgQ = lg_cur - 6;
     size_t count, col; unsigned row;
@@ -283,11 +323,24 @@ SPPARK_DEVFN void r64_table_item(F* out, const ntt_tables<F>& T, unsigned kind, 
     if (i >= count) return;
     F w = ntt_twiddle(T, (col * bit_rev32(row, 6)) << (T.lg_n - lg_cur));
     if (scaled) w = w * T.scale;
+    if (cmode == 1) w = w * ntt_twiddle(*G, col);
+    if (cmode == 2 && kind != 2) w = w * ntt_twiddle(*G, (size_t)bit_rev32(row, 6) << (T.lg_n - lg_cur));
     out[i] = w;
 }
 template<class F>
-__global__ __launch_bounds__(256) void k_r64_table(F* out, ntt_tables<F> T, unsigned kind, unsigned lg_cur, int scaled)
-{   r64_table_item(out, T, kind, lg_cur, scaled, (size_t)blockIdx.x * blockDim.x + threadIdx.x);   }
+__global__ __launch_bounds__(256) void k_r64_table(F* out, ntt_tables<F> T, unsigned kind, unsigned lg_cur, int scaled, unsigned cmode, ntt_tables<F> G)
+{   r64_table_item(out, T, kind, lg_cur, scaled, (size_t)blockIdx.x * blockDim.x + threadIdx.x, cmode, &G);   }
+
+// the 64 constants of a folded coset transform: cz[x] = g^(x << (lg_n - 6)) (cmode 1) / g^(rev6(x) << (lg_n - 6)) (cmode 2)
+template<class F>
+SPPARK_DEVFN void r64_cz_item(F* out, const ntt_tables<F>& G, unsigned cmode, unsigned x)
+{
+    if (x >= 64) return;
+    out[x] = ntt_twiddle(G, (size_t)(cmode == 2 ? bit_rev32(x, 6) : x) << (G.lg_n - 6));
+}
+template<class F>
+__global__ __launch_bounds__(64) void k_r64_cz(F* out, ntt_tables<F> G, unsigned cmode)
+{   r64_cz_item(out, G, cmode, threadIdx.x);   }
 
 // ---- planning (host) -----------------------------------------------------------------------------
 // GS/DIF order (step 0 splits the whole transform); CT/DIT executes the steps in reverse.
@@ -310,6 +363,18 @@ static inline r64_plan make_r64_plan(unsigned lg_n)                  // lg_n >= 
     }
     pl.step[pl.nsteps++] = r64_step{2, 12, 12};
     return pl;
+}
+
+// How a coset transform runs on this plan: 0 = the separate scaling launch (a plan with a generic top pass, the reference's RR
+// order whose exponents follow neither index, 2^12 with natural exponents), 1 / 2 = folded (r64_table_item above).
+// |gs|: the DIF network; |foldable|: a coset transform in the NN / NR / RN order.
+static inline unsigned r64_coset_mode(const r64_plan& pl, bool gs, bool inverse, bool foldable)
+{
+    if (!foldable || pl.nsteps == 0) return 0;
+    for (unsigned i = 0; i < pl.nsteps; i++) if (pl.step[i].kind == 0) return 0;
+    const unsigned mode = gs != inverse ? 1 : 2;
+    if (mode == 1 && pl.nsteps < 2) return 0;
+    return mode;
 }
 
 } // namespace sppark_amd

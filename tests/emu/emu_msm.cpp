@@ -26,6 +26,7 @@
 #include "../../sppark_amd/csrc/msm/curve_select.hpp"
 #include "../../sppark_amd/csrc/msm/msm_kernels.hpp"
 #include "../../sppark_amd/csrc/msm/msm_sort_records.hpp"
+#include "../../sppark_amd/csrc/msm/msm_piece_kernels.hpp"
 #include "../../sppark_amd/csrc/ec/jacobian_host.hpp"
 #include "../../sppark_amd/csrc/ff/fp2_host.hpp"
 #ifdef SPPARK_G2
@@ -174,6 +175,8 @@ static void finalize_sum(M* out, const xyzz_mem<F::N>* in)
 
 static unsigned g_pack = 0;
 extern "C" void emu_msm_pack(unsigned mode) { g_pack = mode; }       // 0: 8-byte level-A records
+static unsigned g_piece_cmax = 0;                                   // join == 2: pieces per bucket the piece tree takes (0: from the average bucket)
+extern "C" void emu_msm_piece_cmax(unsigned c) { g_piece_cmax = c; }
 
 extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                        const unsigned char* scalars, int mont,
@@ -332,12 +335,27 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         // k_join_runs: segments of <= JOIN_WALK records are summed here; the tree sees the rest
         std::vector<u32> keyC(nrecA);
         u32 any_long = 0;
-        if (join) {
+        if (join == 1) {
             for (size_t t = 0; t < ((nrec / 2 + 1 + 255) / 256) * 256; t++)
                 join_runs_item<inst_fp>(buckets.data(), keyC.data(), keyA.data(), ptA.data(), (unsigned)nrec, &any_long, t);
             ik = keyC.data();
         }
-        if (join_stats) { join_stats[0] = any_long; join_stats[1] = 0; for (size_t i = 0; join && i < nrec; i++) join_stats[1] += keyC[i] != KEY_NONE; }
+        if (join_stats) { join_stats[0] = any_long; join_stats[1] = 0; for (size_t i = 0; join == 1 && i < nrec; i++) join_stats[1] += keyC[i] != KEY_NONE; }
+        if (join == 2) {
+            // the piece tree of the small sizes (msm_piece_kernels.hpp), as msm_driver.hpp launches it: log2(cmax) levels over
+            // (bucket, pair) work items; the records of buckets with more pieces keep their keys and go through the fan-in tree
+            const unsigned cmax = g_piece_cmax ? g_piece_cmax : piece_cmax((size_t)p.n / p.NB / p.L + 1);
+            any_long = 0;
+            for (unsigned t = 0; (cmax >> (t + 1)) >= 1; t++) {
+                const unsigned last = (cmax >> (t + 2)) == 0;
+                const size_t nthr = (size_t)p.nwins * p.NB * (cmax >> (t + 1));
+                for (size_t id = 0; id < ((nthr + 255) / 256) * 256; id++)
+                    piece_level_item<inst_fp>(buckets.data(), keyA.data(), ptA.data(), off.data(), p.NB, p.L, p.chunks_per_win, p.nwins,
+                                              cmax, t, last, &any_long, id);
+            }
+            ik = keyA.data();
+            if (join_stats) { join_stats[0] = any_long; join_stats[1] = 0; for (size_t i = 0; i < nrec; i++) join_stats[1] += keyA[i] != KEY_NONE; }
+        }
         if (!join || any_long)
         for (;;) {
             unsigned nthreads = (unsigned)((nrec + p.F - 1) / p.F);

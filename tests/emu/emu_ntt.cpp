@@ -69,11 +69,14 @@ static void emu_bitrev(F* d, unsigned lg)
 
 // the radix-64 plan of ntt_engine::run (single-word fields, lg >= 12): k_ntt6 / k_ntt12 round by round,
 // generic passes for the other steps; tables from r64_table_item, as ntt_engine::r64_table builds them
-template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int inverse, ntt_tables<FF>& T, unsigned nt, unsigned direct_max)
+template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int inverse, ntt_tables<FF>& T, unsigned nt, unsigned direct_max,
+                                              unsigned cmode, const ntt_tables<FF>& G)
 {
     if constexpr (sizeof(FF) <= 8) {
         const size_t n = (size_t)1 << lg;
         r64_plan rp = make_r64_plan(lg);
+        std::vector<FF> cz(64);
+        for (unsigned x = 0; x < 64 && cmode; x++) r64_cz_item(cz.data(), G, cmode, x);
         for (unsigned i = 0; i < rp.nsteps; i++) {
             const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
             const bool last = i == rp.nsteps - 1;
@@ -100,10 +103,14 @@ template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int i
             }
             const int scaled = inverse && last;
             std::vector<FF> tw, t1, t2, tile(4096);
-            ntt_r64_args<FF> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur};
+            ntt_r64_args<FF> A{T.inner, nullptr, nullptr, nullptr, st.lg_cur, nullptr};
+            // as ntt_engine::run(): the coset powers in the tables of the step on the whole transform (natural exponents) / of
+            // every step (bit-reversed exponents), the 64 constants in that step / in k_ntt12
+            const unsigned cm = cmode == 1 && st.lg_cur != lg ? 0 : cmode;
+            if (cmode == 2 ? st.kind == 2 : (cmode == 1 && st.lg_cur == lg)) A.cz = cz.data();
             auto fill = [&](std::vector<FF>& v, unsigned kind, int sc) {
                 v.resize(kind == 0 ? (size_t)1 << st.lg_cur : kind == 1 ? (size_t)1 << (st.lg_cur - 6) : 4096);
-                for (size_t k = 0; k < v.size(); k++) r64_table_item(v.data(), T, kind, st.lg_cur, sc, k);
+                for (size_t k = 0; k < v.size(); k++) r64_table_item(v.data(), T, kind, st.lg_cur, sc, k, cm == 2 && kind == 2 ? 0u : cm, &G);
             };
             if (st.kind == 2 || st.lg_cur <= direct_max) { fill(tw, 0, scaled); A.tw = tw.data(); }
             else { fill(t1, 1, scaled); fill(t2, 2, 0); A.t1 = t1.data(); A.t2 = t2.data(); }
@@ -131,6 +138,14 @@ template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int i
 
 static unsigned g_r64_min = 12, g_r64_direct = 20;          // as ntt_engine's knobs (SPPARK_NTT_R64_MIN / _DIRECT)
 extern "C" void emu_ntt_plan(unsigned r64_min, unsigned r64_direct) { g_r64_min = r64_min; g_r64_direct = r64_direct; }
+static unsigned g_coset_fold = 1;                           // as ntt_engine's knob (SPPARK_NTT_COSET_FOLD): 0 = the separate coset_item pass
+extern "C" void emu_ntt_coset_fold(unsigned on) { g_coset_fold = on; }
+// how a coset transform of 2^lg elements runs (r64_coset_mode): 0 separate scaling pass, 1 / 2 folded
+extern "C" unsigned emu_ntt_coset_mode(unsigned lg, int order, int direction)
+{
+    if (sizeof(F) > 8 || lg < 12 || lg < g_r64_min || !g_coset_fold) return 0;
+    return r64_coset_mode(make_r64_plan(lg), order == 1 || order == 3, direction == 1, order != 3);
+}
 // the one-stage-per-round passes of the 256-bit fields (k_ntt_pass_lat): stages per pass (0: the register passes),
 // log2 columns per tile row, log2 tile elements -- as ntt_engine's lat_* choices
 static unsigned g_lat_smax = sizeof(F) > 8 ? 8 : 0;         // as ntt_engine<F>::LAT_SMAX
@@ -228,7 +243,11 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
         case 2: bitrev = true; gs = false; break;
         default: bitrev = true; gs = true; break;
     }
-    if (!inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)bitrev, i);
+    // as ntt_engine::run(): a coset transform on a plan of k_ntt6 / k_ntt12 steps is folded into the passes
+    unsigned cmode = 0;
+    if (sizeof(F) <= 8 && lg >= 12 && lg >= g_r64_min && g_coset_fold)
+        cmode = r64_coset_mode(make_r64_plan(lg), gs, inverse != 0, type == 1 && order != 3);
+    if (!inverse && type == 1 && !cmode) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)bitrev, i);
 
 #ifndef EMU_SMAX
 #define EMU_SMAX (sizeof(F) > 8 ? 4 : 8)        // as ntt_engine<F>::S_MAX
@@ -236,7 +255,7 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
     const bool lat = g_lat_smax != 0;
     ntt_plan pl = lat ? make_ntt_lat_plan(lg, g_lat_smax, g_lat_lgc, g_lat_lgtile) : make_ntt_plan(lg, LG_LINE, LG_TILE, EMU_SMAX);
     if (sizeof(F) <= 8 && lg >= 12 && lg >= g_r64_min) {
-        emu_r64_passes<F>(d, lg, gs, inverse, T, nt, g_r64_direct);
+        emu_r64_passes<F>(d, lg, gs, inverse, T, nt, g_r64_direct, cmode, G);
         pl.npass = 0;
     }
     // as ntt_engine::has_pass_table(): passes on sub-problems of <= 2^16 (256-bit fields: 2^24) elements read their
@@ -291,7 +310,7 @@ extern "C" int emu_ntt(void* inout, unsigned lg, int order, int direction, int t
 #undef EMU_ROUNDS
         }
     }
-    if (inverse && type == 1) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)!bitrev, i);
+    if (inverse && type == 1 && !cmode) for (size_t i = 0; i < n; i++) coset_item(d, G, (int)!bitrev, i);
     if (order == 3) emu_bitrev(d, lg);
     return 0;
 }

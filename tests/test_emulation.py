@@ -230,6 +230,40 @@ def test_msm_short_segment_join_on_host(oracle):
                     assert stats[1] == 0            # no record left for the tree
 
 
+def test_msm_piece_tree_on_host(oracle):
+    """The record list of a small MSM by the piece tree (msm_piece_kernels.hpp piece_level_item): few buckets of many
+    entries, every bucket cut into tens of fixed-length runs, its pieces found from the sort's offsets and added up
+    level by level.  Uniform scalars: no record is left for the fan-in tree, whatever the window / run length (aligned
+    and unaligned bucket starts, buckets inside one run, runs that end with the list, odd piece counts); a bucket with
+    more pieces than the tree was sized for (skewed scalars; a forced small limit) keeps its records and goes through
+    the fan-in tree; zero digits (shorter lists); G1 results against the oracle in every case."""
+    O = oracle
+    L = _emu("BLS12_381")
+    L.emu_msm_piece_cmax.argtypes = [ctypes.c_uint]; L.emu_msm_piece_cmax.restype = None
+    n = 3000
+    pts, sc = recipe.msm_inputs(0, n, 4321, edge=True)
+    s_eq = sc.copy(); s_eq[:] = sc[0]
+    s_mix = sc.copy(); s_mix[n // 3:] = sc[1]
+    s_half = sc.copy(); s_half[::2] = 0
+    s_small = np.zeros_like(sc); s_small[:, :3] = sc[:, :3]
+    try:
+        for s, what in ((sc, "uniform"), (s_eq, "equal"), (s_mix, "mix"), (s_half, "half zero"), (s_small, "24-bit")):
+            exp = O.msm_affine(0, pts, s, algo=0, param=4)
+            for wb, LL in ((4, 8), (5, 7), (6, 16), (3, 5), (8, 4), (7, 1)):
+                for cmax in (0, 2, 8, 4096):
+                    L.emu_msm_piece_cmax(cmax)
+                    out = np.zeros(144, dtype=np.uint8)
+                    stats = np.zeros(2, dtype=np.uint32)
+                    L.emu_msm(P(out), P(pts), 96, n, P(s), 0, wb, LL, 4, 4, 2, 2, P(stats), 0)
+                    assert (O.jac_to_affine(0, out) == exp).all(), (what, wb, LL, cmax)
+                    if what == "uniform" and cmax in (0, 4096):
+                        assert stats[0] == 0 and stats[1] == 0, (wb, LL, cmax, stats)      # nothing left for the fan-in tree
+                    if what == "equal" and cmax == 2 and LL <= 16:
+                        assert stats[0] == 1 and stats[1] > 0
+    finally:
+        L.emu_msm_piece_cmax(0)
+
+
 @pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])
 def test_low_latency_point_ops_on_host(oracle, curve, feature):
     """add_pairs / dbl_pairs (products in interleaved pairs, unmasked quotient digits: the forms the top of the

@@ -267,6 +267,19 @@ def main():
             sppark_amd.NTT(0, x, Ord.NN, "gl64", stream=stream)      # natural in, natural out (adds the bit reversal)
         e1.record(); torch.cuda.synchronize()
         fwd_nn = e0.elapsed_time(e1) / reps
+        # coset NR (ntt/ntt.cuh:197-207 scales by the powers of the coset generator in a separate kernel; here they ride in
+        # the passes' twiddle tables, csrc/ntt/ntt_r64_kernels.hpp r64_coset_mode): same protocol
+        yc = ref.clone()
+        sppark_amd.coset_NTT(0, yc, Ord.NR, "gl64", stream=stream); torch.cuda.synchronize()
+        coset_host = yc.cpu().numpy().view(np.uint64)
+        coset_nr = 1e30
+        for _batch in range(2):
+            e0.record()
+            for _ in range(reps):
+                sppark_amd.coset_NTT(0, yc, Ord.NR, "gl64", stream=stream)
+            e1.record(); torch.cuda.synchronize()
+            coset_nr = min(coset_nr, e0.elapsed_time(e1) / reps)
+        del yc
         # CHECKER: the timed transform at the timed size against the oracle, whole array
         y = ref.clone()
         sppark_amd.NTT(0, y, Ord.NR, "gl64", stream=stream); torch.cuda.synchronize()
@@ -276,6 +289,8 @@ def main():
         sppark_amd.iNTT(0, y, Ord.RN, "gl64", stream=stream); torch.cuda.synchronize()
         ntt_ok = ntt_ok and bool(torch.equal(y, ref))
         assert ntt_ok, "timed NTT differs from the oracle"
+        coset_ok = bool((coset_host == O.ntt_gl64(ref.cpu().numpy().view(np.uint64), O.NR, O.FORWARD, O.COSET)).all())
+        assert coset_ok, "timed coset NTT differs from the oracle"
         # SURVEY 8(d) timing protocol (ii), through-the-FFI: compute_ntt on a HOST buffer, what every caller of the
         # reference hits (poc/ntt-cuda/src/lib.rs:7-118 -> ntt/ntt.cuh:215-244: H2D, transform, D2H); wall clock,
         # pageable numpy memory as a Rust Vec / Go slice is; output asserted against the device path checked above
@@ -291,13 +306,19 @@ def main():
             O.ref_ntt_dev("gl64", xr.data_ptr(), lg, 1, 0, 0); torch.cuda.synchronize()
             same = bool((xr.cpu().numpy().view(np.uint64) == y_host).all())
             assert same, "the reference's own NTT and sppark_amd's differ on the timed input"
+            xr.copy_(ref); torch.cuda.synchronize()
+            O.ref_ntt_dev("gl64", xr.data_ptr(), lg, 1, 0, 1); torch.cuda.synchronize()
+            same_coset = bool((xr.cpu().numpy().view(np.uint64) == coset_host).all())
+            assert same_coset, "the reference's own coset NTT and sppark_amd's differ on the timed input"
             r_fwd, r_inv, r_nn = (min(O.ref_ntt_dev_ms("gl64", xr.data_ptr(), lg, o, d_, 0, reps) for _ in range(3))
                                   for o, d_ in ((1, 0), (2, 1), (0, 0)))
+            r_coset = min(O.ref_ntt_dev_ms("gl64", xr.data_ptr(), lg, 1, 0, 1, reps) for _ in range(2))
             ref_build = {"what": "supranational/sppark's own NTT through its HIP path (hipcc -include util/cuda2hip.hpp, gfx950), "
                                  "same box, same device-resident array, NTT::Base_dev_ptr",
-                         "forward_ms": r_fwd, "inverse_ms": r_inv, "forward_nn_ms": r_nn,
-                         "output_equals_ours": same,
-                         "speedup_forward": r_fwd / fwd, "speedup_inverse": r_inv / inv, "speedup_forward_nn": r_nn / fwd_nn}
+                         "forward_ms": r_fwd, "inverse_ms": r_inv, "forward_nn_ms": r_nn, "coset_nr_ms": r_coset,
+                         "output_equals_ours": same, "coset_output_equals_ours": same_coset,
+                         "speedup_forward": r_fwd / fwd, "speedup_inverse": r_inv / inv, "speedup_forward_nn": r_nn / fwd_nn,
+                         "speedup_coset_nr": r_coset / coset_nr}
             del xr
         # HBM traffic of one transform: a CONSTANT from the committed rocprofv3 --pmc passes of this workload
         # (tools/make_ntt_pmc_traffic.py), newest round first; null for any other size
@@ -318,7 +339,8 @@ def main():
                "input": {"elements": 1 << lg, "values": "torch.randint(0, 2^62) on the device, generator seed 2: 2^%d independent values, all distinct positions" % lg,
                          "seed": 2},
                "timing": "HIP events around 20 back-to-back transforms on a non-null stream, best of 3 batches",
-               "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn,
+               "forward_ms": fwd, "inverse_ms": inv, "forward_nn_ms": fwd_nn, "coset_nr_ms": coset_nr,
+               "coset_equals_oracle": coset_ok,
                "through_ffi": through_ffi,
                "reference_hip_build": ref_build,
                "forward_elems_per_s": (1 << lg) / (fwd * 1e-3), "inverse_elems_per_s": (1 << lg) / (inv * 1e-3),
@@ -516,6 +538,33 @@ def main():
             assert ok, "shard-size MSM differs from the oracle"
             shard["msm_ms_at_2^%d" % lgs] = {"ms": ms, "points_per_s": m / (ms * 1e-3), "windows": ctx.plan(m)["windows"], "equals_oracle": ok}
         extras["shard_sizes"] = shard
+        # the headline size on points that do NOT repeat (poc/msm-cuda/tests/msm.rs:19-39 checks against an arbitrary-point
+        # oracle; the BASELINE shape above has 2^11 distinct points): P_i = (a + i b) G generated on the device, the same
+        # uniform scalars, the result against (sum s_i (a + i b) mod r) G -- integer arithmetic + one oracle scalar multiplication
+        try:
+            pa, pb = 0x243f6a8885a308d313198a2e03707344, 0xa4093822299f31d0082efa99
+            dpts = torch.empty((n, 96), dtype=torch.uint8, device="cuda")
+            t1 = time.perf_counter()
+            sppark_amd.generate_progression(dpts, n, pa, pb, 96, "bls12_381")
+            gen_s = time.perf_counter() - t1
+            dout = ctx.invoke(dpts, sc)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(3):
+                dout = ctx.invoke(dpts, sc)
+            torch.cuda.synchronize()
+            d_ms = (time.perf_counter() - t1) / 3 * 1e3
+            s0, s1 = fold.weighted_sums(sc)
+            dexp = O.g1_mul(O.BLS12_381, O.g1_generator(O.BLS12_381), (pa * s0 + pb * s1) % r_mod)
+            ok = bool((sppark_amd.to_affine(dout) == dexp).all())
+            assert ok, "MSM over all-distinct points differs from the known discrete logarithm"
+            extras["all_distinct_points"] = {"distinct_points": n, "ms": d_ms, "points_per_s": n / (d_ms * 1e-3), "equals_known_discrete_log": ok,
+                                             "generate_s": gen_s,
+                                             "what": "P_i = (a + i b) G for i < n, device-resident, the headline's scalars; expected (sum s_i (a + i b) mod r) G"}
+            del dpts
+        except AssertionError:
+            raise
+        except Exception as ex:                                 # noqa: BLE001
+            extras["all_distinct_points_error"] = repr(ex)[:200]
         ctx.enable_timing(True)
         sppark_amd.ffi.load("bls12_381").sppark_msm_release_cached()
 

@@ -67,7 +67,11 @@ SppError mult_pippenger_fp2_inf(void *out, const void *points, size_t npoints,
 /* Not in the reference: which bucket-accumulation kernel mult_pippenger_fp2_inf runs (process-wide).  0 = automatic:
  * a PAIR of waves per 64 mixed additions, one Fp2 component per wave (msm/msm_g2c_kernels.hpp), over the 14-limb base
  * fields (BLS12-381, BLS12-377: 2^22 points 47.8 -> 40.2 ms), one lane per addition over the 10-limb one (alt_bn128);
- * 1 / 2 force either.  Same result either way; the tests run both against the oracle. */
+ * 1 / 2 force either.  Same result either way; the tests run both against the oracle.
+ * A TEST AND TUNING HOOK, not part of the drop-in surface: the switch is one process-wide variable per library, read at the
+ * start of every mult_pippenger_fp2_inf call -- set it while no G2 call of this library is in flight on another thread (a
+ * call that overlaps the change runs entirely under the old or the new value, but which one is unspecified), and set it
+ * back to 0 when done. */
 SppError sppark_msm_g2_path(unsigned mode);
 
 /* poc/msm-cuda/cuda/pippenger.cu:20-25.  points: Affine_t (X | Y, infinity
@@ -192,7 +196,8 @@ SppError sppark_msm_tune_sums(sppark_msm_ctx *ctx, unsigned top_items);
 /* The tail of an MSM.  join: 0 = the record segments of at most eight records (with uniform scalars: all
  * of them) are summed by one launch (k_join_runs) and the fan-in tree only sees the longer ones; 1 = every
  * segment goes through the tree; 2 / 3 = A/B switches: 2 = without the one-launch narrow end of the tree
- * (k_reduce_tail), 3 = without the low-latency bucket-sum kernels for small grids.  k1: buckets per work item of the first bucket-sum level (a power of
+ * (k_reduce_tail), 3 = without the low-latency bucket-sum kernels for small grids, 4 = without the cooperative (four waves
+ * per operation) kernels, 5 = without the piece tree of the small sizes.  k1: buckets per work item of the first bucket-sum level (a power of
  * two; 0 = the same as the other levels). */
 SppError sppark_msm_tune_tail(sppark_msm_ctx *ctx, unsigned join, unsigned k1);
 /* Pipeline shape.  groups: the windows are sorted and accumulated in this many groups, the digits +
@@ -204,8 +209,19 @@ SppError sppark_msm_tune_tail(sppark_msm_ctx *ctx, unsigned join, unsigned k1);
  * the chunk is halved until it fits (0 = what is free). */
 SppError sppark_msm_tune_pipeline(sppark_msm_ctx *ctx, unsigned groups, size_t chunk_points,
                                   size_t max_scratch_bytes);
+/* the sort's side of the plan: out = { point slabs, points per slab, index bits kept in a 4-byte level-A sort record (0: 8-byte
+ * records), log2 slabs per index group, index groups, window groups, first-level bucket chunk, pieces per bucket the piece
+ * tree of a small MSM takes (0: the record list goes through k_join_runs / the fan-in tree) } */
+void sppark_msm_plan_sort(const sppark_msm_ctx *ctx, size_t npoints, unsigned out[8]);
+/* level-A sort records: 0 = 4 bytes unless sppark_msm_tune gives a slab count, 1 = 8 bytes, 2 = 4 bytes also with a given slab
+ * count (the slabs are then the power of two below npoints / nslabs): record format and slab count can be varied independently */
+SppError sppark_msm_tune_records(sppark_msm_ctx *ctx, unsigned records);
 /* chunks the last invoke was cut into / window groups the context would use for npoints */
 unsigned sppark_msm_last_chunks(const sppark_msm_ctx *ctx);
+/* invocations of this context whose record list and bucket sums ran twice: small MSMs sum the pieces of a bucket by a tree sized
+ * for the average bucket (msm_piece_kernels.hpp); a bucket beyond that size (skewed scalars) is found after the fact and the
+ * fan-in tree then runs over what was left.  A counter for tests and tuning; the result is exact either way. */
+unsigned sppark_msm_tail_redone(const sppark_msm_ctx *ctx);
 unsigned sppark_msm_plan_groups(const sppark_msm_ctx *ctx, size_t npoints);
 SppError sppark_msm_reserve(sppark_msm_ctx *ctx, size_t npoints, size_t ffi_affine_sz,
                             int host_points, int host_scalars);

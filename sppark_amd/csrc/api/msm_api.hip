@@ -445,6 +445,7 @@ SPPARK_FFI RustError sppark_msm_tune_tail(sppark_msm_ctx* ctx, unsigned join, un
 SPPARK_FFI RustError sppark_msm_tune_pipeline(sppark_msm_ctx* ctx, unsigned groups, size_t chunk_points, size_t max_scratch_bytes)
 {   return guarded([&] { ctx->impl.tune.groups = groups; ctx->impl.tune.chunk = chunk_points; ctx->impl.tune.max_scratch = max_scratch_bytes; });   }
 SPPARK_FFI unsigned sppark_msm_last_chunks(const sppark_msm_ctx* ctx) { return ctx->impl.chunks_of_last_invoke(); }
+SPPARK_FFI unsigned sppark_msm_tail_redone(const sppark_msm_ctx* ctx) { return ctx->impl.tail_redone(); }
 SPPARK_FFI RustError sppark_msm_reserve(sppark_msm_ctx* ctx, size_t npoints, size_t ffi_affine_sz,
                                         int host_points, int host_scalars)
 {   return guarded([&] { ctx->impl.reserve_for(npoints, ffi_affine_sz, host_points, host_scalars); });   }
@@ -478,6 +479,16 @@ SPPARK_FFI void sppark_msm_plan(const sppark_msm_ctx* ctx, size_t npoints, unsig
     msm_plan p = ctx->impl.plan_for(npoints);
     out[0] = p.wbits; out[1] = p.nwins; out[2] = p.NB; out[3] = p.L; out[4] = p.NA; out[5] = p.LB; out[6] = p.F; out[7] = p.K;
 }
+// the sort's side of the plan: out = { slabs, points per slab, index bits kept in a 4-byte level-A record (0: 8-byte records),
+// log2 slabs per index group, index groups, window groups, first-level bucket chunk, pieces per bucket the piece tree takes }
+SPPARK_FFI void sppark_msm_plan_sort(const sppark_msm_ctx* ctx, size_t npoints, unsigned out[8])
+{
+    msm_plan p = ctx->impl.plan_for(npoints);
+    out[0] = p.nslabs; out[1] = p.slab_sz; out[2] = p.IB; out[3] = p.SH; out[4] = p.NG; out[5] = p.G; out[6] = p.K1;
+    out[7] = ctx->impl.piece_tree_cmax(p, p.G > 1, 0);
+}
+SPPARK_FFI RustError sppark_msm_tune_records(sppark_msm_ctx* ctx, unsigned records)
+{   return guarded([&] { if (records > 2) throw hip_error(-(int)hipErrorInvalidValue, "tune_records"); ctx->impl.tune.records = records; });   }
 // window groups the context would use for |npoints|
 SPPARK_FFI unsigned sppark_msm_plan_groups(const sppark_msm_ctx* ctx, size_t npoints) { return ctx->impl.plan_for(npoints).G; }
 

@@ -802,6 +802,7 @@ private:
         }
     }
 
+public:
     // pieces per bucket the piece tree of a small MSM takes, 0 = the record list goes through k_join_runs / the fan-in tree:
     // one window group, not the fixed-base window, buckets longer than the join's walk, at most 2^10 pieces
     // (tune.join 5: never -- the A/B switch)
@@ -812,6 +813,7 @@ private:
         const unsigned c = piece_cmax((size_t)p.n / p.NB / p.L + 1);
         return c <= 1024 ? c : 0;
     }
+private:
 
     // Horner over the window sums (the reference's host-side collect, pippenger.cuh:627-727, is O(256 * windows))
     static point_t horner(const std_bucket_t* sums, const msm_plan& p)

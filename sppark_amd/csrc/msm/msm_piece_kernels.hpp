@@ -58,9 +58,13 @@ SPPARK_DEVFN piece_job piece_job_of(u32* rec_key, const u32* off, unsigned NB, u
                                     unsigned cmax, unsigned t, unsigned last, u32* any_long, size_t id)
 {
     piece_job j; j.live = j.add = j.finish = false; j.dst = j.src = 0; j.B = 0;
+    // pair-major: lane l of a wave is bucket B0 + l of ONE pair index m, so the waves of the pair indices beyond the
+    // average bucket's pieces (cmax has 3 x head-room) hold no work at all and leave at once, and those that stay are full
+    // (bucket-major, a wave was 64 pair indices of one bucket: a quarter of its lanes busy, four times the waves)
     const unsigned pm = cmax >> (t + 1);
-    const size_t B = id / pm; const unsigned m = (unsigned)(id % pm);
-    if (B >= (size_t)nwins * NB) return j;
+    const size_t nb = (size_t)nwins * NB;
+    const size_t B = id % nb; const unsigned m = (unsigned)(id / nb);
+    if (m >= pm) return j;
     const piece_geom g = piece_geometry(off, NB, L, chunks_per_win, (unsigned)(B / NB), (unsigned)(B % NB));
     if (g.cnt == 0) return j;
     if (g.cnt > cmax) { if (t == 0 && m == 0) *any_long = 1; return j; }

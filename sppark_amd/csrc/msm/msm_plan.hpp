@@ -26,6 +26,7 @@ struct msm_plan {
 struct msm_tunables {                   // 0 = automatic
     unsigned wbits = 0, L = 0, F = 0, K = 0, nslabs = 0, LB = 0;
     unsigned big = 0;                   // level-A partitions above this many entries are sorted cooperatively (0 = 2^18)
+    unsigned records = 0;               // level-A sort records: 0 = 4 bytes unless a slab count is given, 1 = 8 bytes, 2 = 4 bytes also with a given slab count (rounded to power-of-two slabs)
     unsigned groups = 0;                // window groups (1 = everything on one stream)
     unsigned top = 0;                   // bucket sums: items per window handed to the subset-sum top (0 = 4096, 1 = never)
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
@@ -124,7 +125,8 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.slab_sz = (p.n + p.nslabs - 1) / p.nslabs;
     // 4-byte level-A records: sign | index mod 2^IB | k_lo, IB = 31 - LB; the index bits above IB follow from the position of
     // a record in its partition, which needs slabs of a power of two <= 2^IB points (so that an index group is a whole
-    // number of slabs) and at most 128 groups.  Not with an explicit slab count (the tunable means what it says).
+    // number of slabs) and at most 128 groups.  Not with an explicit slab count (the tunable means what it says) unless
+    // tunables.records = 2 asks for both (the slabs are then the power of two below n / nslabs); records = 1: never.
     p.IB = p.SH = 0; p.NG = 1;
     if (!t.nslabs && p.LB < 16) {
         const unsigned IB = 31 - p.LB;
@@ -132,7 +134,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
         // not 33 of 2^21, which would be two rounds of twice the work on 256 compute units instead of three)
         const unsigned lgs = std::min(lg2_floor(p.slab_sz ? p.slab_sz : 1), IB);
         const size_t ss = (size_t)1 << lgs, ns = (npoints + ss - 1) / ss, ng = (((ns ? ns : 1) - 1) >> (IB - lgs)) + 1;
-        if (ng <= 128 && ns <= 4096) { p.slab_sz = (unsigned)ss; p.nslabs = (unsigned)std::max<size_t>(1, ns); p.IB = IB; p.SH = IB - lgs; p.NG = (unsigned)ng; }
+        // (at most 2 * 64 + 1 slabs: the heuristic's 64, doubled by the rounding, plus a ragged one -- what the per-slab
+        // histograms H and k_scan_slabs' serial loop are sized for)
+        if (ng <= 128 && ns <= 129) { p.slab_sz = (unsigned)ss; p.nslabs = (unsigned)std::max<size_t>(1, ns); p.IB = IB; p.SH = IB - lgs; p.NG = (unsigned)ng; }
     }
     // fan-in of the record tree (< 3 would never shrink the list): 4 up to 2^20 points, where the buckets are longer
     // than the join's walk and the tree does the work -- one addition per work item and level instead of three
@@ -146,7 +150,9 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     p.K = std::min(p.K, p.NB);
     // first level: 16 buckets per work item once a window has >= 2^21 of them (2^26 points: tail 11.35 -> 11.03 ms)
     // 8 where that hands 4096 partial sums per window straight to the subset-sum top (2^15 buckets: no chunked level at all)
-    p.K1 = std::min(t.K1 ? t.K1 : (p.NB >= (1u << 21) ? 16u : p.NB == (1u << 15) ? 8u : p.K), p.NB);
+    // (round 6, profiles/r06_msm_sums_sweep.log: 2^14 buckets likewise -- 2^18 points, tail 0.69 -> 0.64 ms; 128 buckets --
+    // 2^15 / 2^16 points -- go to the top as they are, the first level only replaces the buckets without entries: 0.51 -> 0.48 ms)
+    p.K1 = std::min(t.K1 ? t.K1 : (p.NB >= (1u << 21) ? 16u : (p.NB == (1u << 15) || p.NB == (1u << 14)) ? 8u : p.NB == 128u ? 1u : p.K), p.NB);
     // window groups: ONE by default.  Measured on MI355X (profiles/r02_msm_groups.log): whatever
     // the sort of the next group gains by running beside k_accumulate, the accumulation loses --
     // 2^26 points: 168.5 ms with one group, 169-190 ms with 2..12 groups, with the sort stream on

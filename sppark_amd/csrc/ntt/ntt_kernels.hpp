@@ -546,7 +546,9 @@ SPPARK_DEVFN void ntt_rx_run(F* data, F* lds, const ntt_tables<F>& T, const ntt_
 {
     constexpr unsigned MAXLG = ntt_small_cap<F>::value;
     static_assert(LGC <= MAXLG && (LGC == 0 || LGC >= 7), "a compiled-in size fills at least one wave");
-    const unsigned lg = LGC ? LGC : T.lg_n, nh = 1u << (lg - 1);
+    // (a one-element "transform" has no pair: every lane idle, nothing read or written -- the driver returns before it gets
+    // here, ntt_engine::run, but the kernel is safe on its own)
+    const unsigned lg = LGC ? LGC : T.lg_n, nh = lg ? 1u << (lg - 1) : 0u;
     const bool live = l < nh;
     const unsigned lq = live ? l : 0;                           // (idle lanes read the tables at valid indices)
     F x0 = F(), x1 = F(), sum, dif, g0 = F(), g1 = F(), w[MAXLG];

@@ -96,6 +96,11 @@ def load(name):
         L.sppark_msm_tune_pipeline.restype = _Error
         L.sppark_msm_last_chunks.argtypes = [vp]
         L.sppark_msm_last_chunks.restype = cu
+        L.sppark_msm_plan_sort.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint * 8)]
+        L.sppark_msm_tune_records.argtypes = [vp, cu]
+        L.sppark_msm_tune_records.restype = _Error
+        L.sppark_msm_tail_redone.argtypes = [vp]
+        L.sppark_msm_tail_redone.restype = cu
         L.sppark_msm_plan_groups.argtypes = [vp, sz]
         L.sppark_msm_plan_groups.restype = cu
         L.sppark_batch_addition.argtypes = [vp, vp, sz, vp, vp, sz]

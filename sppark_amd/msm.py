@@ -109,6 +109,10 @@ class MsmContext:
     def last_chunks(self):
         return int(self.L.sppark_msm_last_chunks(self.h))
 
+    def tail_redone(self):
+        """invocations whose tail ran twice: the piece tree of a small MSM met a bucket beyond its size (skewed scalars)"""
+        return int(self.L.sppark_msm_tail_redone(self.h))
+
     def plan_groups(self, npoints):
         return int(self.L.sppark_msm_plan_groups(self.h, npoints))
 
@@ -129,7 +133,17 @@ class MsmContext:
         out = (ctypes.c_uint * 8)()
         self.L.sppark_msm_plan(self.h, npoints, ctypes.byref(out))
         keys = ("window_bits", "windows", "buckets_per_window", "run_length", "partitions", "low_bits", "fan_in", "bucket_chunk")
-        return dict(zip(keys, [int(v) for v in out]))
+        d = dict(zip(keys, [int(v) for v in out]))
+        self.L.sppark_msm_plan_sort(self.h, npoints, ctypes.byref(out))
+        keys = ("slabs", "slab_points", "record_index_bits", "lg_slabs_per_group", "index_groups", "window_groups", "first_bucket_chunk", "piece_tree_max")
+        d.update(zip(keys, [int(v) for v in out]))
+        d["packed_records"] = d["record_index_bits"] != 0
+        return d
+
+    def tune_records(self, records=0):
+        """level-A sort records: 0 = automatic (4 bytes unless tune(nslabs=...) is given), 1 = 8 bytes, 2 = 4 bytes also with a
+        given slab count"""
+        ffi.check(self.L, self.L.sppark_msm_tune_records(self.h, records))
 
     def set_points(self, points, npoints=None, ffi_affine_sz=None, fixed_base=False):
         """Keep a copy of the bases in HBM (msm_t(points, np, ffi_affine_sz),
@@ -239,7 +253,10 @@ def batch_addition(points, bitmap, refmap=None, curve="bls12_381", ffi_affine_sz
 
 def set_g2_path(mode, curve="bls12_381"):
     """sppark_msm_g2_path: the accumulation kernel of the G2 entry point (process-wide per library): 0 = automatic
-    (a pair of waves per addition, one Fp2 component each, for the 14-limb base fields), 1 = wave pairs, 2 = one lane."""
+    (a pair of waves per addition, one Fp2 component each, for the 14-limb base fields), 1 = wave pairs, 2 = one lane.
+    A test / tuning hook: not thread-safe against G2 calls in flight (include/sppark_amd.h)."""
+    if curve in ffi.NO_G2:
+        raise ffi.SpparkError(-1, "%s has no G2 (no pairing): no sppark_msm_g2_path" % curve)
     L = ffi.load(curve)
     ffi.check(L, L.sppark_msm_g2_path(int(mode)))
 

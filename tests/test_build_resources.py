@@ -116,6 +116,41 @@ def test_g2_one_component_per_wave_kernel_fits_two_waves_per_simd(obj):
     assert 4 * int(md.get("group_segment_fixed_size") or 0) <= 160 * 1024, md
 
 
+def test_g2_wave_pair_kernel_keeps_its_barriers_paired():
+    """k_accumulate_g2c branches on the wave's role into two separately inlined walks, each with its own copies of the
+    work-group barriers (msm_g2c_kernels.hpp): correct because s_barrier on gfx9 counts WAVES, not program addresses, and both
+    walks execute the same number of barriers in the same order (the host emulation runs the pair as threads over a counting
+    barrier and would hang otherwise).  What a compiler could do to that -- merge the tails of the two walks, drop or
+    duplicate a barrier on one side -- shows in the emitted code: the static number of s_barrier instructions of the
+    kernel must stay even, half of them before the second walk's first barrier (the walks are emitted one after the
+    other), and the object must have been built for gfx950 (the one architecture this reasoning is made for)."""
+    import subprocess
+    import isa_stats
+    path = os.path.join(OBJ, "bls12_381__msm_k_accumulate.hip__SPPARK_G2.o")
+    if not os.path.exists(path):
+        pytest.skip("not built here")
+    co = isa_stats.code_object(path)
+    hdr = subprocess.run([isa_stats.LLVM + "/llvm-readelf", "-h", co], capture_output=True, text=True).stdout
+    assert "gfx950" in hdr, hdr[-400:]
+    dis = subprocess.run([isa_stats.LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+    body, on = [], False
+    for line in dis.splitlines():
+        if line.endswith(">:"):
+            on = "k_accumulate_g2c" in line
+            continue
+        if on:
+            body.append(line.split()[0] if line.split() else "")
+    bars = [i for i, op in enumerate(body) if op == "s_barrier"]
+    assert len(bars) >= 8 and len(bars) % 2 == 0, len(bars)
+    # the same number of instructions between consecutive barriers in both walks, within the difference the two components'
+    # arithmetic makes (component 1 of a product is a sum, component 0 a difference of two base products)
+    half = len(bars) // 2
+    gaps0 = [bars[i + 1] - bars[i] for i in range(half - 1)]
+    gaps1 = [bars[half + i + 1] - bars[half + i] for i in range(half - 1)]
+    for a, b in zip(gaps0, gaps1):
+        assert abs(a - b) <= 0.25 * max(a, b) + 192, (gaps0, gaps1)
+
+
 @pytest.mark.parametrize("unit,feature", [("api/ntt_api.hip", "FEATURE_GOLDILOCKS"), ("api/ntt_api.hip", "FEATURE_BLS12_381 -DSPPARK_NTT_WITH_MSM"),
                                           ("api/msm_api.hip", "FEATURE_BN254")])
 def test_tuning_build_still_compiles(unit, feature):

@@ -333,6 +333,42 @@ def test_msm_tail_variants(oracle, libs, curve, name):
     ctx.close()
 
 
+@pytest.mark.parametrize("curve,name", CURVES)
+def test_msm_piece_tree_of_small_sizes(oracle, libs, curve, name):
+    """Small MSMs (up to 2^16 points: a few buckets of hundreds of entries per window) sum the pieces of a bucket by a tree over
+    the bucket's own pieces (msm_piece_kernels.hpp), sized for the average bucket; the fan-in tree is run AFTERWARDS, and the
+    bucket sums again, only when the device reports a bucket beyond that size.  Uniform scalars at the automatic plan and at
+    forced ones (aligned / unaligned bucket starts, odd piece counts, ragged sizes): against the oracle and WITHOUT a second
+    pass; all scalars equal, a mix, 16-bit scalars, every second scalar zero: against the oracle, the heavy buckets through the
+    second pass; the same calls with the piece tree switched off (tune_tail 5) and without the cooperative kernels (4)."""
+    import sppark_amd
+    O = oracle
+    ctx = sppark_amd.MsmContext(name)
+    for n, plans in ((1 << 12, (dict(), dict(wbits=5, L=7))), (5000, (dict(), dict(wbits=6, L=16))), ((1 << 15) + 17, (dict(),)),
+                     (1 << 16, (dict(), dict(wbits=9, L=8)))):
+        pts, sc = recipe.msm_inputs(curve, n, 31 + n, ndistinct=700, flagged=True, edge=True)
+        s_eq = sc.copy(); s_eq[:] = sc[2]
+        s_mix = sc.copy(); s_mix[n // 5:] = sc[1]
+        s_16 = np.zeros_like(sc); s_16[:, :2] = sc[:, :2]
+        s_half = sc.copy(); s_half[::2] = 0
+        for what, s_ in (("uniform", sc), ("equal", s_eq), ("mix", s_mix), ("16-bit", s_16), ("half zero", s_half)):
+            if n > 5000 and what in ("16-bit", "half zero") and curve != 0:
+                continue
+            exp = O.msm_affine(curve, pts, s_, algo=0, param=8)
+            for plan in plans:
+                for join in (0, 5, 4):
+                    ctx.tune(**plan); ctx.tune_tail(join, 0)
+                    before = ctx.tail_redone()
+                    out = ctx.invoke(pts, s_, ffi_affine_sz=pts.shape[1])
+                    assert (sppark_amd.to_affine(out, name) == exp).all(), (n, what, plan, join)
+                    redone = ctx.tail_redone() - before
+                    if join == 5 or what == "uniform":
+                        assert redone == 0, (n, what, plan, join)
+                    if join != 5 and what == "equal":
+                        assert redone == 1, (n, what, plan, join)
+    ctx.close()
+
+
 def test_msm_skewed_scalars(oracle, libs):
     """SURVEY 8(d) skew cases: all scalars equal, 50% zeros, 16-bit scalars,
     all points equal."""

@@ -46,7 +46,7 @@ def _check(p, n, bits):
     if p["IB"]:
         assert p["IB"] + p["LB"] == 31 and p["slab_sz"] & (p["slab_sz"] - 1) == 0 and p["slab_sz"] << p["SH"] == 1 << p["IB"]
         assert p["NG"] == ((p["nslabs"] - 1) >> p["SH"]) + 1 and 1 <= p["NG"] <= 128 and n <= p["NG"] << p["IB"]
-        assert (p["nslabs"] - 1) * p["slab_sz"] < n and p["nslabs"] <= 4096
+        assert (p["nslabs"] - 1) * p["slab_sz"] < n and p["nslabs"] <= 129
     else:
         assert p["SH"] == 0 and p["NG"] == 1
     assert p["F"] >= 4                                                                # (< 3 would never shrink the record list)

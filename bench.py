@@ -323,7 +323,7 @@ def main():
         # HBM traffic of one transform: a CONSTANT from the committed rocprofv3 --pmc passes of this workload
         # (tools/make_ntt_pmc_traffic.py), newest round first; null for any other size
         ntt_traffic, ntt_traffic_note = None, ""
-        for fn in ("r05_ntt_gl64_pmc.json",):
+        for fn in ("r06_ntt_gl64_pmc.json", "r05_ntt_gl64_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     pmc = json.load(f)
@@ -613,9 +613,9 @@ def main():
         nwins = plan["windows"]
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the timed run, so the
         # value is a CONSTANT read from the committed rocprofv3 --pmc passes of this same workload
-        # (profiles/r05_pmc_traffic.json, else r04 / r03 / ...), not an in-run measurement; null for any other workload.
+        # (profiles/r06_pmc_traffic.json, else r05 / r04 / ...), not an in-run measurement; null for any other workload.
         traffic, traffic_note = None, ""
-        for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     pmc = json.load(f)

@@ -23,6 +23,7 @@ extern template __global__ void k_join_runs<msm_fp_d>(bucket_m*, u32*, const u32
 extern template __global__ void k_reduce_tail<msm_fp_d>(bucket_m*, u32*, bucket_m*, u32*, bucket_m*, unsigned, unsigned, const u32*);
 extern template __global__ void k_piece_level<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
                                                         unsigned, unsigned, unsigned, u32*);
+extern template __global__ void k_bucket_small_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const u32*, unsigned, unsigned);
 extern template __global__ void k_piece_level_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
                                                              unsigned, unsigned, unsigned, u32*);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
@@ -257,6 +258,16 @@ SPPARK_FFI RustError mult_pippenger_fp2_inf(void* out, const void* points, size_
     return guarded([&] {
         borrowed<msm2_impl> msm(-1);
         msm->tune.g2_coop = g2_path.load(std::memory_order_relaxed);
+#ifdef SPPARK_TUNING
+        // tuning builds: the plan knobs of the pooled G2 context (tools/gpu_g2_bench.py sweeps them)
+        {
+            struct g2k { const char* name; unsigned msm_tunables::*f; };
+            static const g2k ks[] = {{"SPPARK_G2_WBITS", &msm_tunables::wbits}, {"SPPARK_G2_L", &msm_tunables::L}, {"SPPARK_G2_F", &msm_tunables::F},
+                                     {"SPPARK_G2_K", &msm_tunables::K}, {"SPPARK_G2_K1", &msm_tunables::K1}, {"SPPARK_G2_TOP", &msm_tunables::top},
+                                     {"SPPARK_G2_JOIN", &msm_tunables::join}};
+            for (const g2k& k : ks) { const char* e = getenv(k.name); msm->tune.*(k.f) = e ? (unsigned)atoi(e) : 0u; }    // (pooled context: absent = automatic again)
+        }
+#endif
         if (is_device_pointer(points) || is_device_pointer(scalars)) HIP_OK(hipDeviceSynchronize());
         point2_t r;
         msm->invoke(r, points, npoints, scalars, false, ffi_affine_sz);

@@ -191,15 +191,58 @@ template<class P, int LB> struct montx_dev {
     SPPARK_DEVFN static montx_dev one()
     {   montx_dev r; for (int j = 0; j < NL; j++) r.l[j] = pow2_tab<RBITS - 32 * NW>::T.l[j]; SPPARK_BND(r.bnd_set(1.0, 1.0);) return r;   }
 
-    // standard wire form (x * 2^(32 NW), 32-bit words, canonical) -> internal (x * 2^RBITS),
-    // normalised, < 2p:  w * 2^(2*RBITS - 32 NW) / 2^RBITS
+    // standard wire form (x * 2^(32 NW), 32-bit words, canonical) -> internal (x * 2^RBITS), normalised, < 2p.
+    // The two domains differ by 2^SH, SH = RBITS - 32 NW (8 bits on fourteen 28-bit limbs, 5 on nine 29-bit ones), so the
+    // conversion is a SHIFT and the subtraction of a small multiple of p -- not a product (round 6: k_convert_points did two
+    // 14 x 14 products + reductions per point, 787 of its 1030 vector instructions, and ran 3.9 ms at 2^26 points for 15 GB
+    // of traffic).  With t = w 2^SH < 2^SH p and the quotient estimate
+    //     q = (top32(w) * QM) >> (62 - SH),   top32 = bits [PB - 32, PB) of the value, QM = floor(2^62 / (top32(p) + 1)),
+    // q <= floor(t / p) (both roundings go down) and q >= floor(t / p) - 1 (together they lose less than 2^(SH - 29) <= 2^-5;
+    // ten 28-bit limbs over a 254-bit field, alt_bn128's G2, have SH = 24), so t - q p is in [0, 2p).  Canonical input
+    // (w < p) is the wire format's contract; any w < 2^PB still lands below 2p.
+    // (plain constexpr: evaluated for the constants below by the host AND the device pass of a translation unit)
+    static constexpr int mod_bits()
+    {
+        int i = NW - 1;
+        while (i > 0 && P::MOD[i] == 0) i--;
+        int b = 32;
+        while (b > 1 && !((P::MOD[i] >> (b - 1)) & 1)) b--;
+        return 32 * i + b;
+    }
+    static constexpr int SH = RBITS - 32 * NW, PB = mod_bits(), TB = PB - 32;
+    static_assert(SH >= 0 && SH < LB && SH <= 24 && PB > 64 && PB <= 32 * NW, "shift conversion: domain offset and modulus size");
+    static constexpr u32 top32(const u32* w)                  // bits [TB, TB + 32)
+    {
+        const int wi = TB >> 5, sh = TB & 31;
+        u64 two = w[wi];
+        if (wi + 1 < NW) two |= (u64)w[wi + 1] << 32;
+        return (u32)(two >> sh);
+    }
+    static constexpr u64 PT = (u64)top32(P::MOD) + 1;
+    static constexpr u32 QM = (u32)(((u64)1 << 62) / PT);           // < 2^31: top32(p) has its top bit set
+    SPPARK_DEVFN static constexpr u32 limb_of_shifted(const u32* w, int j)      // limb j of w * 2^SH
+    {
+        const int bit = LB * j - SH;
+        if (bit < 0) return (u32)((u64)w[0] << (-bit)) & MASK;
+        const int wi = bit >> 5, sh = bit & 31;
+        if (wi >= NW) return 0;
+        u64 two = w[wi];
+        if (wi + 1 < NW) two |= (u64)w[wi + 1] << 32;
+        return j == NL - 1 ? (u32)(two >> sh) : (u32)(two >> sh) & MASK;
+    }
     SPPARK_DEVFN static montx_dev from_std(const u32* w)
     {
-        montx_dev a, k;
+        const u32 q = (u32)(((u64)top32(w) * QM) >> (62 - SH));
+        montx_dev r;
+        long long c = 0;
         #pragma unroll
-        for (int j = 0; j < NL; j++) { a.l[j] = limb_of(w, j); k.l[j] = pow2_tab<2 * (RBITS - 32 * NW)>::T.l[j]; }
-        SPPARK_BND(a.bnd_set(1.0, 1.0); k.bnd_set(1.0, 1.0);)       // canonical wire words, a constant below p
-        return a * k;
+        for (int j = 0; j < NL; j++) {
+            c += (long long)limb_of_shifted(w, j) - (long long)((u64)q * mod_limb(j));
+            r.l[j] = j == NL - 1 ? (u32)c : ((u32)c & MASK);
+            c >>= LB;
+        }
+        SPPARK_BND(r.bnd_set(2.0, 1.0);)                            // in [0, 2p), limbs normalised (see above)
+        return r;
     }
     // internal (any admissible lazy value: limbs < 2^31) -> canonical standard wire words:
     // v * 2^(32 NW) / 2^RBITS, then the conditional subtraction and re-limbing

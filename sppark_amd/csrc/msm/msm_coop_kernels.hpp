@@ -301,3 +301,38 @@ void k_piece_level_coop(xyzz_mem<FP::N>* __restrict__ buckets, u32* __restrict__
 }
 
 } // namespace sppark_amd
+
+namespace sppark_amd {
+
+// ---------------------------------------------------------------------------
+// The bucket sums of a SMALL window (NB = 2^m <= 256 buckets: MSMs of up to 2^16 points) straight from the buckets:
+//     sum_{j = 1 .. NB} j B_{j-1}  =  sum_{b = 0 .. m} 2^b S_b,      S_b = sum of the buckets whose 1-BASED number has bit b set.
+// Work-group (b, w) gathers the NB / 2 buckets of S_b (b = m: the single bucket number NB) -- the buckets without entries are
+// taken as infinity from the sort's offsets, which is all the first chunked level did for such windows -- sums them by the
+// cooperative tree, doubles b times and leaves part b; k_bucket_top_sum_coop adds the m + 1 parts of a window as before.
+// Against k_bucket_level1_coop + k_bucket_top_bits_coop: one launch less, no plain-sum part of twice the items (the 0-based
+// form carries sum_j B_j as a part of its own), a tree of log2(NB / 2) levels instead of log2(NB).
+// 2^12 points (8 buckets): 0.142 -> 0.07 ms of bucket sums; 2^16 (128 buckets): 0.19 -> 0.17 (profiles/r06_msm_small_sums_ab.log).
+// ---------------------------------------------------------------------------
+template<class FP>
+__global__ __launch_bounds__(COOP_NT)
+void k_bucket_small_bits_coop(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ buckets,
+                              const u32* __restrict__ off, unsigned NB, unsigned m)
+{
+    __shared__ coop_lds<FP> ex;
+    __shared__ coop_img<FP, SMALL_SUMS_MAX_NB / 2> img;
+    const unsigned b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const unsigned cnt = b >= m ? 1u : NB / 2;
+    if (tid < SMALL_SUMS_MAX_NB / 2) img.store(tid, small_sums_gather<FP>(buckets, off, NB, m, b, w, tid));
+    coop_barrier();
+    coop_ctx<FP> c{&ex, tid >> 6, tid & 63, 0};
+    if (cnt > 1) coop_tree_sum<FP, SMALL_SUMS_MAX_NB / 2>(&img, cnt / 2, c);
+    xyzz_dev<FP> x;
+    if (c.lane == 0) x = img.load(0); else x.set_inf();
+    #pragma unroll 1
+    for (unsigned k = 0; k < b; k++) coop_dbl<FP>(x, c);
+    if (tid == 0) x.store(&parts[(size_t)w * (m + 1) + b]);
+}
+
+} // namespace sppark_amd
+

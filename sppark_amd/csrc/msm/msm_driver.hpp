@@ -35,6 +35,7 @@
 #include "../ec/jacobian_host.hpp"
 #include "../util/runtime.hpp"
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -133,7 +134,7 @@ private:
         l.keyA = take(nrecA * 4); l.ptA = take(nrecA * sizeof(bucket_t));
         l.keyB = take(nrecB * 4); l.ptB = take(nrecB * sizeof(bucket_t));
         l.keyC = take(nrecA * 4); l.flag = take(4);                 // k_join_runs: filtered keys, "a long segment exists"
-        size_t n1 = (size_t)p.nwins * (p.NB / p.K1);
+        size_t n1 = (size_t)p.nwins * std::max<size_t>(p.NB / p.K1, lg2_floor(p.NB) + 1);      // (the small windows' m + 1 parts: k_bucket_small_bits_coop)
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n1 * sizeof(bucket_t)); l.W2 = take(n1 * sizeof(bucket_t));
         l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
@@ -718,7 +719,24 @@ private:
         bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
         bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
         bucket_t* result;
-        {
+        // windows of up to 256 buckets (MSMs of up to 2^16 points): the subset sums straight from the buckets, then the parts of a
+        // window (msm_coop_kernels.hpp k_bucket_small_bits_coop); needs the offsets of every window: one window group
+        bool small_sums = false;
+        if constexpr (MONTX)
+            small_sums = !multi && fb_n == 0 && p.NB <= SMALL_SUMS_MAX_NB && p.NB >= 2 && tune.K1 == 0 && tune.top == 0 && tune.K == 0
+                         && tune.join != 3 && tune.join != 4;
+        if constexpr (MONTX) {
+            if (small_sums) {
+                const unsigned m = lg2_floor(p.NB);
+                hipLaunchKernelGGL(k_bucket_small_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), 0, stream,
+                                   A2, buckets, (const u32*)(blob + l.off[0]), p.NB, m);
+                HIP_OK(hipGetLastError());
+                hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, W2, A2, m);
+                HIP_OK(hipGetLastError());
+                result = W2;
+            }
+        }
+        if (!small_sums) {
             unsigned nitems = p.NB / p.K1;
             size_t nthr = (size_t)p.nwins * nitems;
             // grids of at most one resident round (one wave per SIMD: 65 536 lanes) are chains of dependent additions:
@@ -810,7 +828,17 @@ public:
     {
         if (multi || fb_n || tune.join == 5 || tune.join == 1) return 0;
         if ((size_t)p.n / p.NB <= (size_t)4 * p.L) return 0;
-        const unsigned c = piece_cmax((size_t)p.n / p.NB / p.L + 1);
+        // The TOP window is not uniform even for uniform scalars: the recoding folds s > r/2 to r - s, so its digit is at most
+        // (r/2) >> off_top and each of its buckets holds n 2^off_top / (r/2) entries -- BLS12-377's r = 0x12ab... in 4-bit
+        // windows: 0.43 n in one bucket against the average n / 8.  The tree is sized for that bucket too (the other short
+        // windows at the top are at most twice the average: within piece_cmax's head-room).
+        const unsigned off_top = p.nbits - window_len(p.nwins - 1, p.nwins, p.nbits);
+        long double r = 0;
+        for (int i = FRp::N - 1; i >= 0; i--) r = r * 4294967296.0L + (long double)FRp::MOD[i];
+        long double frac = ldexpl(1.0L, (int)off_top) / (r / 2);
+        if (frac > 1.0L) frac = 1.0L;
+        const size_t top_pieces = (size_t)((long double)p.n * frac / p.L) + 2;
+        const unsigned c = std::max(piece_cmax((size_t)p.n / p.NB / p.L + 1), piece_cmax_exact(top_pieces + top_pieces / 4 + 4));
         return c <= 1024 ? c : 0;
     }
 private:

@@ -602,6 +602,22 @@ SPPARK_DEVFN xyzz_dev<FP> bucket_top_sum_gather(const xyzz_mem<FP::N>* parts, un
     return acc;
 }
 
+// the small windows' form of the same sum, straight from the buckets (k_bucket_small_bits_coop, msm_coop_kernels.hpp)
+static constexpr unsigned SMALL_SUMS_MAX_NB = 256;
+// the t-th (0-based) bucket NUMBER in 1 .. NB with bit b set; b == m: NB itself
+SPPARK_DEVFN unsigned small_sums_member(unsigned b, unsigned m, unsigned t)
+{   return b >= m ? (1u << m) : ((((t >> b) << 1) | 1u) << b) | (t & ((1u << b) - 1u));   }
+
+template<class FP>
+SPPARK_DEVFN xyzz_dev<FP> small_sums_gather(const xyzz_mem<FP::N>* buckets, const u32* off, unsigned NB, unsigned m,
+                                            unsigned b, unsigned w, unsigned t)
+{
+    xyzz_dev<FP> r; r.set_inf();
+    if (t >= (b >= m ? 1u : NB / 2)) return r;
+    const unsigned j = small_sums_member(b, m, t) - 1;              // 0-based bucket
+    return bucket_load<FP>(buckets + (size_t)w * NB, off + (size_t)w * (NB + 1), j);
+}
+
 template<class FP>
 __global__ __launch_bounds__(BUCKET_TOP_NT, 2)
 void k_bucket_top_bits(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ A,

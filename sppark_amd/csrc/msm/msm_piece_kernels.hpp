@@ -107,12 +107,12 @@ void k_piece_level(xyzz_mem<FP::N>* __restrict__ buckets, u32* __restrict__ rec_
 // the top window: it is a bit shorter than the others when the scalar bits do not divide evenly, and the modulus cuts its
 // range -- BLS12-381's r = 0x73ed... leaves 115 of the 128 values of a 7-bit top window, all of magnitude <= 64: 2.2 x the
 // entries per bucket.  The extra levels are launches of a few lanes that find nothing to add.)
-static inline unsigned piece_cmax(size_t avg_pieces)
+static inline unsigned piece_cmax_exact(size_t want)            // the power of two >= want
 {
-    size_t want = 3 * avg_pieces + 4;
     unsigned c = 2;
     while (c < want && c < 4096) c <<= 1;
     return c;
 }
+static inline unsigned piece_cmax(size_t avg_pieces) { return piece_cmax_exact(3 * avg_pieces + 4); }
 
 } // namespace sppark_amd

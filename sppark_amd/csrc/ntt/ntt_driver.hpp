@@ -323,6 +323,7 @@ public:
         // constants (r64_coset_mode, ntt_r64_kernels.hpp): no separate scaling launch (2^24: 0.217 -> 0.19 ms)
         unsigned cmode = 0;
         const F* r64_czp = nullptr;
+        const F* top_crow = nullptr;
         if (R64 && lg >= 12 && lg >= knobs.r64_min) {
             rp = make_r64_plan(lg);
             cmode = knobs.coset_fold ? r64_coset_mode(rp, gs, inverse != 0, type == NTT_COSET && order != NTT_RR) : 0;
@@ -339,7 +340,14 @@ public:
                       && (r64_tabs[i][1] = r64_table(gpu.hip_id, lg, inverse, 2, st.lg_cur, 0, T, stream, cm, G)) != nullptr;
             }
             if (ok && cmode) ok = (r64_czp = r64_cz(gpu.hip_id, lg, inverse, cmode, G, stream)) != nullptr;
-            if (!ok) { rp.nsteps = 0; cmode = 0; }
+            // (a generic pass on top of the plan takes its share as 2^S row constants: g^(row << lgQ) / g^(rev_S(row)))
+            if (ok && cmode && rp.step[0].kind == 0) {
+                const unsigned S = rp.step[0].S;
+                ok = (top_crow = cached_table(tw_key(gpu.hip_id, inverse, 3, cmode, S, lg), (size_t)1 << S, stream, [&](F* t) {
+                          hipLaunchKernelGGL(k_pass_crow<F>, dim3(1), dim3(256), 0, stream, t, G, cmode, S);
+                      })) != nullptr;
+            }
+            if (!ok) { rp.nsteps = 0; cmode = 0; top_crow = nullptr; }
         }
         if (!inverse && type == NTT_COSET && !cmode)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
@@ -358,6 +366,7 @@ public:
         for (unsigned i = 0; i < pl.npass; i++) {
             const bool last = i == pl.npass - 1;
             ntt_pass P;
+            P.cmode = 0; P.crow = P.cg_lo = P.cg_hi = nullptr; P.cg_h = 0;
             if (rp.nsteps) {
                 const r64_step st = rp.step[gs ? i : rp.nsteps - 1 - i];
                 if constexpr (R64) {
@@ -381,6 +390,7 @@ public:
                     }
                 }
                 P.lg_cur = st.lg_cur; P.S = st.S; P.lgC = lgc; P.lgG = 0;       // a strided pass above >= 12 further stages
+                P.cmode = cmode; P.crow = top_crow; P.cg_lo = G.lo; P.cg_hi = G.hi; P.cg_h = G.h;      // (a folded coset transform)
             } else {
                 P = pl.pass[gs ? i : pl.npass - 1 - i];
             }

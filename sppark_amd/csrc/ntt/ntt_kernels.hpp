@@ -60,7 +60,19 @@ struct ntt_pass {
     unsigned lgC;       // log2 columns (lo) per tile
     unsigned lgG;       // log2 sub-problems per tile (only when the tile spans all Q columns)
     int apply_scale;    // multiply by tables.scale when storing (inverse, last executed pass)
+    // A coset transform folded into the pass on the WHOLE transform when that is a generic pass above the radix-64 steps
+    // (ntt_r64_kernels.hpp r64_coset_mode; 0 = none).  cmode 1, natural exponents: crow[row] = g^(row << lgQ) on the data
+    // side (DIF load / DIT store) and g^col, from the powers of g (cg_lo / cg_hi / cg_h as ntt_tables::lo / hi / h), on the
+    // twiddle side (DIF store / DIT load); cmode 2, bit-reversed exponents: crow[row] = g^(rev_S(row)) on the twiddle side.
+    // One or two products per element of this pass instead of a scaling pass over the array.
+    unsigned cmode;
+    const void *crow, *cg_lo, *cg_hi;
+    unsigned cg_h;
 };
+// the coset factors of one element of such a pass (typed views of the fields above)
+template<class F> SPPARK_DEVFN F ntt_pass_crow(const ntt_pass& P, unsigned row) { return reinterpret_cast<const F*>(P.crow)[row]; }
+template<class F> SPPARK_DEVFN F ntt_pass_gcol(const ntt_pass& P, size_t col)
+{   return reinterpret_cast<const F*>(P.cg_lo)[col & (((size_t)1 << P.cg_h) - 1)] * reinterpret_cast<const F*>(P.cg_hi)[col >> P.cg_h];   }
 
 SPPARK_DEVFN unsigned bit_rev32(unsigned x, unsigned bits)
 {
@@ -184,7 +196,11 @@ SPPARK_DEVFN void ntt_round_high(F* data, F* tile, const ntt_tables<F>& T, const
             const unsigned gm = (g << S) + (a << R2) + b;
             if (DIF || R2 == 0) x[a] = data[((geo.row0 + gm) << geo.lgQ) + geo.c0 + c];
             else                x[a] = tile[ntt_lds_index<R2>(gm, c, P.lgC)];
+            if (DIF && P.cmode == 1) x[a] = x[a] * ntt_pass_crow<F>(P, (a << R2) + b);     // coset, data side (uniform branch)
         }
+        // single-round pass: the twiddle side is here too
+        F cgc = F();
+        if (R2 == 0 && P.cmode == 1) cgc = ntt_pass_gcol<F>(P, geo.c0 + c);
         // single-round pass (R2 == 0): the inter-pass twiddles w^(col * rev(a)) are applied here
         constexpr bool GEN = ntt_gen_twiddles<F>::value && R2 == 0;
         F pw[GEN ? (1u << R1) : 1];
@@ -198,6 +214,8 @@ SPPARK_DEVFN void ntt_round_high(F* data, F* tile, const ntt_tables<F>& T, const
                 if (R2 == 0) {                          // single-round pass: finish here
                     if (GEN) { if (geo.lgQ && a) x[a] = x[a] * pw[GEN ? bit_rev32(a, R1) : 0]; }
                     else if (geo.lgQ) { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
+                    if (P.cmode == 1) x[a] = x[a] * cgc;
+                    if (P.cmode == 2) x[a] = x[a] * ntt_pass_crow<F>(P, a);
                     if (P.apply_scale) x[a] = x[a] * T.scale;
                     data[((geo.row0 + (g << S) + a) << geo.lgQ) + geo.c0 + c] = x[a];
                 } else {
@@ -212,10 +230,13 @@ SPPARK_DEVFN void ntt_round_high(F* data, F* tile, const ntt_tables<F>& T, const
                     if (GEN) { if (a) x[a] = x[a] * pw[GEN ? bit_rev32(a, R1) : 0]; }
                     else { unsigned ex = (geo.c0 + c) * bit_rev32(a, R1); x[a] = x[a] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
+                if (R2 == 0 && P.cmode == 1) x[a] = x[a] * cgc;
+                if (R2 == 0 && P.cmode == 2) x[a] = x[a] * ntt_pass_crow<F>(P, a);
             }
             radix_dit<F, INV, R1>(x, T.inner);
             #pragma unroll
             for (unsigned a = 0; a < (1u << R1); a++) {
+                if (P.cmode == 1) x[a] = x[a] * ntt_pass_crow<F>(P, (a << R2) + b);        // coset, data side
                 if (P.apply_scale) x[a] = x[a] * T.scale;
                 data[((geo.row0 + (g << S) + (a << R2) + b) << geo.lgQ) + geo.c0 + c] = x[a];
             }
@@ -253,6 +274,8 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
                 ntt_twiddle_powers<F, R2, true>(pw, T, (col * bit_rev32(a, R1)) << sh, (col << R1) << sh);
             }
         }
+        F cgc = F();                                            // coset, twiddle side (uniform branches)
+        if (P.cmode == 1) cgc = ntt_pass_gcol<F>(P, geo.c0 + c);
         #pragma unroll
         for (unsigned b = 0; b < (1u << R2); b++) {
             const unsigned gm = (g << S) + (a << R2) + b;
@@ -264,6 +287,8 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
                     else if (tabled) x[b] = x[b] * T.pass_tw[((size_t)((a << R2) + b) << geo.lgQ) + geo.c0 + c];
                     else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
+                if (P.cmode == 1) x[b] = x[b] * cgc;
+                if (P.cmode == 2) x[b] = x[b] * ntt_pass_crow<F>(P, (a << R2) + b);
             }
         }
         if (DIF) {
@@ -275,6 +300,8 @@ SPPARK_DEVFN void ntt_round_low(F* data, F* tile, const ntt_tables<F>& T, const 
                     else if (tabled) x[b] = x[b] * T.pass_tw[((size_t)((a << R2) + b) << geo.lgQ) + geo.c0 + c];
                     else { unsigned ex = (geo.c0 + c) * bit_rev32((a << R2) + b, S); x[b] = x[b] * ntt_twiddle(T, (size_t)ex << (T.lg_n - P.lg_cur)); }
                 }
+                if (P.cmode == 1) x[b] = x[b] * cgc;
+                if (P.cmode == 2) x[b] = x[b] * ntt_pass_crow<F>(P, (a << R2) + b);
                 if (P.apply_scale) x[b] = x[b] * T.scale;
                 data[((geo.row0 + (g << S) + (a << R2) + b) << geo.lgQ) + geo.c0 + c] = x[b];
             }
@@ -885,6 +912,7 @@ static inline ntt_plan make_ntt_plan(unsigned lg_n, unsigned lgCmax, unsigned lg
         unsigned left = np - i;
         unsigned S = (rem + left - 1) / left;                   // near-equal split, <= 8
         ntt_pass p; p.lg_cur = rem; p.S = S; p.apply_scale = 0;
+        p.cmode = 0; p.crow = p.cg_lo = p.cg_hi = nullptr; p.cg_h = 0;
         unsigned lgQ = rem - S;
         if (lgQ >= lgCmax) { p.lgC = lgCmax; p.lgG = 0; }
         else {

@@ -341,6 +341,16 @@ SPPARK_DEVFN void r64_cz_item(F* out, const ntt_tables<F>& G, unsigned cmode, un
 template<class F>
 __global__ __launch_bounds__(64) void k_r64_cz(F* out, ntt_tables<F> G, unsigned cmode)
 {   r64_cz_item(out, G, cmode, threadIdx.x);   }
+// the 2^S row constants of a generic top pass (ntt_pass::crow): g^(row << (lg_n - S)) (cmode 1) / g^(rev_S(row)) (cmode 2)
+template<class F>
+SPPARK_DEVFN void pass_crow_item(F* out, const ntt_tables<F>& G, unsigned cmode, unsigned S, unsigned row)
+{
+    if (row >= (1u << S)) return;
+    out[row] = ntt_twiddle(G, cmode == 2 ? (size_t)bit_rev32(row, S) : (size_t)row << (G.lg_n - S));
+}
+template<class F>
+__global__ __launch_bounds__(256) void k_pass_crow(F* out, ntt_tables<F> G, unsigned cmode, unsigned S)
+{   pass_crow_item(out, G, cmode, S, threadIdx.x);   }
 
 // ---- planning (host) -----------------------------------------------------------------------------
 // GS/DIF order (step 0 splits the whole transform); CT/DIT executes the steps in reverse.
@@ -365,13 +375,14 @@ static inline r64_plan make_r64_plan(unsigned lg_n)                  // lg_n >= 
     return pl;
 }
 
-// How a coset transform runs on this plan: 0 = the separate scaling launch (a plan with a generic top pass, the reference's RR
-// order whose exponents follow neither index, 2^12 with natural exponents), 1 / 2 = folded (r64_table_item above).
+// How a coset transform runs on this plan: 0 = the separate scaling launch (the reference's RR order, whose exponents follow
+// neither index; 2^12 with natural exponents), 1 / 2 = folded (r64_table_item above; a generic pass on top of the plan takes
+// its share as row constants and, for the natural exponents, g^col per work item: ntt_pass::cmode, ntt_kernels.hpp).
 // |gs|: the DIF network; |foldable|: a coset transform in the NN / NR / RN order.
 static inline unsigned r64_coset_mode(const r64_plan& pl, bool gs, bool inverse, bool foldable)
 {
     if (!foldable || pl.nsteps == 0) return 0;
-    for (unsigned i = 0; i < pl.nsteps; i++) if (pl.step[i].kind == 0) return 0;
+    for (unsigned i = 1; i < pl.nsteps; i++) if (pl.step[i].kind == 0) return 0;      // (a generic pass is only ever the top one)
     const unsigned mode = gs != inverse ? 1 : 2;
     if (mode == 1 && pl.nsteps < 2) return 0;
     return mode;

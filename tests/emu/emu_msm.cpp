@@ -97,6 +97,27 @@ extern "C" int emu_field_op(int field, int op, void* out, const void* a, const v
     return 0;
 }
 
+// montx_dev::from_std (wire words -> the bucket field's own limbs; a shift and the subtraction of q p, ff/montx_dev.hpp): the limbs
+// of every result, for a big-integer check on the Python side.  info = { limbs, limb bits, domain shift }; 0 when the library's
+// bucket field has no internal form
+template<class FX> static int from_std_limbs(unsigned* out, const void* a, size_t n, unsigned info[3])
+{
+    info[0] = FX::NL; info[1] = FX::RBITS / FX::NL; info[2] = FX::SH;
+    for (size_t i = 0; i < n; i++) {
+        const FX r = FX::from_std((const u32*)a + i * FX::NW);
+        for (int j = 0; j < FX::NL; j++) out[i * FX::NL + j] = r.l[j];
+    }
+    return 1;
+}
+// which 0: the G1 bucket field of this library; 1: 28-bit limbs over the same modulus (the base field of the G2 pipeline: for
+// alt_bn128 ten limbs, a domain offset of 24 bits)
+extern "C" int emu_from_std_limbs(int which, unsigned* out, const void* a, size_t n, unsigned info[3])
+{
+    if (which == 1) return from_std_limbs<montx_dev<curve_p::fp, 28>>(out, a, n, info);
+    if constexpr (field_is_montx<msm_fp_d>::value) return from_std_limbs<msm_fp_d>(out, a, n, info);
+    return 0;
+}
+
 // op 0: a += b (xyzz)   1: a += affine(b)   2: a -= affine(b)   3: a = 2a
 extern "C" int emu_xyzz_op(int op, void* out, const void* a, const void* b, size_t n)
 {
@@ -375,6 +396,31 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
     for (size_t id = 0; id < n1; id++) bucket_level1_item<inst_fp>(A1.data(), W1.data(), buckets.data(), p.NB, p.K, p.nwins, id, off.data());
     unsigned lgG = lg2_floor(p.K);
     inst_m *ia = A1.data(), *iw = W1.data(), *oa = A2.data(), *ow = W2.data();
+    // top == 2: the small windows' bucket sums straight from the buckets (k_bucket_small_bits_coop: small_sums_gather, a pairwise
+    // tree, b doublings per part; then the parts of a window as in the subset-sum top), as msm_driver.hpp runs them for NB <= 256
+    if (top == 2 && p.NB <= SMALL_SUMS_MAX_NB && p.NB >= 2) {
+        const unsigned m = lg2_floor(p.NB);
+        std::vector<inst_m> parts((size_t)p.nwins * (m + 1));
+        std::vector<inst_m> res(p.nwins);
+        for (unsigned w = 0; w < p.nwins; w++) {
+            for (unsigned b = 0; b <= m; b++) {
+                std::vector<xyzz_dev<inst_fp>> acc(SMALL_SUMS_MAX_NB / 2);
+                for (unsigned t = 0; t < SMALL_SUMS_MAX_NB / 2; t++) acc[t] = small_sums_gather<inst_fp>(buckets.data(), off.data(), p.NB, m, b, w, t);
+                const unsigned cnt = b >= m ? 1u : p.NB / 2;
+                for (unsigned s = cnt / 2; s >= 1; s >>= 1)
+                    for (unsigned t = 0; t < s; t++) bucket_add_fast<inst_fp>(acc[t], acc[t + s]);
+                for (unsigned k = 0; k < b; k++) bucket_dbl_fast<inst_fp>(acc[0]);
+                acc[0].store(&parts[(size_t)w * (m + 1) + b]);
+            }
+            std::vector<xyzz_dev<inst_fp>> acc(32);
+            for (unsigned tid = 0; tid < 32; tid++) acc[tid] = bucket_top_sum_gather<inst_fp>(parts.data(), m, w, tid);
+            for (unsigned s = 16; s >= 1; s >>= 1)
+                for (unsigned tid = 0; tid < s; tid++) bucket_add_fast<inst_fp>(acc[tid], acc[tid + s]);
+            acc[0].store(&W2[w]);
+        }
+        iw = W2.data();
+        nitems = 1;
+    }
     while (nitems > 1) {
         // the subset-sum top (k_bucket_top_bits / k_bucket_top_sum), as msm_driver.hpp hands over to it: the per-lane parts
         // are the product's own functions, the LDS tree between them a plain pairwise reduction with the same additions

@@ -82,6 +82,10 @@ template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int i
             const bool last = i == rp.nsteps - 1;
             if (st.kind == 0) {
                 ntt_pass P; P.lg_cur = st.lg_cur; P.S = st.S; P.lgC = LG_LINE; P.lgG = 0; P.apply_scale = inverse && last;
+                // as ntt_engine::run(): the generic top pass's share of a folded coset transform
+                std::vector<FF> crow((size_t)1 << st.S);
+                for (unsigned r = 0; r < crow.size() && cmode; r++) pass_crow_item(crow.data(), G, cmode, st.S, r);
+                P.cmode = cmode; P.crow = crow.data(); P.cg_lo = G.lo; P.cg_hi = G.hi; P.cg_h = G.h;
                 std::vector<FF> tile(ntt_lds_elems(P) + 1);
                 T.pass_tw = nullptr;
                 const size_t tile_elems = (size_t)1 << (P.S + P.lgC);

@@ -96,7 +96,8 @@ def test_cooperative_kernels_fit_one_work_group_per_cu():
         assert int(md.get("vgpr_count") or 0) <= 512, (name[:60], md)
         # static LDS: the exchange area (+ the image of a tree / a level); the top's image of 2^nl points is dynamic and
         # sized by the driver (top_bits_coop_lds) under the 160 KB of a CU
-        assert int(md.get("group_segment_fixed_size") or 0) <= 40 * 1024, (name[:60], md)
+        # (k_bucket_small_bits_coop holds the 128 buckets of a subset sum beside the exchange area: 56 KB, two work-groups per CU)
+        assert int(md.get("group_segment_fixed_size") or 0) <= (60 if "small_bits" in name else 40) * 1024, (name[:60], md)
         assert int(md.get("private_segment_fixed_size") or 0) <= 1280, (name[:60], "scratch", md)
 
 

@@ -69,6 +69,42 @@ def test_device_field_code_on_host(oracle, curve):
                 assert (e.view(np.uint8) == out[i * nb:(i + 1) * nb]).all(), (curve, which, op, i)
 
 
+@pytest.mark.parametrize("curve,feature,which", [(0, "BLS12_381", 0), (1, "BN254", 0), (1, "BN254", 1)])
+def test_wire_to_bucket_field_conversion_on_host(oracle, curve, feature, which):
+    """montx_dev::from_std: wire words -> the bucket field's own limbs as a SHIFT by the domain offset and the subtraction of
+    q p with an estimated quotient (ff/montx_dev.hpp; a product until round 5).  For every input the limbs must be normalised
+    and their value congruent to w 2^SH and below 2p -- checked with big integers on the inputs where the estimate is at
+    its edges: w 2^SH just below / at / above every multiple k p that the shift can reach (sampled for the wide shifts),
+    0, 1, p - 1, powers of two, all-ones patterns below p, random values.  which = 1: the ten 28-bit limbs under alt_bn128's
+    G2 pipeline (a domain offset of 24 bits: the widest quotient)."""
+    O = oracle
+    L = _emu(feature)
+    p = O.FP_MODULUS[curve]
+    nb = O.FP_BYTES[curve]
+    info = np.zeros(3, dtype=np.uint32)
+    probe = np.zeros(nb, dtype=np.uint8); out = np.zeros(64, dtype=np.uint32)
+    assert L.emu_from_std_limbs(which, P(out), P(probe), 1, P(info)) == 1
+    NL, LB, SH = (int(v) for v in info)
+    assert (NL, LB) == ((14, 28) if curve == 0 else (10, 28) if which else (9, 29)) and SH == NL * LB - 8 * nb
+    rng = np.random.default_rng(77 + curve)
+    vals = {0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2}
+    vals |= {1 << k for k in range(0, p.bit_length() - 1, 7)} | {(1 << k) - 1 for k in range(1, p.bit_length(), 5)}
+    ks = range(1, (1 << SH) + 1) if SH <= 10 else [int(v) for v in rng.integers(1, 1 << SH, 600)] + [1, 2, (1 << SH) - 1, 1 << SH]
+    for k in ks:                                                # w 2^SH around k p
+        w0 = (k * p) >> SH
+        vals |= {w for w in (w0 - 1, w0, w0 + 1, w0 + 2) if 0 <= w < p}
+    vals |= {int.from_bytes(rng.bytes(nb + 8), "little") % p for _ in range(500)}
+    vals = sorted(vals)
+    a = np.frombuffer(b"".join(v.to_bytes(nb, "little") for v in vals), dtype=np.uint8).copy()
+    out = np.zeros(len(vals) * NL, dtype=np.uint32)
+    L.emu_from_std_limbs(which, P(out), P(a), len(vals), P(info))
+    for i, w in enumerate(vals):
+        limbs = [int(v) for v in out[i * NL:(i + 1) * NL]]
+        assert all(l < (1 << LB) for l in limbs), (hex(w), limbs)
+        v = sum(l << (LB * j) for j, l in enumerate(limbs))
+        assert v < 2 * p and (v - (w << SH)) % p == 0, (hex(w), hex(v))
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_msm_pipeline_on_host(oracle, curve):
     O = oracle
@@ -228,6 +264,27 @@ def test_msm_short_segment_join_on_host(oracle):
                 assert bool(stats[0]) == expect_long, (wb, LL, stats)
                 if not expect_long:
                     assert stats[1] == 0            # no record left for the tree
+
+
+@pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])
+def test_msm_small_window_bucket_sums_on_host(oracle, curve, feature):
+    """The bucket sums of windows of up to 256 buckets straight from the buckets (k_bucket_small_bits_coop: the buckets of
+    S_b = the 1-based numbers with bit b set, small_sums_member / small_sums_gather; empty buckets from the sort's offsets;
+    b doublings per part) against the oracle: 2 .. 256 buckets per window, uniform and sparse scalars (most buckets empty),
+    all scalars equal."""
+    O = oracle
+    L = _emu(feature)
+    fb = O.FP_BYTES[curve]
+    n = 700
+    pts, sc = recipe.msm_inputs(curve, n, 555, edge=True)
+    s_sparse = np.zeros_like(sc); s_sparse[::7] = sc[::7]
+    s_eq = sc.copy(); s_eq[:] = sc[4]
+    for s in (sc, s_sparse, s_eq):
+        exp = O.msm_affine(curve, pts, s, algo=0, param=4)
+        for wb in (2, 3, 4, 5, 8, 9):
+            out = np.zeros(3 * fb, dtype=np.uint8)
+            L.emu_msm(P(out), P(pts), pts.shape[1], n, P(s), 0, wb, 8, 4, 4, 2, 1, None, 2)
+            assert (O.jac_to_affine(curve, out) == exp).all(), (curve, wb)
 
 
 def test_msm_piece_tree_on_host(oracle):

@@ -171,21 +171,22 @@ def test_ntt_coset_folded_into_radix64_passes_on_host(oracle, field, feature):
     """Coset transforms on a plan of k_ntt6 / k_ntt12 steps carry the powers of the coset generator in their twiddle tables
     and 64 constants instead of a separate scaling pass (r64_coset_mode / r64_table_item / r64_cz_item): the four foldable
     cases -- forward DIF (NR) and inverse DIT (RN, NN) with natural exponents, inverse DIF (NR) and forward DIT (RN, NN)
-    with bit-reversed ones -- at 2^12 (k_ntt12 alone: bit-reversed exponents only) and 2^18 (k_ntt6 + k_ntt12) with the
-    step's twiddles from one table and from the two small ones, against the oracle; RR and the sizes with a generic top
-    pass keep the separate pass; with the fold switched off the same bytes."""
+    with bit-reversed ones -- at 2^12 (k_ntt12 alone: bit-reversed exponents only), 2^18 (k_ntt6 + k_ntt12) with the
+    step's twiddles from one table and from the two small ones, and with a generic pass on top of the plan (2^13: one
+    stage in a single round, 2^14: two stages, 2^15 / 2^17: three / five, table and generated twiddles; ntt_pass::cmode),
+    against the oracle; RR keeps the separate pass; with the fold switched off the same bytes."""
     O = oracle
     L = _emu(feature)
     f = O.ntt_gl64 if field == "gl64" else O.ntt_bb31
     try:
-        for lg, direct in ((12, 20), (18, 20), (18, 12), (14, 20)):
+        for lg, direct in ((12, 20), (18, 20), (18, 12), (13, 20), (14, 20), (15, 20), (17, 20)):
             x = recipe.ntt_input(field, lg, 700 + lg)
             L.emu_ntt_plan(12, direct)
             for order in range(4):
                 for direction in range(2):
                     exp = f(x, order, direction, 1)
                     # NR forward / RN, NN inverse: natural exponents (1); NR inverse / RN, NN forward: bit-reversed (2)
-                    want = 0 if order == 3 or lg == 14 else 1 if (order == 1) != (direction == 1) else 2
+                    want = 0 if order == 3 else 1 if (order == 1) != (direction == 1) else 2
                     if lg == 12 and want == 1:
                         want = 0
                     L.emu_ntt_coset_fold(1)

@@ -364,8 +364,9 @@ def test_msm_piece_tree_of_small_sizes(oracle, libs, curve, name):
                     redone = ctx.tail_redone() - before
                     if join == 5 or what == "uniform":
                         assert redone == 0, (n, what, plan, join)
-                    if join != 5 and what == "equal":
-                        assert redone == 1, (n, what, plan, join)
+                    pl = ctx.plan(n)
+                    if join != 5 and what == "equal" and n // pl["run_length"] > pl["piece_tree_max"] + 1:
+                        assert redone == 1, (n, what, plan, join)      # ONE bucket per window holds everything: beyond the tree's size
     ctx.close()
 
 

@@ -40,7 +40,7 @@ python tools/rocprof_timeline.py $(find gpurun_out/prof_tl -name "*.db" | head -
 rm -f gpurun_out/pmc_msm_acc6.txt gpurun_out/pmc_bn254_acc6.txt
 bash tools/gpu_pmc_job.sh msm_acc6 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU|SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" -- python tools/gpu_msm_one.py 26 0 | grep -i "accumulate\|convert\|kernel "
 bash tools/gpu_pmc_job.sh bn254_acc6 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" -- python tools/gpu_msm_bn254.py 26 | grep -i "accumulate\|kernel "
-/usr/bin/time -v timeout 900 python bench.py > $R/gpurun_out/r6e_bench_final.json 2> $R/gpurun_out/r6e_bench_final.err; grep "Elapsed (wall" $R/gpurun_out/r6e_bench_final.err; tail -c 600 $R/gpurun_out/r6e_bench_final.json
+SECONDS=0; timeout 900 python bench.py > $R/gpurun_out/r6e_bench_final.json 2> $R/gpurun_out/r6e_bench_final.err; echo "bench.py wall: $SECONDS s" | tee $R/gpurun_out/r6e_bench_wall.txt; tail -c 600 $R/gpurun_out/r6e_bench_final.json
 timeout 400 env NTT_LGS=12,16,20,22,24,26 python tools/gpu_ntt_bench.py > $R/gpurun_out/r6e_ntt_bench.log 2>&1
 timeout 400 env NTT_LGS=12,16,18,20,22,24 python tools/gpu_ntt_orders.py > $R/gpurun_out/r6e_ntt_orders.log 2>&1; grep "2^24" $R/gpurun_out/r6e_ntt_orders.log | cut -c1-220
 timeout 400 python tools/gpu_ntt_vs_reference.py > $R/gpurun_out/r6e_ntt_vs_reference.log 2>&1; grep -v amdgpu $R/gpurun_out/r6e_ntt_vs_reference.log | tail -30

@@ -407,6 +407,15 @@ private:
         if constexpr (INTERNAL) {
             if (on == nullptr) on = stream;
             unsigned grid = (n + 255) / 256;
+            // G1 points in either wire layout at a 16-byte-aligned base: the coalesced form (msm_kernels.hpp k_convert_points_staged)
+            if constexpr (MONTX) {
+                if ((stride == 2 * FP_BYTES || stride == 2 * FP_BYTES + 8) && ((size_t)src & 15) == 0 && tune.join != 6) {
+                    if (stride == 2 * FP_BYTES) hipLaunchKernelGGL((k_convert_points_staged<fp_d, false>), dim3(grid), dim3(256), 0, on, dst, src, n);
+                    else                        hipLaunchKernelGGL((k_convert_points_staged<fp_d, true>), dim3(grid), dim3(256), 0, on, dst, src, n);
+                    HIP_OK(hipGetLastError());
+                    return;
+                }
+            }
             if (stride > 2 * FP_BYTES) hipLaunchKernelGGL((k_convert_points<fp_d, true>), dim3(grid), dim3(256), 0, on, dst, src, n, (unsigned)stride);
             else                       hipLaunchKernelGGL((k_convert_points<fp_d, false>), dim3(grid), dim3(256), 0, on, dst, src, n, (unsigned)stride);
             HIP_OK(hipGetLastError());

@@ -644,6 +644,92 @@ void k_bucket_top_sum(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* 
 }
 
 // ---------------------------------------------------------------------------
+// k_convert_points with COALESCED accesses (round 6; plain points of the G1 bucket fields): the wire points of a work-group --
+// 256 x 96 contiguous bytes -- are read in 16-byte pieces by consecutive lanes (every 128-byte line once, by one instruction)
+// into an LDS image whose point stride is padded to an odd multiple of 16 bytes (112 for 96: the eight lanes of a b128 LDS
+// access then hit disjoint banks), each lane converts ITS point from the image, and the 128-byte records go back the same way
+// (stride 144 in LDS, whole lines to memory).  The per-lane form (a lane reads 6 x 16 bytes 96 bytes apart from its neighbour)
+// asks the L1 for every line six times, with 32 waves' footprints thrashing its 32 KB.
+// ---------------------------------------------------------------------------
+template<class FP>
+SPPARK_DEVFN constexpr unsigned convert_lds_stride(unsigned raw) { return (raw / 4) % 8 == 0 ? raw + 16 : raw; }
+// FLAGGED: the Affine_inf_t layout (X | Y | flag byte + padding: 8 bytes more per point, what arkworks / the Rust wrapper pass).
+// Its points are 6.5 pieces long, so the LDS image is the memory image itself and a lane reads its point in 8-byte words
+// (104 bytes = 26 banks apart: sixteen lanes of a b64 access on disjoint bank pairs).
+template<class FP, bool FLAGGED>
+__global__ __launch_bounds__(256)
+void k_convert_points_staged(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, unsigned n)
+{
+    typedef affine_loader<FP> AL;
+    constexpr unsigned IN = 2 * FP::NW * 4 + (FLAGGED ? 8 : 0), OUT = AL::STRIDE;     // bytes per wire point / per record
+    constexpr unsigned IN_L = FLAGGED ? IN : convert_lds_stride<FP>(IN), OUT_L = convert_lds_stride<FP>(OUT);
+    static_assert(IN % 8 == 0 && (256 * IN) % 16 == 0 && OUT % 16 == 0, "8 / 16-byte pieces");
+    constexpr unsigned LDS_BYTES = 256 * (IN_L > OUT_L ? IN_L : OUT_L) + 16;
+    __shared__ uint4 img[LDS_BYTES / 16];
+    unsigned char* lds = reinterpret_cast<unsigned char*>(img);
+    const unsigned tid = threadIdx.x;
+    const size_t p0 = (size_t)blockIdx.x * 256;
+    const unsigned cnt = n - p0 < 256 ? (unsigned)(n - p0) : 256u;              // points of this work-group
+    // ---- in: consecutive lanes, consecutive 16-byte pieces
+    const unsigned char* gin = src + p0 * IN;
+    const unsigned bytes = cnt * IN;
+    #pragma unroll
+    for (unsigned it = 0; it < (256 * IN / 16 + 255) / 256; it++) {
+        const unsigned g = it * 256 + tid, at = g * 16;
+        if (at + 16 <= bytes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(gin + at);
+            if (FLAGGED) *reinterpret_cast<uint4*>(lds + at) = v;
+            else         *reinterpret_cast<uint4*>(lds + (g / (IN / 16)) * IN_L + (g % (IN / 16)) * 16) = v;
+        } else if (FLAGGED && at + 8 <= bytes) {                                // (an odd number of points: the last 8 bytes)
+            *reinterpret_cast<uint2*>(lds + at) = *reinterpret_cast<const uint2*>(gin + at);
+        }
+    }
+    __syncthreads();
+    u32 w[OUT / 4] = {};
+    if (tid < cnt) {
+        u32 in[IN / 4];
+        if (FLAGGED) {
+            #pragma unroll
+            for (unsigned j = 0; j < IN / 8; j++) {
+                const uint2 v = *reinterpret_cast<const uint2*>(lds + tid * IN_L + j * 8);
+                in[2*j] = v.x; in[2*j+1] = v.y;
+            }
+        } else {
+            #pragma unroll
+            for (unsigned j = 0; j < IN / 16; j++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(lds + tid * IN_L + j * 16);
+                in[4*j] = v.x; in[4*j+1] = v.y; in[4*j+2] = v.z; in[4*j+3] = v.w;
+            }
+        }
+        bool inf;
+        if (FLAGGED) inf = (in[2 * FP::NW] & 1u) != 0;                          // the flag byte
+        else {
+            u32 any = 0;
+            #pragma unroll
+            for (unsigned i = 0; i < 2 * FP::NW; i++) any |= in[i];
+            inf = any == 0;                                                     // Affine_t: infinity = all-zero coordinates
+        }
+        const FP x = FP::from_std(in), y = FP::from_std(in + FP::NW);
+        x.to_wire(w); y.to_wire(w + FP::NL);
+        if (inf) w[FP::NL - 1] |= 0x80000000u;
+    }
+    __syncthreads();                                                            // (every lane has read its point: the image is reused)
+    if (tid < cnt) {
+        #pragma unroll
+        for (unsigned j = 0; j < OUT / 16; j++)
+            *reinterpret_cast<uint4*>(lds + tid * OUT_L + j * 16) = make_uint4(w[4*j], w[4*j+1], w[4*j+2], w[4*j+3]);
+    }
+    __syncthreads();
+    // ---- out: whole lines
+    uint4* gout = reinterpret_cast<uint4*>(dst + p0 * OUT);
+    #pragma unroll
+    for (unsigned it = 0; it < OUT / 16; it++) {
+        const unsigned g = it * 256 + tid;
+        if (g < cnt * (OUT / 16)) gout[g] = *reinterpret_cast<const uint4*>(lds + (g / (OUT / 16)) * OUT_L + (g % (OUT / 16)) * 16);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Coordinate fields with an internal representation (ff/montx_dev.hpp): the points are
 // converted ONCE per MSM (or once per preload) into the field's own records, and the W
 // window sums are converted back to the reference's wire image at the end.

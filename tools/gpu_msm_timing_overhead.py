@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, sppark_amd
 from sppark_amd import synth
-for lg in (16, 20, 23):
+for lg in (10, 12, 16, 18, 20):
     n = 1 << lg
     pts, _ = synth.replicated_points(n, "bls12_381", 2048, 1)
     sc = synth.uniform_scalars(n, "bls12_381", 1)

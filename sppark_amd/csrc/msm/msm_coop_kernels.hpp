@@ -92,9 +92,12 @@ void k_bucket_top_bits_coop(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<
 }
 
 // k_bucket_top_sum: the m + 1 <= 32 parts of a window, one work-group of four waves per window
+// |fin| (nullable): the window sum also in the reference's wire image (what k_finalize would write), coordinate r by wave r --
+// the small MSMs save that launch
 template<class FP>
 __global__ __launch_bounds__(COOP_NT)
-void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned m)
+void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned m,
+                           xyzz_mem<FP::NW>* __restrict__ fin)
 {
     __shared__ coop_lds<FP> ex;
     __shared__ coop_img<FP, 32> img;
@@ -106,6 +109,15 @@ void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP:
     while (2 * s0 < m + 1) s0 <<= 1;
     coop_tree_sum<FP, 32>(&img, s0, c);
     if (tid == 0) img.load(0).store(&out[w]);
+    if (fin != nullptr && c.lane == 0) {                            // (xyzz_dev::store_std, a coordinate per wave)
+        const xyzz_dev<FP> r = img.load(0);
+        const FP& f = c.role == 0 ? r.X : c.role == 1 ? r.Y : c.role == 2 ? r.ZZZ : r.ZZ;
+        u32 s[FP::NW];
+        if (r.is_inf()) { for (int i = 0; i < FP::NW; i++) s[i] = 0; }
+        else f.to_std(s);
+        u32* d = reinterpret_cast<u32*>(&fin[w]) + c.role * FP::NW;
+        for (int i = 0; i < FP::NW; i++) d[i] = s[i];
+    }
 }
 
 } // namespace sppark_amd

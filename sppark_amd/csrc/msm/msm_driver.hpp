@@ -730,7 +730,7 @@ private:
         bucket_t* result;
         // windows of up to 256 buckets (MSMs of up to 2^16 points): the subset sums straight from the buckets, then the parts of a
         // window (msm_coop_kernels.hpp k_bucket_small_bits_coop); needs the offsets of every window: one window group
-        bool small_sums = false;
+        bool small_sums = false, finalized = false;
         if constexpr (MONTX)
             small_sums = !multi && fb_n == 0 && p.NB <= SMALL_SUMS_MAX_NB && p.NB >= 2 && tune.K1 == 0 && tune.top == 0 && tune.K == 0
                          && tune.join != 3 && tune.join != 4;
@@ -740,9 +740,10 @@ private:
                 hipLaunchKernelGGL(k_bucket_small_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), 0, stream,
                                    A2, buckets, (const u32*)(blob + l.off[0]), p.NB, m);
                 HIP_OK(hipGetLastError());
-                hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, W2, A2, m);
+                hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, W2, A2, m,
+                                   (std_bucket_t*)(blob + l.sums));            // (the wire image with it: no k_finalize)
                 HIP_OK(hipGetLastError());
-                result = W2;
+                result = W2; finalized = true;
             }
         }
         if (!small_sums) {
@@ -781,7 +782,7 @@ private:
                             hipLaunchKernelGGL(k_bucket_top_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), lds, stream,
                                                oa, ia, iw, nitems, m, lgG);
                             HIP_OK(hipGetLastError());
-                            hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m);
+                            hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m, (std_bucket_t*)nullptr);
                             HIP_OK(hipGetLastError());
                         }
                     }
@@ -821,8 +822,10 @@ private:
         // ---- device -> host: one XYZZ per window (wire image); Horner on the host ------------------
         if constexpr (INTERNAL) {
             std_bucket_t* fin = (std_bucket_t*)(blob + l.sums);
-            hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((p.nwins + 63) / 64), dim3(64), 0, stream, fin, result, p.nwins);
-            HIP_OK(hipGetLastError());
+            if (!finalized) {
+                hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((p.nwins + 63) / 64), dim3(64), 0, stream, fin, result, p.nwins);
+                HIP_OK(hipGetLastError());
+            }
             HIP_OK(hipMemcpyAsync(h_out, fin, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
         } else {
             HIP_OK(hipMemcpyAsync(h_out, result, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));

@@ -52,8 +52,10 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // (round 3, with the sort split following the size and the cheaper tail: 2^17..2^19 moved from 8 / 8 / 11 to
     // 14 / 15 / 16 bits -- 2^18: 2.15 -> 1.82 ms, 2^19: 3.10 -> 2.42 ms, profiles/r03_msm_small_grid2.log)
     // (round 4, with the cooperative tail: 8 bits at 2^15 too -- 0.85 -> 0.73 ms, profiles/r04_msm_small_grid.log)
+    // (round 6, with the piece tree and the small windows' sums: 8 bits at 2^14 too -- 0.68 -> 0.59 ms wall; 2^13 is level between
+    // 4 and 8 bits and stays, profiles/r06_msm_small_grid2.log)
     unsigned autow = lg >= 22 ? std::min(22u, lg - 4) : lg >= 19 ? 16u : lg == 18 ? 15u : lg == 17 ? 14u
-                   : lg >= 15 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
+                   : lg >= 14 ? 8u : std::max(4u, lg > 10 ? lg - 10 : 0u);
     p.wbits = t.wbits ? t.wbits : autow;
     p.wbits = std::min(24u, std::max(2u, p.wbits));
     p.nwins = (scalar_bits - 1) / p.wbits + 1;      // as pippenger.cuh:365

@@ -45,6 +45,8 @@ timeout 400 env NTT_LGS=12,16,20,22,24,26 python tools/gpu_ntt_bench.py > $R/gpu
 timeout 400 env NTT_LGS=12,16,18,20,22,24 python tools/gpu_ntt_orders.py > $R/gpurun_out/r6e_ntt_orders.log 2>&1; grep "2^24" $R/gpurun_out/r6e_ntt_orders.log | cut -c1-220
 timeout 400 python tools/gpu_ntt_vs_reference.py > $R/gpurun_out/r6e_ntt_vs_reference.log 2>&1; grep -v amdgpu $R/gpurun_out/r6e_ntt_vs_reference.log | tail -30
 timeout 400 python tools/gpu_msm_tail.py ab 10 12 14 15 16 17 18 19 20 21 22 23 24 25 26 > $R/gpurun_out/r6e_msm_sizes.log 2>&1; grep -v amdgpu $R/gpurun_out/r6e_msm_sizes.log | grep "auto\|no piece"
+timeout 300 python tools/gpu_msm_timing_overhead.py 2>&1 | grep "timing=" > $R/gpurun_out/r6e_msm_small_wall.log; cat $R/gpurun_out/r6e_msm_small_wall.log
+timeout 600 python tools/gpu_msm_tail.py grid 13 14 > $R/gpurun_out/r6e_msm_small_grid_2p13_2p14.log 2>&1; grep "best\|auto" $R/gpurun_out/r6e_msm_small_grid_2p13_2p14.log
 timeout 600 python tools/gpu_msm_fixed.py 22:20 24 26 > $R/gpurun_out/r6e_msm_fixed_base.log 2>&1; grep -v amdgpu $R/gpurun_out/r6e_msm_fixed_base.log
 for lg in 26 24 22 20 16; do timeout 200 python tools/gpu_msm_bn254.py $lg 2>&1 | grep -v amdgpu | tail -1 >> $R/gpurun_out/r6e_msm_bn254.log; done; cat $R/gpurun_out/r6e_msm_bn254.log
 for spec in "gl64 22 2" "gl64 20 3" "bb31 22 2" "bls12_381 20 2"; do timeout 120 python tools/gpu_lde_one.py $spec 2>&1 | grep LDE >> $R/gpurun_out/r6e_ntt_lde.log; done; timeout 120 python tools/gpu_poly_one.py 2>&1 | grep -v amdgpu >> $R/gpurun_out/r6e_ntt_lde.log; cat $R/gpurun_out/r6e_ntt_lde.log

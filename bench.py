@@ -588,7 +588,7 @@ def main():
             cpu_msm = lambda p_, s_: O.ref_msm_affine(O.BLS12_381, p_, s_, nthreads=cores)
         else:
             cpu_msm = lambda p_, s_: O.msm_affine(O.BLS12_381, p_, s_, algo=0, param=cores)
-        # size the sample for ~15 s of CPU work from a 2^16 probe (config 1 of BASELINE.json)
+        # size the sample for ~10 s of CPU work from a 2^16 probe (config 1 of BASELINE.json)
         hp = pts[:1 << 16].cpu().numpy(); hs = sc[:1 << 16].cpu().numpy()
         probe = 1e30
         for _ in range(2):                                      # (the first call also starts the thread pool)
@@ -596,7 +596,7 @@ def main():
             cpu_msm(hp, hs)
             probe = min(probe, time.perf_counter() - t1)
         lgm = 16
-        while lgm < min(args.lg, 24) and probe * (1 << (lgm + 1 - 16)) * 0.6 < 15.0:
+        while lgm < min(args.lg, 24) and probe * (1 << (lgm + 1 - 16)) * 0.6 < 6.0:      # (~10 s of CPU work: 2^23 points on 256 threads)
             lgm += 1
         m = 1 << lgm
         hp = pts[:m].cpu().numpy(); hs = sc[:m].cpu().numpy()

@@ -130,15 +130,16 @@ def msm_affine_bytes(curve, g2, points_raw, stride, flagged, scalars_raw):
     F = Fp2(FP[curve], FP2_NR[curve]) if g2 else Fp(FP[curve])
     b = _b_g2(curve) if g2 else B_G1[curve]
     pts = decode_points(curve, g2, points_raw, stride, flagged)
-    acc = None
-    cache = {}
+    # equal points share one scalar multiplication: sum_i s_i P = (sum_i s_i) P, the scalars added as plain integers
+    # (the n = 1000 cases repeat 64 points: 64 double-and-add ladders instead of 1000)
+    total = {}
     for i, P in enumerate(pts):
         assert on_curve(F, P, b), "input point %d is not on the curve" % i
         s = int.from_bytes(scalars_raw[32 * i:32 * i + 32], "little")
         if P is None or s == 0:
             continue
-        key = (P, s)
-        if key not in cache:
-            cache[key] = ec_mul(F, P, s)
-        acc = ec_add(F, acc, cache[key])
+        total[P] = total.get(P, 0) + s
+    acc = None
+    for P, s in total.items():
+        acc = ec_add(F, acc, ec_mul(F, P, s))
     return encode_affine(curve, g2, acc)

@@ -1,10 +1,14 @@
 """Time-bounded randomised parity run on the GPU, beyond the seeded cases of tests/: every result against the oracle
-(the checker; never the thing measured).  Usage: python tools/gpu_fuzz.py SECONDS [SEED]
+(the checker; never the thing measured).  Usage: python tools/gpu_fuzz.py SECONDS [SEED] [mid]
 
 MSM: all G1 curves, G2 of the curves that have it; sizes 1 .. 2^18 (log-uniform, ragged), few / many distinct points,
 flagged and plain layouts, infinities, P / -P pairs, repeated (point, scalar) pairs; scalar shapes: uniform, all equal,
 half zero, short, r - 1 / (r +- 1) / 2 heavy, digits clustered in one bucket; random plan tunables (window bits, run
 length, fan-in, chunks, slabs, sort split, top hand-over, tail variant, record format).
+mid: MSMs of 2^17 .. 2^24.3 points (ragged sizes, where the plan changes run length, slabs, index groups of the 4-byte
+sort records, oversized partitions, window groups) over a window of the ALL-DISTINCT progression P_i = (a + i b) G
+(sppark_g1_generate_progression), device-resident, expected (a sum s_i + b sum i s_i mod r) G from integer arithmetic on the
+scalars (oracle/fold.py) and one oracle scalar multiplication: any wrong gather index changes the result.
 NTT: all fields, sizes 2^1 .. 2^20, the 16 modes, inputs heavy in the values where a reduction can go wrong
 (0, 1, p - 1, p - 2, 2^32 - 1, 2^32, 2^64 - 2^32 ..., all-equal arrays, one-hot arrays)."""
 import os
@@ -79,6 +83,47 @@ def fuzz_msm(rng, it, ctxs, g2):
     return bool((got == exp).all()), what
 
 
+A_PROG, B_PROG = 0x243f6a8885a308d313198a2e03707344, 0xa4093822299f31d0082efa99       # < 2^126, < 2^96
+MID_MAX = (1 << 24) + (1 << 22)
+
+
+def fuzz_mid(rng, it, state):
+    import torch
+    from sppark_amd import synth
+    from oracle import fold
+    name = ("bls12_381", "bn254")[it % 2]; curve = O.CURVE_ID[name]
+    fb = O.FP_BYTES[curve]; r = O.FR_MODULUS[curve]
+    if name not in state:
+        pts = torch.empty((MID_MAX, 2 * fb), dtype=torch.uint8, device="cuda")
+        sppark_amd.generate_progression(pts, MID_MAX, A_PROG, B_PROG, 2 * fb, name)
+        state[name] = (pts, sppark_amd.MsmContext(name, stream=torch.cuda.current_stream().cuda_stream), O.g1_generator(curve))
+    pts, ctx, G = state[name]
+    n = min(MID_MAX, int(2 ** rng.uniform(17, 24.3)) + int(rng.integers(-5, 6)))
+    o = int(rng.integers(0, MID_MAX - n + 1))
+    sc = synth.uniform_scalars(n, name, seed=int(rng.integers(1, 1 << 30)))
+    mode = int(rng.integers(0, 6))
+    if mode == 1: sc[:] = sc[0].clone()
+    elif mode == 2: sc[torch.rand(n, device="cuda") < 0.5] = 0
+    elif mode == 3: sc[:, int(rng.integers(2, 20)):] = 0
+    elif mode == 4: sc[torch.rand(n, device="cuda") < 0.97] = sc[0].clone()
+    elif mode == 5: sc[int(rng.integers(0, n // 2)): n - int(rng.integers(0, n // 2))] = sc[1].clone()
+    t = dict(wbits=int(rng.choice([0, 0, 0, 12, 15, 18, 21, 23])), L=int(rng.choice([0, 0, 0, 32, 100, 128, 256])),
+             F=int(rng.choice([0, 0, 4, 32])), K=int(rng.choice([0, 0, 2, 8])), nslabs=int(rng.choice([0, 0, 0, 5, 64])))
+    ctx.tune(**t)
+    ts = int(rng.choice([0, 0, 13, 10])); ctx.tune_sort(ts)
+    big = int(rng.choice([0, 0, 30000])); ctx.tune_split(big)
+    top = int(rng.choice([0, 0, 1, 512, 4096])); ctx.tune_sums(top)
+    join = int(rng.choice([0, 0, 1, 6])); k1 = int(rng.choice([0, 0, 4, 16])); ctx.tune_tail(join, k1)
+    rec = int(rng.choice([0, 0, 1, 2])); ctx.tune_records(rec)
+    groups = int(rng.choice([0, 0, 2, 3])); ctx.tune_pipeline(groups=groups)
+    what = dict(kind="mid", curve=name, n=n, offset=o, mode=mode, sort=ts, big=big, top=top, join=join, k1=k1, records=rec, groups=groups, **t)
+    torch.cuda.synchronize()
+    got = sppark_amd.to_affine(ctx.invoke(pts[o:o + n], sc), name)
+    s0, s1 = fold.weighted_sums(sc)
+    exp = O.g1_mul(curve, G, ((A_PROG + o * B_PROG) * s0 + B_PROG * s1) % r)
+    return bool((got == exp).all()), what
+
+
 def ntt_edge_input(rng, field, lg):
     n = 1 << lg
     x = recipe.ntt_input(field, lg, int(rng.integers(1, 1 << 30)))
@@ -130,20 +175,23 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
     rng = np.random.default_rng(seed)
-    ctxs = {name: sppark_amd.MsmContext(name) for _, name in G1}
+    mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
+    ctxs = {} if mid else {name: sppark_amd.MsmContext(name) for _, name in G1}
+    state = {}
     t0 = time.time()
-    counts = {"g1": 0, "g2": 0, "ntt": 0}
+    counts = {"g1": 0, "g2": 0, "ntt": 0, "mid": 0}
     points = 0
     bad = []
     it = 0
     while time.time() - t0 < budget:
         sel = it % 8
         try:
-            if sel < 4: ok, what = fuzz_msm(rng, it // 8 * 4 + sel, ctxs, False)
+            if mid: ok, what = fuzz_mid(rng, it, state)
+            elif sel < 4: ok, what = fuzz_msm(rng, it // 8 * 4 + sel, ctxs, False)
             elif sel == 4: ok, what = fuzz_msm(rng, it // 8, ctxs, True)
             else: ok, what = fuzz_ntt(rng, it // 8 * 3 + sel - 5)
         except Exception as e:                                      # an error return is a finding too: report, go on
-            ok, what = False, dict(kind=("g1" if sel < 4 else "g2" if sel == 4 else "ntt"), iteration=it, error=repr(e))
+            ok, what = False, dict(kind=("mid" if mid else "g1" if sel < 4 else "g2" if sel == 4 else "ntt"), iteration=it, error=repr(e))
         counts[what["kind"]] += 1
         points += what.get("n", 0)
         if not ok:
@@ -152,6 +200,12 @@ def main():
     redo = {name: c.tail_redone() for name, c in ctxs.items()}
     for c in ctxs.values():
         c.close()
+    if mid:
+        for _, c, _ in state.values():
+            c.close()
+        print("seed %d, %.0f s: %d mid-size MSMs over the all-distinct progression (%d points in all); mismatches: %d"
+              % (seed, time.time() - t0, counts["mid"], points, len(bad)))
+        sys.exit(1 if bad else 0)
     print("seed %d, %.0f s: %d G1 MSMs (%d points in all), %d G2 MSMs, %d NTTs against the oracle; mismatches: %d; tails redone: %s"
           % (seed, time.time() - t0, counts["g1"], points, counts["g2"], counts["ntt"], len(bad), redo))
     sys.exit(1 if bad else 0)

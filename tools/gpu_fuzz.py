@@ -9,6 +9,9 @@ mid: MSMs of 2^17 .. 2^24.3 points (ragged sizes, where the plan changes run len
 sort records, oversized partitions, window groups) over a window of the ALL-DISTINCT progression P_i = (a + i b) G
 (sppark_g1_generate_progression), device-resident, expected (a sum s_i + b sum i s_i mod r) G from integer arithmetic on the
 scalars (oracle/fold.py) and one oracle scalar multiplication: any wrong gather index changes the result.
+api: the other ways into the same path at 1 .. 2^16 points: host / device buffers mixed, window groups and chunks that do not
+divide n, a bounded scratch, preloaded bases (a prefix of them), fixed-base tables with forced widths, bitmap batch
+additions (with and without a reference map), LDEs of every field (2^0 .. 2^12, blow-up 2 .. 8, with the coefficient output).
 NTT: all fields, sizes 2^1 .. 2^20, the 16 modes, inputs heavy in the values where a reduction can go wrong
 (0, 1, p - 1, p - 2, 2^32 - 1, 2^32, 2^64 - 2^32 ..., all-equal arrays, one-hot arrays)."""
 import os
@@ -81,6 +84,65 @@ def fuzz_msm(rng, it, ctxs, g2):
         exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
         got = sppark_amd.to_affine(out, name)
     return bool((got == exp).all()), what
+
+
+def fuzz_api(rng, it, state):
+    import torch
+    sel = it % 4
+    if sel == 3:                                                    # LDE
+        field = NTT_FIELDS[(it // 4) % len(NTT_FIELDS)]
+        small = field in ("gl64", "bb31")
+        lg, lgb = int(rng.integers(0, 13 if small else 10)), int(rng.integers(1, 4))
+        x, _ = ntt_edge_input(rng, field, lg) if lg else (recipe.ntt_input(field, 0, 5), 0)
+        w = 1 if small else 4
+        exp, aux_exp = O.lde(field, x, lgb, want_aux=True)
+        buf = np.zeros(((1 << (lg + lgb)), w), dtype=x.dtype); buf[:1 << lg] = x.reshape(-1, w)
+        aux = np.zeros((1 << lg, w), dtype=x.dtype)
+        sppark_amd.LDE(0, buf, lg, lgb, field, aux_out=aux)
+        return bool((buf.reshape(exp.shape) == exp).all() and (aux.reshape(aux_exp.shape) == aux_exp).all()), dict(kind="api", what="lde", field=field, lg=lg, lgb=lgb)
+    curve, name = G1[(it // 4) % len(G1)]
+    n = max(1, int(2 ** rng.uniform(0, 16)) + int(rng.integers(-3, 4)))
+    flagged = bool(rng.integers(0, 2))
+    pts, sc = recipe.msm_inputs(curve, n, int(rng.integers(1, 1 << 30)), ndistinct=int(rng.choice([1, 3, 64, 700])), flagged=flagged, edge=bool(rng.integers(0, 2)))
+    sc = scalar_shape(rng, curve, sc, n, int(rng.integers(0, 8)))
+    st = pts.shape[1]
+    dev = lambda a: torch.from_numpy(a).cuda()
+    if sel == 2:                                                    # bitmap batch addition
+        r = O.FR_MODULUS[curve]
+        words = (n + 31) // 32
+        bm = rng.random(words * 32) < rng.choice([0.0, 0.03, 0.5, 1.0]); rm = rng.random(words * 32) < 0.3
+        use_ref = bool(rng.integers(0, 2))
+        s = np.zeros((n, 32), dtype=np.uint8)
+        pick = bm ^ rm if use_ref else bm
+        s[pick[:n]] = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
+        if use_ref: s[(pick & rm)[:n]] = np.frombuffer((r - 1).to_bytes(32, "little"), dtype=np.uint8)
+        bw = np.packbits(bm.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+        rw = np.packbits(rm.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1)
+        out = sppark_amd.batch_addition(pts, bw, rw if use_ref else None, name, ffi_affine_sz=st)
+        return bool((sppark_amd.to_affine(out, name) == O.msm_affine(curve, pts, s, algo=0, param=4)).all()), dict(kind="api", what="batch_addition", curve=name, n=n, ref=use_ref)
+    ctx = sppark_amd.MsmContext(name)
+    try:
+        exp = O.msm_affine(curve, pts, sc, algo=0, param=8)
+        if sel == 0:                                                # buffers x groups x chunks x scratch bound
+            groups = int(rng.choice([0, 1, 2, 3, 5])); chunk = int(rng.choice([0, 0, 1 + n // 3, 4096, 7001]))
+            ctx.tune(wbits=int(rng.choice([0, 0, 9, 13])))
+            ctx.tune_pipeline(groups=groups, chunk_points=chunk, max_scratch_bytes=int(rng.choice([0, 0, 0, 1 << 26])))
+            hp, hs = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            out = ctx.invoke(pts if hp else dev(pts), sc if hs else dev(sc), ffi_affine_sz=st)
+            what = dict(what="pipeline", groups=groups, chunk=chunk, host_points=hp, host_scalars=hs)
+        else:                                                       # preloaded bases, plain or with fixed-base tables
+            fixed = bool(rng.integers(0, 2)); wb = int(rng.choice([0, 8, 10, 13, 16, 21])) if fixed else 0
+            ctx.tune(wbits=wb)
+            ctx.set_points(pts if rng.integers(0, 2) else dev(pts), ffi_affine_sz=st, fixed_base=fixed)
+            ctx.tune(wbits=0)
+            m = n if rng.integers(0, 2) else max(1, n // int(rng.integers(2, 5)))
+            s_ = np.ascontiguousarray(sc[:m])
+            out = ctx.invoke(None, s_ if rng.integers(0, 2) else dev(s_), npoints=m)
+            if m < n: exp = O.msm_affine(curve, pts[:m], s_, algo=0, param=8)
+            what = dict(what="preloaded", fixed=fixed, wbits=wb, m=m)
+        return bool((sppark_amd.to_affine(out, name) == exp).all()), dict(kind="api", curve=name, n=n, flagged=flagged, **what)
+    finally:
+        ctx.close()
 
 
 A_PROG, B_PROG = 0x243f6a8885a308d313198a2e03707344, 0xa4093822299f31d0082efa99       # < 2^126, < 2^96
@@ -176,10 +238,11 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
     rng = np.random.default_rng(seed)
     mid = len(sys.argv) > 3 and sys.argv[3] == "mid"
-    ctxs = {} if mid else {name: sppark_amd.MsmContext(name) for _, name in G1}
+    api = len(sys.argv) > 3 and sys.argv[3] == "api"
+    ctxs = {} if mid or api else {name: sppark_amd.MsmContext(name) for _, name in G1}
     state = {}
     t0 = time.time()
-    counts = {"g1": 0, "g2": 0, "ntt": 0, "mid": 0}
+    counts = {"g1": 0, "g2": 0, "ntt": 0, "mid": 0, "api": 0}
     points = 0
     bad = []
     it = 0
@@ -187,11 +250,12 @@ def main():
         sel = it % 8
         try:
             if mid: ok, what = fuzz_mid(rng, it, state)
+            elif api: ok, what = fuzz_api(rng, it, state)
             elif sel < 4: ok, what = fuzz_msm(rng, it // 8 * 4 + sel, ctxs, False)
             elif sel == 4: ok, what = fuzz_msm(rng, it // 8, ctxs, True)
             else: ok, what = fuzz_ntt(rng, it // 8 * 3 + sel - 5)
         except Exception as e:                                      # an error return is a finding too: report, go on
-            ok, what = False, dict(kind=("mid" if mid else "g1" if sel < 4 else "g2" if sel == 4 else "ntt"), iteration=it, error=repr(e))
+            ok, what = False, dict(kind=("mid" if mid else "api" if api else "g1" if sel < 4 else "g2" if sel == 4 else "ntt"), iteration=it, error=repr(e))
         counts[what["kind"]] += 1
         points += what.get("n", 0)
         if not ok:
@@ -200,11 +264,13 @@ def main():
     redo = {name: c.tail_redone() for name, c in ctxs.items()}
     for c in ctxs.values():
         c.close()
-    if mid:
+    if mid or api:
         for _, c, _ in state.values():
             c.close()
-        print("seed %d, %.0f s: %d mid-size MSMs over the all-distinct progression (%d points in all); mismatches: %d"
-              % (seed, time.time() - t0, counts["mid"], points, len(bad)))
+        print("seed %d, %.0f s: %d %s; mismatches: %d"
+              % (seed, time.time() - t0, counts["mid"] + counts["api"],
+                 "mid-size MSMs over the all-distinct progression (%d points in all)" % points if mid else
+                 "calls through the pipeline / preloaded / fixed-base / batch-addition / LDE entry points", len(bad)))
         sys.exit(1 if bad else 0)
     print("seed %d, %.0f s: %d G1 MSMs (%d points in all), %d G2 MSMs, %d NTTs against the oracle; mismatches: %d; tails redone: %s"
           % (seed, time.time() - t0, counts["g1"], points, counts["g2"], counts["ntt"], len(bad), redo))

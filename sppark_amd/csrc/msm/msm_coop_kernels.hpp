@@ -62,51 +62,64 @@ SPPARK_DEVFN void coop_tree_sum(coop_img<FP, CAP>* img, unsigned s0, coop_ctx<FP
     }
 }
 
-static inline size_t top_bits_coop_lds(size_t nl) { return 2 * 4 * nl * 64 * 4 + 4 * nl * COOP_NT * 4; }
+// (the exchange area of the cooperative operations + an image of COOP_NT / 2 points: 56 KB on fourteen limbs, two work-groups per CU)
+static inline size_t top_bits_coop_lds(size_t nl) { return 2 * 4 * nl * 64 * 4 + 4 * nl * (COOP_NT / 2) * 4; }
 
-// k_bucket_top_bits with the tree and the doubling chain in cooperative form (same grid, same per-lane gather, same output)
+// k_bucket_top_bits with the tree and the doubling chain in cooperative form (same per-lane gather, same sums), one work-group
+// per PIECE of a sum (msm_kernels.hpp bucket_top_piece; sb = sp = 1: per sum, as k_bucket_top_bits): part q of window w.
+// The first level of the tree is one-wave additions by the lower half of the lanes (the upper half hands over through the
+// image, which then holds COOP_NT / 2 points: two work-groups fit a CU); the rest is cooperative.
+// 2^20 points (16 windows of 4096 items, the plain sum in two pieces): 0.43 -> 0.36 ms; profiles/r06_msm_top_cut_sweep.log.
 template<class FP>
 __global__ __launch_bounds__(COOP_NT)
 void k_bucket_top_bits_coop(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<FP::N>* __restrict__ A,
-                            const xyzz_mem<FP::N>* __restrict__ Wt, unsigned nitems, unsigned m, unsigned lgG)
+                            const xyzz_mem<FP::N>* __restrict__ Wt, unsigned nitems, unsigned m, unsigned lgG,
+                            unsigned sb, unsigned sp)
 {
     extern __shared__ unsigned char top_lds[];
     coop_lds<FP>* ex = reinterpret_cast<coop_lds<FP>*>(top_lds);
-    coop_img<FP, COOP_NT>* img = reinterpret_cast<coop_img<FP, COOP_NT>*>(top_lds + sizeof(coop_lds<FP>));
-    const unsigned b = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    coop_img<FP, COOP_NT / 2>* img = reinterpret_cast<coop_img<FP, COOP_NT / 2>*>(top_lds + sizeof(coop_lds<FP>));
+    const unsigned q = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const top_piece pc = bucket_top_piece(q, m, sb, sp);
     {
-        const xyzz_dev<FP> acc = bucket_top_gather<FP>(A, Wt, nitems, m, b, w, tid, COOP_NT);
-        img->store(tid, acc);
+        xyzz_dev<FP> acc = bucket_top_gather<FP>(A, Wt, nitems, m, pc.b, w, pc.sub * COOP_NT + tid, pc.nsub * COOP_NT);
+        if (tid >= COOP_NT / 2) img->store(tid - COOP_NT / 2, acc);
+        coop_barrier();
+        if (tid < COOP_NT / 2) {                                    // (slot tid is read and rewritten by lane tid alone)
+            bucket_add_fast<FP>(acc, img->load(tid));
+            img->store(tid, acc);
+        }
     }
     coop_barrier();
     coop_ctx<FP> c{ex, tid >> 6, tid & 63, 0};
     // (with fewer items than lanes the upper lanes hold infinity: the tree starts where there is something to add)
-    coop_tree_sum<FP, COOP_NT>(img, nitems >= COOP_NT ? COOP_NT / 2 : nitems / 2, c);
+    const unsigned live = nitems / pc.nsub;
+    coop_tree_sum<FP, COOP_NT / 2>(img, live >= COOP_NT / 2 ? COOP_NT / 4 : live / 2, c);
     xyzz_dev<FP> x;
     if (c.lane == 0) x = img->load(0); else x.set_inf();
-    if (b < m) {
+    if (pc.b < m) {
         #pragma unroll 1
-        for (unsigned k = 0; k < b + lgG; k++) coop_dbl<FP>(x, c);
+        for (unsigned k = 0; k < pc.b + lgG; k++) coop_dbl<FP>(x, c);
     }
-    if (tid == 0) x.store(&parts[(size_t)w * (m + 1) + b]);
+    if (tid == 0) x.store(&parts[(size_t)w * (m * sb + sp) + q]);
 }
 
-// k_bucket_top_sum: the m + 1 <= 32 parts of a window, one work-group of four waves per window
+// k_bucket_top_sum: the nparts <= 32 parts of a window (m + 1 sums, or their pieces), one work-group of four waves per window
 // |fin| (nullable): the window sum also in the reference's wire image (what k_finalize would write), coordinate r by wave r --
 // the small MSMs save that launch
 template<class FP>
 __global__ __launch_bounds__(COOP_NT)
-void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned m,
+void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned nparts,
                            xyzz_mem<FP::NW>* __restrict__ fin)
 {
     __shared__ coop_lds<FP> ex;
     __shared__ coop_img<FP, 32> img;
     const unsigned w = blockIdx.x, tid = threadIdx.x;
-    if (tid < 32) img.store(tid, bucket_top_sum_gather<FP>(parts, m, w, tid));
+    if (tid < 32) img.store(tid, bucket_top_sum_gather<FP>(parts, nparts - 1, w, tid));
     coop_barrier();
     coop_ctx<FP> c{&ex, tid >> 6, tid & 63, 0};
     unsigned s0 = 1;
-    while (2 * s0 < m + 1) s0 <<= 1;
+    while (2 * s0 < nparts) s0 <<= 1;
     coop_tree_sum<FP, 32>(&img, s0, c);
     if (tid == 0) img.load(0).store(&out[w]);
     if (fin != nullptr && c.lane == 0) {                            // (xyzz_dev::store_std, a coordinate per wave)

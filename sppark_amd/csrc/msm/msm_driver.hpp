@@ -740,7 +740,7 @@ private:
                 hipLaunchKernelGGL(k_bucket_small_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), 0, stream,
                                    A2, buckets, (const u32*)(blob + l.off[0]), p.NB, m);
                 HIP_OK(hipGetLastError());
-                hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, W2, A2, m,
+                hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, W2, A2, m + 1,
                                    (std_bucket_t*)(blob + l.sums));            // (the wire image with it: no k_finalize)
                 HIP_OK(hipGetLastError());
                 result = W2; finalized = true;
@@ -777,12 +777,22 @@ private:
                     if constexpr (MONTX) {
                         if (coop) {
                             // the tree and the doubling chains by four waves per operation (msm_coop_kernels.hpp)
+                            // (a work-group per PIECE of a sum: msm_kernels.hpp bucket_top_piece; join == 7: per sum, the A/B switch)
+                            unsigned sb = 1, sp = 1;
+                            if (tune.join != 7) bucket_top_cut(nitems, COOP_NT, sb, sp);
+#ifdef SPPARK_TUNING
+                            if (const char* e = getenv("SPPARK_TOP_CUT")) {         // "sb sp" as two digits, e.g. 24 (sweeps only)
+                                const unsigned v = (unsigned)atoi(e), s1 = v / 10, s2 = v % 10;
+                                if (s1 >= 1 && s2 >= 1 && m * s1 + s2 <= 32 && nitems >= COOP_NT * s2) { sb = s1; sp = s2; }
+                            }
+#endif
                             const size_t lds = top_bits_coop_lds(fp_d::N);
                             if (lds > 65536) lds_attr((const void*)k_bucket_top_bits_coop<fp_d>, lds);
-                            hipLaunchKernelGGL(k_bucket_top_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), lds, stream,
-                                               oa, ia, iw, nitems, m, lgG);
+                            hipLaunchKernelGGL(k_bucket_top_bits_coop<fp_d>, dim3(m * sb + sp, p.nwins), dim3(COOP_NT), lds, stream,
+                                               oa, ia, iw, nitems, m, lgG, sb, sp);
                             HIP_OK(hipGetLastError());
-                            hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m, (std_bucket_t*)nullptr);
+                            hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m * sb + sp,
+                                               (std_bucket_t*)nullptr);
                             HIP_OK(hipGetLastError());
                         }
                     }

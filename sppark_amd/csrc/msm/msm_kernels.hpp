@@ -594,6 +594,32 @@ SPPARK_DEVFN void bucket_top_finish(xyzz_dev<FP>& acc, xyzz_mem<FP::N>* parts, u
     }
     acc.store(&parts[(size_t)w * (m + 1) + b]);
 }
+// The sums CUT INTO PIECES (round 6, the cooperative kernels): a work-group per piece instead of per sum.  The work-groups of a
+// top are few (13 x 16 at 2^20 points) and each one's time is its lanes' chain of additions -- 8 per lane for a subset sum of
+// 4096 items, 16 for the plain sum, which alone sets the kernel's time.  Piece s of |nsub| of a sum is what the lanes
+// s nt .. (s + 1) nt - 1 of a work-group of nsub x nt lanes would gather (bucket_top_gather with that lane number: every
+// piece owns as many selected items as any other); doubling is linear, so every piece takes its sum's b + lgG doublings
+// itself and the pieces of a window are its m sb + sp parts.  q: part number within the window.
+struct top_piece { unsigned b, sub, nsub; };
+SPPARK_DEVFN top_piece bucket_top_piece(unsigned q, unsigned m, unsigned sb, unsigned sp)
+{
+    top_piece t;
+    if (q < m * sb) { t.b = q / sb; t.sub = q % sb; t.nsub = sb; }
+    else            { t.b = m; t.sub = q - m * sb; t.nsub = sp; }
+    return t;
+}
+// pieces per subset sum (sb) and per plain sum (sp) for |nitems| items and work-groups of |nt| lanes.  Measured
+// (profiles/r06_msm_top_cut_sweep.log, 2^18 .. 2^24 points): cutting the PLAIN sum of a 4096-item top in two -- the one
+// work-group with twice the additions per lane of all the others -- is the whole gain (tail 2^19 0.79 -> 0.72 ms, 2^20
+// 0.99 -> 0.94, 2^21 1.24 -> 1.16, 2^22 1.35 -> 1.30); more pieces (2 / 4, 2 / 8: twice the work-groups, two per CU) bring
+// nothing further -- what is left is the tree and the doublings -- and at 2048 items (2^18 points) nothing changes.
+// At most 32 parts per window (k_bucket_top_sum_coop's image).
+static inline void bucket_top_cut(unsigned nitems, unsigned nt, unsigned& sb, unsigned& sp)
+{
+    sb = 1;
+    sp = nitems >= 16 * nt ? 2 : 1;
+}
+
 template<class FP>
 SPPARK_DEVFN xyzz_dev<FP> bucket_top_sum_gather(const xyzz_mem<FP::N>* parts, unsigned m, unsigned w, unsigned tid)
 {

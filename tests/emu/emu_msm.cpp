@@ -198,6 +198,8 @@ static unsigned g_pack = 0;
 extern "C" void emu_msm_pack(unsigned mode) { g_pack = mode; }       // 0: 8-byte level-A records
 static unsigned g_piece_cmax = 0;                                   // join == 2: pieces per bucket the piece tree takes (0: from the average bucket)
 extern "C" void emu_msm_piece_cmax(unsigned c) { g_piece_cmax = c; }
+static unsigned emu_top_pieces = 1;                                 // the subset-sum top by pieces of a sum: 1 = the product's cut, 0 = per sum, "sb sp" forced
+extern "C" void emu_msm_top_pieces(unsigned on) { emu_top_pieces = on; }
 
 extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride, size_t npoints,
                        const unsigned char* scalars, int mont,
@@ -426,20 +428,32 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
         // are the product's own functions, the LDS tree between them a plain pairwise reduction with the same additions
         if (top != 1 && nitems <= (top ? top : BUCKET_TOP_MAX) && nitems >= 32 && (nitems & (nitems - 1)) == 0 && p.NB / p.K >= 32) {
             const unsigned m = lg2_floor(nitems);
-            std::vector<inst_m> parts((size_t)p.nwins * (m + 1));
+            // emu_top_pieces: a work-group per PIECE of a sum (bucket_top_piece / bucket_top_cut, as k_bucket_top_bits_coop
+            // runs them: the gather of a piece with its virtual lane numbers, the doublings per piece, the parts of a
+            // window = its pieces); off: per sum (k_bucket_top_bits)
+            unsigned sb = 1, sp = 1;
+            if (emu_top_pieces == 1) bucket_top_cut(nitems, BUCKET_TOP_NT, sb, sp);
+            else if (emu_top_pieces >= 10 && nitems >= BUCKET_TOP_NT * (emu_top_pieces % 10) && m * (emu_top_pieces / 10) + emu_top_pieces % 10 <= 32) {
+                sb = emu_top_pieces / 10; sp = emu_top_pieces % 10;         // a forced cut "sb sp" (two digits), as SPPARK_TOP_CUT
+            }
+            const unsigned np = m * sb + sp;
+            std::vector<inst_m> parts((size_t)p.nwins * np);
             auto tree = [&](std::vector<xyzz_dev<inst_fp>>& acc, unsigned nt) {
                 for (unsigned s = nt >> 1; s >= 1; s >>= 1)
                     for (unsigned tid = 0; tid < s; tid++) bucket_add_fast<inst_fp>(acc[tid], acc[tid + s]);
             };
             for (unsigned w = 0; w < p.nwins; w++) {
-                for (unsigned b = 0; b <= m; b++) {
+                for (unsigned q = 0; q < np; q++) {
+                    const top_piece pc = bucket_top_piece(q, m, sb, sp);
                     std::vector<xyzz_dev<inst_fp>> acc(BUCKET_TOP_NT);
-                    for (unsigned tid = 0; tid < BUCKET_TOP_NT; tid++) acc[tid] = bucket_top_gather<inst_fp>(ia, iw, nitems, m, b, w, tid, BUCKET_TOP_NT);
+                    for (unsigned tid = 0; tid < BUCKET_TOP_NT; tid++)
+                        acc[tid] = bucket_top_gather<inst_fp>(ia, iw, nitems, m, pc.b, w, pc.sub * BUCKET_TOP_NT + tid, pc.nsub * BUCKET_TOP_NT);
                     tree(acc, BUCKET_TOP_NT);
-                    bucket_top_finish<inst_fp>(acc[0], parts.data(), m, lgG, b, w);
+                    if (pc.b < m) for (unsigned k = 0; k < pc.b + lgG; k++) bucket_dbl_fast<inst_fp>(acc[0]);
+                    acc[0].store(&parts[(size_t)w * np + q]);
                 }
                 std::vector<xyzz_dev<inst_fp>> acc(32);
-                for (unsigned tid = 0; tid < 32; tid++) acc[tid] = bucket_top_sum_gather<inst_fp>(parts.data(), m, w, tid);
+                for (unsigned tid = 0; tid < 32; tid++) acc[tid] = bucket_top_sum_gather<inst_fp>(parts.data(), np - 1, w, tid);
                 tree(acc, 32);
                 acc[0].store(&ow[w]);
             }

@@ -332,16 +332,24 @@ def test_low_latency_point_ops_on_host(oracle, curve, feature):
 
 def test_msm_bucket_sum_top_on_host(oracle):
     """The subset-sum top of the bucket sums (bucket_top_gather / _finish / _sum_gather): hand-over at 32 ... 4096 partial
-    sums per window, chunks of 4 and 8, against the oracle and against the chunked levels alone (top = 1)."""
+    sums per window, chunks of 4 and 8, against the oracle and against the chunked levels alone (top = 1); with a
+    work-group per PIECE of a sum (bucket_top_piece; the cooperative kernel's form: the plain sum of a 4096-item top in two
+    pieces, and here also forced cuts of 2 / 4 and 1 / 2 pieces at every size) and per sum."""
     O = oracle
     L = _emu("BLS12_381")
+    L.emu_msm_top_pieces.argtypes = [ctypes.c_uint]; L.emu_msm_top_pieces.restype = None
     n = 700
     pts, sc = recipe.msm_inputs(0, n, 4242, edge=False)
     exp = O.msm_affine(0, pts, sc, algo=0, param=4)
-    for wb, K, top in ((9, 4, 0), (11, 8, 0), (13, 4, 256), (13, 8, 32), (16, 8, 0), (16, 8, 1)):
-        out = np.zeros(144, dtype=np.uint8)
-        L.emu_msm(P(out), P(pts), 96, n, P(sc), 0, wb, 8, 4, K, 2, 1, None, top)
-        assert (O.jac_to_affine(0, out) == exp).all(), (wb, K, top)
+    try:
+        for pieces in (1, 0, 24, 12):                               # automatic, per sum, forced "sb sp"
+            L.emu_msm_top_pieces(pieces)
+            for wb, K, top in ((9, 4, 0), (11, 8, 0), (12, 4, 0), (13, 4, 256), (13, 8, 32), (14, 8, 0), (15, 8, 0), (16, 8, 0), (16, 8, 1)):
+                out = np.zeros(144, dtype=np.uint8)
+                L.emu_msm(P(out), P(pts), 96, n, P(sc), 0, wb, 8, 4, K, 2, 1, None, top)
+                assert (O.jac_to_affine(0, out) == exp).all(), (pieces, wb, K, top)
+    finally:
+        L.emu_msm_top_pieces(1)
 
 
 @pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])

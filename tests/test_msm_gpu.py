@@ -1035,6 +1035,13 @@ def test_msm_bucket_sum_top(oracle, libs, curve, name):
                     ctx.tune_sums(top)
                     out = ctx.invoke(PT, SC, ffi_affine_sz=PT.shape[1])
                     assert (sppark_amd.to_affine(out, ctx_name) == exp).all(), (ctx_name, wb, K, top)
+        # the cooperative top runs a work-group per PIECE of a sum (bucket_top_piece: the plain sum of a top of 4096 items and
+        # more in two pieces -- wb 16 / 18 above); tail variant 7: per sum
+        ctx.tune_tail(7, 0)
+        for wb, top in ((16, 0), (18, 32768), (13, 512)):
+            ctx.tune(wbits=wb); ctx.tune_sums(top)
+            out = ctx.invoke(PT, SC, ffi_affine_sz=PT.shape[1])
+            assert (sppark_amd.to_affine(out, ctx_name) == exp).all(), (ctx_name, wb, top, "per sum")
         ctx.close()
 
 

@@ -42,6 +42,7 @@ for lg in (int(a) for a in args):
         run("no cooperative kernels", join=4)
         run("no piece tree", join=5)
         run("per-lane conversion", join=6)
+        run("top per sum", join=7)
     if mode == "sort":
         pl = ctx.plan(n)
         for lb in range(max(1, pl["low_bits"] - 1), min(13, pl["window_bits"] - 1) + 1):

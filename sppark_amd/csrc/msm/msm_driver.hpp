@@ -234,6 +234,7 @@ public:
             else (void)hipGetLastError();
             if (cur >= 0 && cur != gpu->hip_id) (void)hipSetDevice(cur);
         }
+        if constexpr (G2_COOP_BUILT) { if (fp_d::NL >= 14) tune.long_runs = 1; }       // (the wave-pair accumulation's run lengths: msm_plan.hpp)
         if (stream == nullptr) {
             // a non-blocking private stream (a blocking one pays an implicit legacy-stream check on
             // every launch: +36 ms on a 2^26 MSM); join_default_stream() orders each call after the

@@ -32,6 +32,7 @@ struct msm_tunables {                   // 0 = automatic
     unsigned join = 0;                  // record list: 1 = no k_join_runs (every segment through the fan-in tree), 2 = no one-launch narrow end, 3 = no low-latency bucket-sum kernels, 4 = no cooperative (four waves per operation) kernels (A/B switches)
     unsigned K1 = 0;                    // bucket sums: buckets per work item of the first level (0 = K)
     unsigned g2_coop = 0;               // G2 only: the accumulation with one Fp2 component per wave (msm_g2c_kernels.hpp): 0 = for the 14-limb base fields, 1 = always, 2 = never
+    unsigned long_runs = 0;             // set by the driver for G2 over the 14-limb base fields (the wave-pair accumulation): the run lengths of that kernel (make_plan)
     size_t resident_lanes = 0;          // lanes of k_accumulate the device holds at once (set by the driver from the occupancy query; 0 = unknown)
     size_t chunk = 0;                   // points per chunk of the chunked path (0 = automatic)
     size_t max_scratch = 0;             // upper bound for the scratch blob in bytes (0 = what the device has)
@@ -101,7 +102,13 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // (In WORK-GROUPS: the grid is ceil(chunks / 256) groups of 256 lanes per window, and the groups, not the lanes, are
     // what must fit -- 300 000 points at L = 39 are 130 781 lanes but 17 x 31 = 527 groups for 512 places: 1.17 ms
     // instead of 0.97 at L = 32; at L = 40 they are 510.)
-    if (!t.L && t.resident_lanes >= 256 && p.n >= 4096) {
+    // G2 by wave pairs (msm_g2c_kernels.hpp): an addition costs three of G1's and a run boundary a full Fp2 addition in the join,
+    // half as many runs are resident, and the fit above is calibrated on G1's kernel -- so longer runs, from a sweep of its own
+    // (BLS12-381 G2, profiles/r06_g2_run_length.log): 2^16 3.39 -> 3.13 ms and 2^18 6.55 -> 6.29 with 32, 2^20 13.9 -> 13.3 and
+    // 2^21 24.1 -> 22.9 with 128 (2^19: 64 and 2^22: 128 were the choices already)
+    const bool g2_runs = !t.L && t.long_runs && lg >= 16 && lg < 25;
+    if (g2_runs) L = lg >= 20 ? 128u : lg >= 19 ? 64u : 32u;
+    if (!t.L && !g2_runs && t.resident_lanes >= 256 && p.n >= 4096) {
         const size_t R = t.resident_lanes / 256, T0 = (size_t)p.nwins * (((p.n + L - 1) / L + 255) / 256);
         const size_t k_hi = (T0 + R - 1) / R, k_lo = k_hi > 1 ? k_hi - 1 : 1;
         if (k_hi >= 2 && k_hi <= 64) {

@@ -8,7 +8,7 @@ for name, curve in (("bls12_381", O.BLS12_381_G2), ("bn254", O.BN254_G2)):
     fb = O.FP_BYTES[curve]
     base = np.zeros((1024, 2 * fb + 8), dtype=np.uint8)
     base[:, :2 * fb] = O.g1_gen_points(curve, 1024, 11)
-    for lg in (16, 20, 22):
+    for lg in (16, 18, 20, 21, 22):
         n = 1 << lg
         pts = torch.from_numpy(base[np.arange(n) % 1024]).cuda()
         g = torch.Generator(device="cuda"); g.manual_seed(1)

@@ -85,9 +85,12 @@ static inline msm_plan make_plan(size_t npoints, unsigned scalar_bits, const msm
     // run length: 64 entries per lane, 128 from 2^22 points on, 256 from 2^25 (every chunk boundary costs one
     // full addition in k_join_runs; the accumulation itself is flat in L as long as there are > 10^5 lanes per
     // window.  2^23: tail 3.46 -> 2.67 ms with 128, 2^26: 11.5 -> 10.4 ms with 256, profiles/r03_msm_tail.log)
-    // Below 2^22 points: 8..64 entries, twice what round 2 used (2^14..2^18: -5..-9 %, profiles/r03_msm_small_grid.log)
+    // Below 2^22 points: 8..128 entries -- what still fills one round of 131 072 resident lanes -- twice what round 2 used
+    // (2^14..2^18: -5..-9 %, profiles/r03_msm_small_grid.log); round 6: 128 instead of 64 at 2^20 / 2^21 (the accumulation is
+    // the same one or two full rounds, the record list is half: 2^21 BLS12-381 6.81 -> 6.64 ms, BLS12-377 6.85 -> 6.32, Pallas
+    // 3.63 -> 3.25, alt_bn128 unchanged; 2^20 3.78 -> 3.66 / unchanged; profiles/r06_msm_run_length_mid.log)
     unsigned L = t.L ? t.L : lg >= 22 ? (lg >= 25 ? 256u : 128u)
-                           : 1u << lg2_floor(std::min<size_t>(64, std::max<size_t>(8, entries / 131072)));
+                           : 1u << lg2_floor(std::min<size_t>(128, std::max<size_t>(8, entries / 131072)));
     // Round 4: FIT THE GRID TO THE DEVICE.  k_accumulate's lanes all run the same L additions, so its time is
     // (rounds of resident waves) x L: 17 windows x 2^18 points / 32 = 139 264 lanes are 1.06 x the 131 072 that two waves
     // per SIMD hold -- two rounds, the second one for 6 % of the work (0.96 ms where 16 windows take 0.70,

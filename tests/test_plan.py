@@ -93,7 +93,7 @@ def test_run_length_fits_whole_rounds_of_resident_waves(plan_lib):
                         if p["L"] > 4:                                                # ... tightly: one entry less per run would not fit
                             assert p["nwins"] * -(-(-(-n // (p["L"] - 1))) // 256) > rounds(p) * (R // 256), (n, R, p)
     out = (ctypes.c_uint * 21)()
-    for n, L in ((1 << 17, 20), (1 << 18, 35), (300000, 40), (1 << 22, 128), (12000000, 129), (1 << 13, 8), (1 << 16, 16), (1 << 20, 64), (1 << 26, 256)):
+    for n, L in ((1 << 17, 20), (1 << 18, 35), (300000, 40), (1 << 22, 128), (12000000, 129), (1 << 13, 8), (1 << 16, 16), (1 << 19, 64), (1 << 20, 128), (1 << 21, 128), (1 << 26, 256)):
         plan_lib.emu_make_plan_resident(n, 255, 131072, out)
         assert dict(zip(KEYS, out))["L"] == L, (n, dict(zip(KEYS, out)))
 

@@ -793,8 +793,9 @@ private:
                                                oa, ia, iw, nitems, m, lgG, sb, sp);
                             HIP_OK(hipGetLastError());
                             hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m * sb + sp,
-                                               (std_bucket_t*)nullptr);
+                                               (std_bucket_t*)(blob + l.sums));            // (the wire image with it: no k_finalize)
                             HIP_OK(hipGetLastError());
+                            finalized = true;
                         }
                     }
                     if (!coop) {

@@ -34,7 +34,7 @@ extern template __global__ void k_bucket_levelN_lat<msm_fp_d>(bucket_m*, bucket_
                                                           unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_bits<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_top_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, unsigned, unsigned);
-extern template __global__ void k_bucket_top_sum_coop<msm_fp_d>(bucket_m*, const bucket_m*, unsigned, xyzz_mem<msm_fp_d::NW>*);
+extern template __global__ void k_bucket_top_sum_coop<msm_fp_d>(bucket_m*, const bucket_m*, unsigned, xyzz_mem<msm_fp_d::NW>*, u32*, u32*);
 extern template __global__ void k_reduce_runs_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, const bucket_m*,
                                                          unsigned, unsigned, unsigned, int, const u32*);
 extern template __global__ void k_reduce_tail_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, u32*, bucket_m*, unsigned, unsigned, const u32*);

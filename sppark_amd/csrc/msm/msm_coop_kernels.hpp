@@ -107,11 +107,15 @@ void k_bucket_top_bits_coop(xyzz_mem<FP::N>* __restrict__ parts, const xyzz_mem<
 // k_bucket_top_sum: the nparts <= 32 parts of a window (m + 1 sums, or their pieces), one work-group of four waves per window
 // |fin| (nullable): the window sum also in the reference's wire image (what k_finalize would write), coordinate r by wave r --
 // the small MSMs save that launch
+// |flag_src| (nullable): the piece tree's "a bucket was beyond the tree" word is handed over with the sums -- copied to
+// |flag_dst| (the word behind fin[nwins - 1]: one device-to-host copy brings both) and CLEARED, so that the next MSM finds it
+// zero without a memset of its own (msm_driver.hpp)
 template<class FP>
 __global__ __launch_bounds__(COOP_NT)
 void k_bucket_top_sum_coop(xyzz_mem<FP::N>* __restrict__ out, const xyzz_mem<FP::N>* __restrict__ parts, unsigned nparts,
-                           xyzz_mem<FP::NW>* __restrict__ fin)
+                           xyzz_mem<FP::NW>* __restrict__ fin, u32* __restrict__ flag_src, u32* __restrict__ flag_dst)
 {
+    if (flag_src != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { *flag_dst = *flag_src; *flag_src = 0; }
     __shared__ coop_lds<FP> ex;
     __shared__ coop_img<FP, 32> img;
     const unsigned w = blockIdx.x, tid = threadIdx.x;

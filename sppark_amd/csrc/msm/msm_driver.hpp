@@ -85,6 +85,8 @@ private:
     std_bucket_t* h_sums = nullptr;     // pinned: window sums of every chunk in flight
     size_t h_sums_cap = 0;
     u32* h_flag = nullptr;              // pinned: "a bucket had more pieces than the piece tree takes" of the last MSM (enqueue)
+    const u32* h_flag_cur = nullptr;    // where invoke() reads that flag: |h_flag|, or the word behind the window sums (the small sizes)
+    u32* d_pflag = nullptr;             // the small sizes' flag on the device: zero between MSMs (the kernel that hands it over clears it)
     bool piece_pending = false;         // the last enqueue ran the piece tree and left the fan-in tree out
     std::vector<hipEvent_t> tev;        // timing events: [0] start, [1] end, [2+2g], [3+2g] around k_accumulate of group g
     unsigned char* pre_points = nullptr;    // points kept on the device by preload() (msm_t ctor with points, pippenger.cuh:351-385)
@@ -138,7 +140,7 @@ private:
         l.A1 = take(n1 * sizeof(bucket_t)); l.W1 = take(n1 * sizeof(bucket_t));
         l.A2 = take(n1 * sizeof(bucket_t)); l.W2 = take(n1 * sizeof(bucket_t));
         l.conv = take(INTERNAL && convert ? (size_t)p.n * conv_stride() : 0);     // points in the field's own records
-        l.sums = take((size_t)p.nwins * std::max(sizeof(std_bucket_t), sizeof(bucket_t)));
+        l.sums = take(((size_t)p.nwins + 1) * std::max(sizeof(std_bucket_t), sizeof(bucket_t)));     // (+ the small sizes' flag word)
         l.total = o;
         return l;
     }
@@ -256,6 +258,7 @@ public:
         if (stage) (void)hipFree(stage);
         if (h_sums) (void)hipHostFree(h_sums);
         if (h_flag) (void)hipHostFree(h_flag);
+        if (d_pflag) (void)hipFree(d_pflag);
         if (pre_points) (void)hipFree(pre_points);
         for (auto& e : tev) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_fork, ev_sorted[0], ev_sorted[1], ev_accdone[0], ev_accdone[1],
@@ -649,9 +652,25 @@ private:
         // (|may_defer|: the caller looks at the flag after this MSM -- invoke() with one chunk)
         const unsigned piece_cm = may_defer ? piece_tree_cmax(p, multi, fb_n) : 0;
         piece_pending = false;
+        // windows of up to 256 buckets (MSMs of up to 2^16 points): the subset sums straight from the buckets, then the parts of a
+        // window (msm_coop_kernels.hpp k_bucket_small_bits_coop); needs the offsets of every window: one window group
+        bool small_sums = false;
+        if constexpr (MONTX)
+            small_sums = !multi && fb_n == 0 && p.NB <= SMALL_SUMS_MAX_NB && p.NB >= 2 && tune.K1 == 0 && tune.top == 0 && tune.K == 0
+                         && tune.join != 3 && tune.join != 4;
+        // The flag of the piece tree on that path costs no launch of its own: it lives in a word that is ZERO between MSMs
+        // (no memset), and the last kernel of the path -- k_bucket_top_sum_coop, which writes the window sums' wire image --
+        // puts it behind the sums (one copy brings both to the host) and clears it.  (2^12: a 5 us fill with a 6 us gap in front
+        // of the levels and a 5 us copy behind them, of a 0.39 ms MSM.)  Other paths: memset, levels, a copy of their own.
+        bool flag_with_sums = false;
+        if constexpr (MONTX) flag_with_sums = small_sums && (piece_cm != 0 || redo);
+        if (flag_with_sums && !d_pflag) {
+            HIP_OK(hipMalloc((void**)&d_pflag, 64));
+            HIP_OK(hipMemsetAsync(d_pflag, 0, 64, stream));
+        }
         if (piece_cm && !redo) {
-            u32* flag = (u32*)(blob + l.flag);
-            HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
+            u32* flag = flag_with_sums ? d_pflag : (u32*)(blob + l.flag);
+            if (!flag_with_sums) HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
             const u32* off = (const u32*)(blob + l.off[0]);
             for (unsigned t = 0; (piece_cm >> (t + 1)) >= 1; t++) {
                 const unsigned last = (piece_cm >> (t + 2)) == 0;
@@ -667,7 +686,8 @@ private:
                 HIP_OK(hipGetLastError());
             }
             if (!h_flag) HIP_OK(hipHostMalloc((void**)&h_flag, 64, hipHostMallocDefault));
-            HIP_OK(hipMemcpyAsync(h_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+            if (!flag_with_sums) HIP_OK(hipMemcpyAsync(h_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+            h_flag_cur = flag_with_sums ? reinterpret_cast<const u32*>(h_out + p.nwins) : h_flag;
             piece_pending = true;
         }
         // ---- segmented record tree over the records of all windows -----------------------------
@@ -729,20 +749,17 @@ private:
         bucket_t* A1 = (bucket_t*)(blob + l.A1); bucket_t* W1 = (bucket_t*)(blob + l.W1);
         bucket_t* A2 = (bucket_t*)(blob + l.A2); bucket_t* W2 = (bucket_t*)(blob + l.W2);
         bucket_t* result;
-        // windows of up to 256 buckets (MSMs of up to 2^16 points): the subset sums straight from the buckets, then the parts of a
-        // window (msm_coop_kernels.hpp k_bucket_small_bits_coop); needs the offsets of every window: one window group
-        bool small_sums = false, finalized = false;
-        if constexpr (MONTX)
-            small_sums = !multi && fb_n == 0 && p.NB <= SMALL_SUMS_MAX_NB && p.NB >= 2 && tune.K1 == 0 && tune.top == 0 && tune.K == 0
-                         && tune.join != 3 && tune.join != 4;
+        bool finalized = false;
         if constexpr (MONTX) {
             if (small_sums) {
                 const unsigned m = lg2_floor(p.NB);
                 hipLaunchKernelGGL(k_bucket_small_bits_coop<fp_d>, dim3(m + 1, p.nwins), dim3(COOP_NT), 0, stream,
                                    A2, buckets, (const u32*)(blob + l.off[0]), p.NB, m);
                 HIP_OK(hipGetLastError());
+                std_bucket_t* fin = (std_bucket_t*)(blob + l.sums);
                 hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, W2, A2, m + 1,
-                                   (std_bucket_t*)(blob + l.sums));            // (the wire image with it: no k_finalize)
+                                   fin,                                         // (the wire image with it: no k_finalize)
+                                   flag_with_sums ? d_pflag : (u32*)nullptr, flag_with_sums ? reinterpret_cast<u32*>(fin + p.nwins) : (u32*)nullptr);
                 HIP_OK(hipGetLastError());
                 result = W2; finalized = true;
             }
@@ -793,7 +810,8 @@ private:
                                                oa, ia, iw, nitems, m, lgG, sb, sp);
                             HIP_OK(hipGetLastError());
                             hipLaunchKernelGGL(k_bucket_top_sum_coop<fp_d>, dim3(p.nwins), dim3(COOP_NT), 0, stream, ow, oa, m * sb + sp,
-                                               (std_bucket_t*)(blob + l.sums));            // (the wire image with it: no k_finalize)
+                                               (std_bucket_t*)(blob + l.sums),             // (the wire image with it: no k_finalize)
+                                               (u32*)nullptr, (u32*)nullptr);
                             HIP_OK(hipGetLastError());
                             finalized = true;
                         }
@@ -838,7 +856,7 @@ private:
                 hipLaunchKernelGGL((k_finalize<fp_d, STD_WORDS>), dim3((p.nwins + 63) / 64), dim3(64), 0, stream, fin, result, p.nwins);
                 HIP_OK(hipGetLastError());
             }
-            HIP_OK(hipMemcpyAsync(h_out, fin, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipMemcpyAsync(h_out, fin, (p.nwins + (flag_with_sums ? 1 : 0)) * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
         } else {
             HIP_OK(hipMemcpyAsync(h_out, result, p.nwins * sizeof(std_bucket_t), hipMemcpyDeviceToHost, stream));
         }
@@ -1039,7 +1057,7 @@ public:
             need = std::max(need, layouts[c].total); longest = std::max(longest, cb[c + 1] - cb[c]);
         }
         reserve(need);
-        reserve_sums(nchunks * MAX_WINS);
+        reserve_sums(nchunks * MAX_WINS + 1);                    // (+ the small sizes' flag word behind the sums of a one-chunk MSM)
         const size_t st_pts = align_up(pts_dev ? 0 : longest * ffi_affine_sz), st_sc = align_up(sc_dev ? 0 : longest * SCALAR_BYTES);
         if (host) { reserve_stage(2 * (st_pts + st_sc)); if (nchunks > 1) need_cpy(); }
 
@@ -1080,7 +1098,7 @@ public:
         last_chunks = (unsigned)nchunks;
         // the piece tree left a bucket with more pieces than it takes (skewed scalars): the fan-in tree over the records it
         // left, the bucket sums again (single chunk: the piece tree is for sizes far below a chunk)
-        if (piece_pending && *h_flag != 0) {
+        if (piece_pending && *h_flag_cur != 0) {
             enqueue(plans[0], layouts[0], nullptr, in_stride, preconverted, nullptr, mont, h_sums, false, 0, 0, true);
             HIP_OK(hipStreamSynchronize(stream));
             last_redo++;

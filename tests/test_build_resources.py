@@ -166,3 +166,22 @@ def test_tuning_build_still_compiles(unit, feature):
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-Wno-duplicate-decl-specifier", "-DSPPARK_TUNING"]
                        + ("-D" + feature).split() + [src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_host_field_adc_chains_match_plain_cios(tmp_path):
+    """ff/mont_host.hpp (the Horner over the window sums every MSM ends in): the adc-chain product and the dedicated square
+    against the plain CIOS loop on random and edge operands (all-ones limbs, p - 1), three moduli of 6 / 4 / 6 limbs.  Built with
+    the product's own host compiler (hipcc's clang: the builtins the fast path needs)."""
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("clang++ of the ROCm toolchain not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_field_bench")
+    subprocess.check_call([clang, "-O2", "-std=c++17", "-I", os.path.join(root, "sppark_amd", "csrc"),
+                           os.path.join(root, "tools", "host_field_bench.cpp"), "-o", exe])
+    out = subprocess.run([exe, "20000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("mismatches 0;") == 3, out.stdout
+    src = open(os.path.join(root, "sppark_amd", "csrc", "ff", "mont_host.hpp")).read()
+    assert "SPPARK_HOST_ADC" in src

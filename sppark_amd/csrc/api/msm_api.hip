@@ -26,6 +26,8 @@ extern template __global__ void k_piece_level<msm_fp_d>(bucket_m*, u32*, bucket_
 extern template __global__ void k_bucket_small_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const u32*, unsigned, unsigned);
 extern template __global__ void k_piece_level_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
                                                              unsigned, unsigned, unsigned, u32*);
+extern template __global__ void k_piece_tail_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
+                                                            unsigned, unsigned, unsigned, u32*);
 extern template __global__ void k_bucket_level1<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_levelN<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                       unsigned, unsigned, unsigned, unsigned);

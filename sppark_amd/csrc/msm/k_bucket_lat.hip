@@ -20,4 +20,6 @@ template __global__ void k_bucket_levelN_coop<msm_fp_d>(bucket_m*, bucket_m*, co
 template __global__ void k_bucket_small_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const u32*, unsigned, unsigned);
 template __global__ void k_piece_level_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
                                                       unsigned, unsigned, unsigned, u32*);
+template __global__ void k_piece_tail_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
+                                                     unsigned, unsigned, unsigned, u32*);
 }

@@ -329,6 +329,44 @@ void k_piece_level_coop(xyzz_mem<FP::N>* __restrict__ buckets, u32* __restrict__
     if (work && c.role == 0) x.store(j.finish ? &buckets[j.B] : &rec_pt[j.dst]);
 }
 
+
+// Every level of the piece tree from t0 on in ONE launch: the levels of <= PIECE_FUSE_MAX work items are ~15 us each as
+// launches of their own (2^12 points: eight of them, 0.14 ms of a 0.36 ms MSM) although the cooperative addition of a level
+// is ~4 us -- the rest is the launch, the offsets' dependent loads and the round trip of the operands.  Here a work-group
+// owns 2^lgGB buckets with all their pairs (piece_tail_lgGB), so a level waits for nothing but the work-group's own stores
+// (the barrier's work-group-scope release / acquire: the records stay in global memory, same slots as the per-level form).
+// Same box, wall (profiles/r06_msm_piece_tail_ab.log): 2^10 0.426 -> 0.406 ms, 2^12 0.482 -> 0.463, 2^14 0.550 -> 0.541, 2^16 0.800 -> 0.788;
+// from 2^16 work items on the lane-per-addition launches are faster (2^14: 0.585 with the levels of 2^16 items in here).
+static constexpr size_t PIECE_FUSE_MAX = 32768;
+template<class FP>
+__global__ __launch_bounds__(COOP_NT, 2)         // (two work-groups per CU: 2^12 points are 512 work-groups)
+void k_piece_tail_coop(xyzz_mem<FP::N>* __restrict__ buckets, u32* rec_key, xyzz_mem<FP::N>* rec_pt,
+                       const u32* __restrict__ off, unsigned NB, unsigned L, unsigned chunks_per_win, unsigned nwins,
+                       unsigned cmax, unsigned t0, unsigned lgGB, u32* __restrict__ any_long)
+{
+    __shared__ coop_lds<FP> ex;
+    coop_ctx<FP> c{&ex, threadIdx.x >> 6, threadIdx.x & 63, 0};
+    const size_t nb = (size_t)nwins * NB, B0 = (size_t)blockIdx.x << lgGB;
+    #pragma unroll 1
+    for (unsigned t = t0; (cmax >> (t + 1)) >= 1; t++) {
+        const unsigned last = (cmax >> (t + 2)) == 0, njobs = (cmax >> (t + 1)) << lgGB;
+        #pragma unroll 1
+        for (unsigned base = 0; base < njobs; base += 64) {
+            const unsigned idx = base + c.lane;
+            const size_t B = B0 + (idx & ((1u << lgGB) - 1));
+            piece_job j; j.live = j.add = j.finish = false; j.dst = j.src = 0; j.B = 0;
+            if (idx < njobs && B < nb) j = piece_job_bm(rec_key, off, NB, L, chunks_per_win, cmax, t, last, any_long, B, idx >> lgGB);
+            const bool work = j.live && (j.add || j.finish), add = j.live && j.add;
+            xyzz_dev<FP> x, y;
+            if (work) x = xyzz_dev<FP>::load(&rec_pt[j.dst]); else x.set_inf();
+            if (add)  y = xyzz_dev<FP>::load(&rec_pt[j.src]); else y.set_inf();
+            if (coop_any(add)) coop_add<FP>(x, y, c);
+            if (work && c.role == 0) x.store(j.finish ? &buckets[j.B] : &rec_pt[j.dst]);
+        }
+        coop_barrier();
+    }
+}
+
 } // namespace sppark_amd
 
 namespace sppark_amd {

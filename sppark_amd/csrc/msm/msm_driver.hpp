@@ -672,9 +672,21 @@ private:
             u32* flag = flag_with_sums ? d_pflag : (u32*)(blob + l.flag);
             if (!flag_with_sums) HIP_OK(hipMemsetAsync(flag, 0, 4, stream));
             const u32* off = (const u32*)(blob + l.off[0]);
+            // the levels of few work items in one launch (k_piece_tail_coop; tune.join 8: every level a launch, 16 + x: from 2^x items)
+            unsigned t_fused = ~0u;
+            if constexpr (MONTX) if (tune.join != 4 && tune.join != 8)
+                t_fused = piece_tail_t0((size_t)p.nwins * p.NB, piece_cm, tune.join >= 16 ? (size_t)1 << (tune.join - 16) : PIECE_FUSE_MAX);
             for (unsigned t = 0; (piece_cm >> (t + 1)) >= 1; t++) {
                 const unsigned last = (piece_cm >> (t + 2)) == 0;
                 const size_t nthr = (size_t)p.nwins * p.NB * (piece_cm >> (t + 1));
+                if constexpr (MONTX) if (t == t_fused) {
+                    const unsigned lgGB = piece_tail_lgGB(piece_cm, t);
+                    const size_t nwg = (((size_t)p.nwins * p.NB) + ((size_t)1 << lgGB) - 1) >> lgGB;
+                    hipLaunchKernelGGL(k_piece_tail_coop<fp_d>, dim3((unsigned)nwg), dim3(COOP_NT), 0, stream,
+                                       buckets, keyA, ptA, off, p.NB, p.L, p.chunks_per_win, p.nwins, piece_cm, t, lgGB, flag);
+                    HIP_OK(hipGetLastError());
+                    break;
+                }
                 bool coop = false;
                 if constexpr (MONTX) coop = nthr <= COOP_LEVEL_MAX && tune.join != 4;
                 if constexpr (MONTX) {

@@ -54,16 +54,12 @@ SPPARK_DEVFN size_t piece_slot(const piece_geom& g, unsigned k) { return k == 0 
 
 // work item (bucket B = w NB + b, pair m) of level t; pairs per bucket at this level: cmax >> (t + 1)
 struct piece_job { bool live, add, finish; size_t dst, src; u32 B; };
-SPPARK_DEVFN piece_job piece_job_of(u32* rec_key, const u32* off, unsigned NB, unsigned L, unsigned chunks_per_win, unsigned nwins,
-                                    unsigned cmax, unsigned t, unsigned last, u32* any_long, size_t id)
+// pair m of bucket B (< nwins NB) at level t
+SPPARK_DEVFN piece_job piece_job_bm(u32* rec_key, const u32* off, unsigned NB, unsigned L, unsigned chunks_per_win,
+                                    unsigned cmax, unsigned t, unsigned last, u32* any_long, size_t B, unsigned m)
 {
     piece_job j; j.live = j.add = j.finish = false; j.dst = j.src = 0; j.B = 0;
-    // pair-major: lane l of a wave is bucket B0 + l of ONE pair index m, so the waves of the pair indices beyond the
-    // average bucket's pieces (cmax has 3 x head-room) hold no work at all and leave at once, and those that stay are full
-    // (bucket-major, a wave was 64 pair indices of one bucket: a quarter of its lanes busy, four times the waves)
     const unsigned pm = cmax >> (t + 1);
-    const size_t nb = (size_t)nwins * NB;
-    const size_t B = id % nb; const unsigned m = (unsigned)(id / nb);
     if (m >= pm) return j;
     const piece_geom g = piece_geometry(off, NB, L, chunks_per_win, (unsigned)(B / NB), (unsigned)(B % NB));
     if (g.cnt == 0) return j;
@@ -80,17 +76,51 @@ SPPARK_DEVFN piece_job piece_job_of(u32* rec_key, const u32* off, unsigned NB, u
     j.finish = last && m == 0;
     return j;
 }
+SPPARK_DEVFN piece_job piece_job_of(u32* rec_key, const u32* off, unsigned NB, unsigned L, unsigned chunks_per_win, unsigned nwins,
+                                    unsigned cmax, unsigned t, unsigned last, u32* any_long, size_t id)
+{
+    // pair-major: lane l of a wave is bucket B0 + l of ONE pair index m, so the waves of the pair indices beyond the
+    // average bucket's pieces (cmax has 3 x head-room) hold no work at all and leave at once, and those that stay are full
+    // (bucket-major, a wave was 64 pair indices of one bucket: a quarter of its lanes busy, four times the waves)
+    const size_t nb = (size_t)nwins * NB;
+    return piece_job_bm(rec_key, off, NB, L, chunks_per_win, cmax, t, last, any_long, id % nb, (unsigned)(id / nb));
+}
+
+// The narrow end of the tree in ONE launch (k_piece_tail_coop): every level from t0 on, a work-group owning 2^lgGB buckets
+// with ALL their pairs, so that a level only waits for the work-group's own stores.  Work item |idx| of work-group |wg| at
+// level t: bucket (wg << lgGB) + idx % 2^lgGB, pair idx >> lgGB.  lgGB fills the 64 lanes of a cooperative addition at
+// level t0: 2^lgGB (cmax >> (t0 + 1)) >= 64 where the buckets allow.
+static inline unsigned piece_tail_lgGB(unsigned cmax, unsigned t0)
+{
+    const unsigned pm = cmax >> (t0 + 1);
+    unsigned lg = 0;
+    while ((pm << lg) < 64) lg++;
+    return lg;
+}
+// first level of the one-launch end: the first whose work items (buckets x pair slots) are at most |fuse_max|; the levels
+// before it are launches of their own (lane-per-addition kernels: throughput, not latency)
+static inline unsigned piece_tail_t0(size_t nbuckets, unsigned cmax, size_t fuse_max)
+{
+    unsigned t = 0;
+    while ((cmax >> (t + 1)) >= 1 && nbuckets * (cmax >> (t + 1)) > fuse_max) t++;
+    return t;
+}
+
+template<class FP>
+SPPARK_DEVFN void piece_apply(xyzz_mem<FP::N>* buckets, xyzz_mem<FP::N>* rec_pt, const piece_job& j)
+{
+    if (!j.live || !(j.add || j.finish)) return;
+    xyzz_dev<FP> acc = xyzz_dev<FP>::load(&rec_pt[j.dst]);
+    if (j.add) bucket_add_fast<FP>(acc, xyzz_dev<FP>::load(&rec_pt[j.src]));
+    acc.store(j.finish ? &buckets[j.B] : &rec_pt[j.dst]);
+}
 
 template<class FP>
 SPPARK_DEVFN void piece_level_item(xyzz_mem<FP::N>* buckets, u32* rec_key, xyzz_mem<FP::N>* rec_pt, const u32* off,
                                    unsigned NB, unsigned L, unsigned chunks_per_win, unsigned nwins,
                                    unsigned cmax, unsigned t, unsigned last, u32* any_long, size_t id)
 {
-    const piece_job j = piece_job_of(rec_key, off, NB, L, chunks_per_win, nwins, cmax, t, last, any_long, id);
-    if (!j.live || !(j.add || j.finish)) return;
-    xyzz_dev<FP> acc = xyzz_dev<FP>::load(&rec_pt[j.dst]);
-    if (j.add) bucket_add_fast<FP>(acc, xyzz_dev<FP>::load(&rec_pt[j.src]));
-    acc.store(j.finish ? &buckets[j.B] : &rec_pt[j.dst]);
+    piece_apply<FP>(buckets, rec_pt, piece_job_of(rec_key, off, NB, L, chunks_per_win, nwins, cmax, t, last, any_long, id));
 }
 
 template<class FP>

@@ -198,6 +198,8 @@ static unsigned g_pack = 0;
 extern "C" void emu_msm_pack(unsigned mode) { g_pack = mode; }       // 0: 8-byte level-A records
 static unsigned g_piece_cmax = 0;                                   // join == 2: pieces per bucket the piece tree takes (0: from the average bucket)
 extern "C" void emu_msm_piece_cmax(unsigned c) { g_piece_cmax = c; }
+static size_t g_piece_fuse = 0;                                     // join == 2: work items from which the rest of the piece tree runs work-group-major (0: never)
+extern "C" void emu_msm_piece_fuse(size_t f) { g_piece_fuse = f; }
 static unsigned emu_top_pieces = 1;                                 // the subset-sum top by pieces of a sum: 1 = the product's cut, 0 = per sum, "sb sp" forced
 extern "C" void emu_msm_top_pieces(unsigned on) { emu_top_pieces = on; }
 
@@ -369,9 +371,27 @@ extern "C" int emu_msm(void* out_jac, const unsigned char* points, size_t stride
             // (bucket, pair) work items; the records of buckets with more pieces keep their keys and go through the fan-in tree
             const unsigned cmax = g_piece_cmax ? g_piece_cmax : piece_cmax((size_t)p.n / p.NB / p.L + 1);
             any_long = 0;
+            // g_piece_fuse: the levels of at most that many work items in the order of k_piece_tail_coop -- work-group by
+            // work-group (2^lgGB buckets with all their pairs), every level of a work-group before the next work-group starts
+            const size_t nbk = (size_t)p.nwins * p.NB;
+            const unsigned t_fused = g_piece_fuse ? piece_tail_t0(nbk, cmax, g_piece_fuse) : ~0u;
             for (unsigned t = 0; (cmax >> (t + 1)) >= 1; t++) {
                 const unsigned last = (cmax >> (t + 2)) == 0;
                 const size_t nthr = (size_t)p.nwins * p.NB * (cmax >> (t + 1));
+                if (t == t_fused) {
+                    const unsigned lgGB = piece_tail_lgGB(cmax, t);
+                    for (size_t wg = 0; wg < ((nbk + ((size_t)1 << lgGB) - 1) >> lgGB); wg++)
+                        for (unsigned tt = t; (cmax >> (tt + 1)) >= 1; tt++) {
+                            const unsigned lst = (cmax >> (tt + 2)) == 0, njobs = (cmax >> (tt + 1)) << lgGB;
+                            for (unsigned idx = 0; idx < ((njobs + 63) / 64) * 64; idx++) {
+                                const size_t B = (wg << lgGB) + (idx & ((1u << lgGB) - 1));
+                                if (idx < njobs && B < nbk)
+                                    piece_apply<inst_fp>(buckets.data(), ptA.data(), piece_job_bm(keyA.data(), off.data(), p.NB, p.L, p.chunks_per_win,
+                                                                                                cmax, tt, lst, &any_long, B, idx >> lgGB));
+                            }
+                        }
+                    break;
+                }
                 for (size_t id = 0; id < ((nthr + 255) / 256) * 256; id++)
                     piece_level_item<inst_fp>(buckets.data(), keyA.data(), ptA.data(), off.data(), p.NB, p.L, p.chunks_per_win, p.nwins,
                                               cmax, t, last, &any_long, id);

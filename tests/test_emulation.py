@@ -297,6 +297,7 @@ def test_msm_piece_tree_on_host(oracle):
     O = oracle
     L = _emu("BLS12_381")
     L.emu_msm_piece_cmax.argtypes = [ctypes.c_uint]; L.emu_msm_piece_cmax.restype = None
+    L.emu_msm_piece_fuse.argtypes = [ctypes.c_size_t]; L.emu_msm_piece_fuse.restype = None
     n = 2000
     pts, sc = recipe.msm_inputs(0, n, 4321, edge=True)
     s_eq = sc.copy(); s_eq[:] = sc[0]
@@ -308,17 +309,22 @@ def test_msm_piece_tree_on_host(oracle):
             exp = O.msm_affine(0, pts, s, algo=0, param=4)
             for wb, LL in ((4, 8), (5, 7), (6, 16), (3, 5), (8, 4), (7, 1)):
                 for cmax in ((0, 2, 8, 4096) if what in ("uniform", "equal") else (0, 8)):
-                    L.emu_msm_piece_cmax(cmax)
-                    out = np.zeros(144, dtype=np.uint8)
-                    stats = np.zeros(2, dtype=np.uint32)
-                    L.emu_msm(P(out), P(pts), 96, n, P(s), 0, wb, LL, 4, 4, 2, 2, P(stats), 0)
-                    assert (O.jac_to_affine(0, out) == exp).all(), (what, wb, LL, cmax)
-                    if what == "uniform" and cmax in (0, 4096):
-                        assert stats[0] == 0 and stats[1] == 0, (wb, LL, cmax, stats)      # nothing left for the fan-in tree
-                    if what == "equal" and cmax == 2 and LL <= 16:
-                        assert stats[0] == 1 and stats[1] > 0
+                    # fuse: the narrow end of the tree in k_piece_tail_coop's order (a work-group's buckets through every
+                    # level before the next work-group): every level, from a middle level, never
+                    for fuse in ((0, 1 << 30, 4096) if cmax in (0, 8) else (0, 1 << 30)):
+                        L.emu_msm_piece_cmax(cmax)
+                        L.emu_msm_piece_fuse(fuse)
+                        out = np.zeros(144, dtype=np.uint8)
+                        stats = np.zeros(2, dtype=np.uint32)
+                        L.emu_msm(P(out), P(pts), 96, n, P(s), 0, wb, LL, 4, 4, 2, 2, P(stats), 0)
+                        assert (O.jac_to_affine(0, out) == exp).all(), (what, wb, LL, cmax, fuse)
+                        if what == "uniform" and cmax in (0, 4096):
+                            assert stats[0] == 0 and stats[1] == 0, (wb, LL, cmax, stats)      # nothing left for the fan-in tree
+                        if what == "equal" and cmax == 2 and LL <= 16:
+                            assert stats[0] == 1 and stats[1] > 0
     finally:
         L.emu_msm_piece_cmax(0)
+        L.emu_msm_piece_fuse(0)
 
 
 @pytest.mark.parametrize("curve,feature", [(0, "BLS12_381"), (1, "BN254")])

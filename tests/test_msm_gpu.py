@@ -340,7 +340,9 @@ def test_msm_piece_tree_of_small_sizes(oracle, libs, curve, name):
     bucket sums again, only when the device reports a bucket beyond that size.  Uniform scalars at the automatic plan and at
     forced ones (aligned / unaligned bucket starts, odd piece counts, ragged sizes): against the oracle and WITHOUT a second
     pass; all scalars equal, a mix, 16-bit scalars, every second scalar zero: against the oracle, the heavy buckets through the
-    second pass; the same calls with the piece tree switched off (tune_tail 5) and without the cooperative kernels (4)."""
+    second pass; the same calls with the piece tree switched off (tune_tail 5), without the cooperative kernels (4), with a
+    launch per level instead of the one-launch narrow end k_piece_tail_coop (8), and with that launch taking every level /
+    only the last ones (16 + 30, 16 + 10: work-groups of 1 ... 64 buckets)."""
     import sppark_amd
     O = oracle
     ctx = sppark_amd.MsmContext(name)
@@ -356,7 +358,7 @@ def test_msm_piece_tree_of_small_sizes(oracle, libs, curve, name):
                 continue
             exp = O.msm_affine(curve, pts, s_, algo=0, param=8)
             for plan in plans:
-                for join in (0, 5, 4):
+                for join in (0, 5, 4, 8, 46, 26):
                     ctx.tune(**plan); ctx.tune_tail(join, 0)
                     before = ctx.tail_redone()
                     out = ctx.invoke(pts, s_, ffi_affine_sz=pts.shape[1])

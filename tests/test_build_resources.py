@@ -177,11 +177,15 @@ def test_host_field_adc_chains_match_plain_cios(tmp_path):
     if not os.path.exists(clang):
         pytest.skip("clang++ of the ROCm toolchain not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "host_field_bench")
-    subprocess.check_call([clang, "-O2", "-std=c++17", "-I", os.path.join(root, "sppark_amd", "csrc"),
-                           os.path.join(root, "tools", "host_field_bench.cpp"), "-o", exe])
-    out = subprocess.run([exe, "20000"], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("mismatches 0;") == 3, out.stdout
+    # the product as built (mulx / adcx / adox where the host has them: ff/mont_host_x86.hpp) and the adc-chain C product alone
+    for extra in ([], ["-DSPPARK_HOST_NO_MULX"]):
+        exe = str(tmp_path / ("host_field_bench" + str(len(extra))))
+        subprocess.check_call([clang, "-O2", "-std=c++17", "-I", os.path.join(root, "sppark_amd", "csrc")] + extra +
+                              [os.path.join(root, "tools", "host_field_bench.cpp"), "-o", exe])
+        out = subprocess.run([exe, "20000"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count("mismatches 0;") == 3, out.stdout
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_mont_host_x86.py")], capture_output=True, text=True)
+    assert gen.stdout == open(os.path.join(root, "sppark_amd", "csrc", "ff", "mont_host_x86.hpp")).read()      # the header is the generator's output
     src = open(os.path.join(root, "sppark_amd", "csrc", "ff", "mont_host.hpp")).read()
     assert "SPPARK_HOST_ADC" in src

@@ -51,7 +51,40 @@ template<class P> int run(const char* name, int iters){
   printf("%s: mismatches %d; mul %.1f ns, sqr %.1f ns, 255 doublings %.1f us (%llx)\n", name, bad, m, q, std::chrono::duration<double,std::micro>(t1-t0).count()/100, (unsigned long long)(a.v[0]^pt.X.v[0]));
   return bad;
 }
+#if defined(SPPARK_HOST_MULX) && defined(SPPARK_HOST_ADC)
+// the two products of the fast path side by side (alternating, best of ten): adc chains in C against mulx / adcx / adox
+typedef mont_host<bls12_381_fp_p> F6;
+__attribute__((noinline)) static F6 mul_c(const F6& a, const F6& b)
+{
+    unsigned long long t[8] = {0};
+    for (int i = 0; i < 6; i++) { F6::mac_row(t, a.v, b.v[i]); F6::red_row(t); }
+    uint64_t u[7]; for (int i = 0; i <= 6; i++) u[i] = t[i];
+    F6 r; F6::cond_sub(r.v, u, u[6]); return r;
+}
+__attribute__((noinline)) static F6 mul_asm(const F6& a, const F6& b)
+{
+    uint64_t u[6]; mont_mul_x86_6(u, a.v, b.v, bls12_381_fp_p::MOD64, bls12_381_fp_p::M0_64);
+    F6 r; F6::cond_sub(r.v, u, 0); return r;
+}
+static void ab()
+{
+    F6 a = F6::one(); a = a + a + a; F6 b = a * a + a;
+    double best[2] = {1e9, 1e9};
+    for (int rep = 0; rep < 10; rep++) for (int k = 0; k < 2; k++) {
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 500000; i++) a = k ? mul_asm(a, b) : mul_c(a, b);
+        auto t1 = std::chrono::steady_clock::now();
+        double m = std::chrono::duration<double,std::nano>(t1 - t0).count() / 5e5;
+        if (m < best[k]) best[k] = m;
+    }
+    printf("6 limbs, side by side: adc chains in C %.1f ns, mulx / adcx / adox %.1f ns (mulx+adx on this host: %d) (%llx)\n", best[0], best[1],
+           (int)host_has_mulx_adx(), (unsigned long long)a.v[0]);
+}
+#else
+static void ab() {}
+#endif
 int main(int argc, char** argv){
+  if (argc > 2) ab();
   const int iters = argc > 1 ? atoi(argv[1]) : 200000;
   return run<bls12_381_fp_p>("bls12_381 fp", iters) + run<alt_bn128_fp_p>("alt_bn128 fp", iters) + run<bls12_377_fp_p>("bls12_377 fp", iters) != 0;
 }

@@ -77,7 +77,7 @@ def fuzz_msm(rng, it, ctxs, g2):
         ctx.tune(**t)
         ts = int(rng.choice([0, 0, 1, 4])); ctx.tune_sort(ts)
         top = int(rng.choice([0, 0, 1, 64, 4096])); ctx.tune_sums(top)
-        join = int(rng.choice([0, 0, 1, 5, 6])); k1 = int(rng.choice([0, 0, 2, 8])); ctx.tune_tail(join, k1)
+        join = int(rng.choice([0, 0, 0, 1, 5, 6, 8, 26, 29, 46])); k1 = int(rng.choice([0, 0, 2, 8])); ctx.tune_tail(join, k1)
         rec = int(rng.choice([0, 0, 1, 2])); ctx.tune_records(rec)
         what.update(t, sort=ts, top=top, join=join, k1=k1, records=rec)
         out = ctx.invoke(pts, sc, ffi_affine_sz=pts.shape[1])

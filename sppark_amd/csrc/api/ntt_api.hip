@@ -28,6 +28,7 @@ namespace sppark_amd {
     extern template __global__ void K<ntt_fr_t, DIF, INV>(ntt_fr_t*, ntt_r64_args<ntt_fr_t>);
 SPPARK_R64_EXTERN(k_ntt6, true, false) SPPARK_R64_EXTERN(k_ntt6, true, true) SPPARK_R64_EXTERN(k_ntt6, false, false) SPPARK_R64_EXTERN(k_ntt6, false, true)
 SPPARK_R64_EXTERN(k_ntt12, true, false) SPPARK_R64_EXTERN(k_ntt12, true, true) SPPARK_R64_EXTERN(k_ntt12, false, false) SPPARK_R64_EXTERN(k_ntt12, false, true)
+extern template __global__ void k_ntt12<ntt_fr_t, false, false, true>(ntt_fr_t*, ntt_r64_args<ntt_fr_t>);
 }
 #endif
 #include "../ntt/ntt_driver.hpp"

@@ -10,4 +10,8 @@ namespace sppark_amd {
     template __global__ void K<ntt_fr_t, (SPPARK_NTT_DIF != 0), INV>(ntt_fr_t*, ntt_r64_args<ntt_fr_t>);
 SPPARK_R64_DEFINE(k_ntt6, false) SPPARK_R64_DEFINE(k_ntt6, true)
 SPPARK_R64_DEFINE(k_ntt12, false) SPPARK_R64_DEFINE(k_ntt12, true)
+#if SPPARK_NTT_DIF == 0
+// the first step of sppark_lde's forward RN transform reading the compact coefficients (ntt_r64_args::lde_src)
+template __global__ void k_ntt12<ntt_fr_t, false, false, true>(ntt_fr_t*, ntt_r64_args<ntt_fr_t>);
+#endif
 }

@@ -242,9 +242,19 @@ public:
     size_t cached_table_count() { std::lock_guard<std::mutex> lk(mtx); return tw_cache.size() + cache.size(); }
 
     // in-place transform of a DEVICE buffer of 2^lg elements on |stream|
-    void run(const gpu_info& gpu, F* d, unsigned lg, int order, int direction, int type, hipStream_t stream)
+    // |lde| (sppark_lde's forward RN transform only): the input is still the COMPACT coefficients lde->src (2^lg_domain, bit-reversed
+    // order, unshifted); the first step of the radix-64 plan reads them as the spread array (k_ntt12<.., LDE>), and where the
+    // transform runs another plan the spread is launched here first.
+    // |lde->out| instead (sppark_lde's inverse NR transform): the result goes to |out|, |d| is scratch afterwards -- the last step
+    // of the radix-64 plan stores there (ntt_r64_args::out), any other plan runs in place and copies.
+    struct lde_input { const F* src; unsigned lg_domain, lg_blowup; F* out; };
+    void run(const gpu_info& gpu, F* d, unsigned lg, int order, int direction, int type, hipStream_t stream, const lde_input* lde = nullptr)
     {
-        if (lg == 0) return;                                        // ntt/ntt.cuh:220-221
+        if (lg == 0) {                                              // ntt/ntt.cuh:220-221 (one element: the hand-over of sppark_lde still happens)
+            if (lde && lde->out) HIP_OK(hipMemcpyAsync(lde->out, d, sizeof(F), hipMemcpyDeviceToDevice, stream));
+            else if (lde) lde_spread(gpu, d, lde->src, lde->lg_domain, lde->lg_blowup, true, stream);
+            return;
+        }
         if (lg > F::TWO_ADICITY || order < 0 || order > 3) HIP_OK(hipErrorInvalidValue);
         const int inverse = direction == NTT_INVERSE;
         const table_set ts = tables(gpu.hip_id, lg, inverse, stream);
@@ -254,6 +264,9 @@ public:
 
         // up to 2^11 elements (256-bit fields: 2^9): the whole transform -- permutations, coset powers and 1/n included -- by one work-group
         // in one launch (k_ntt_small, ntt_kernels.hpp)
+        F* final_out = lde ? lde->out : nullptr;
+        if (final_out) lde = nullptr;
+        if (lde && lg <= small_max_lg()) { lde_spread(gpu, d, lde->src, lde->lg_domain, lde->lg_blowup, true, stream); lde = nullptr; }
         if (lg <= small_max_lg()) {
             const unsigned flags = ntt_small_flags(order, inverse != 0, type == NTT_COSET);
             const unsigned lanes = (unsigned)std::max<size_t>(64, n / 2);
@@ -274,6 +287,7 @@ public:
                 SPPARK_NTT_SMALL_PICK(0);
 #undef SPPARK_NTT_SMALL_PICK
             HIP_OK(hipGetLastError());
+            if (final_out) HIP_OK(hipMemcpyAsync(final_out, d, n * sizeof(F), hipMemcpyDeviceToDevice, stream));
             return;
         }
 
@@ -349,6 +363,15 @@ public:
             }
             if (!ok) { rp.nsteps = 0; cmode = 0; top_crow = nullptr; }
         }
+        // sppark_lde: the spread + coset shift inside the first step where that is k_ntt12 on a forward RN transform with at
+        // most 8 positions per coefficient; otherwise as a launch of its own, now
+        bool lde_fused = false;
+        if (lde) {
+            if constexpr (R64)
+                lde_fused = rp.nsteps && !gs && !inverse && order == NTT_RN && type == NTT_STANDARD && rp.step[rp.nsteps - 1].kind == 2
+                         && lde->lg_blowup >= 1 && lde->lg_blowup <= 3 && lde->lg_domain + lde->lg_blowup == lg;
+            if (!lde_fused) lde_spread(gpu, d, lde->src, lde->lg_domain, lde->lg_blowup, true, stream);
+        }
         if (!inverse && type == NTT_COSET && !cmode)
             hipLaunchKernelGGL(k_coset<F>, dim3(egrid), dim3(256), 0, stream, d, G, (int)bitrev);
         const bool lat = !R64 && knobs.lat_smax != 0;
@@ -384,7 +407,13 @@ public:
                             else    { if (inverse) hipLaunchKernelGGL((K<F, false, true>), dim3(tiles), dim3(512), lds, stream, d, A);   \
                                       else         hipLaunchKernelGGL((K<F, false, false>), dim3(tiles), dim3(512), lds, stream, d, A); } \
                         } while (0)
-                        if (st.kind == 1) SPPARK_R64_LAUNCH(k_ntt6); else SPPARK_R64_LAUNCH(k_ntt12);
+                        if (final_out && last && st.kind == 2 && gs) { A.out = final_out; final_out = nullptr; }
+                        if (lde_fused && i == 0) {
+                            const table_set tg = tables(gpu.hip_id, lde->lg_domain, 0, stream);
+                            A.lde_src = lde->src; A.lde_glo = tg.glo; A.lde_ghi = tg.ghi; A.lde_gh = tg.h;
+                            A.lde_lgd = lde->lg_domain; A.lde_lgb = lde->lg_blowup;
+                            hipLaunchKernelGGL((k_ntt12<F, false, false, true>), dim3(tiles), dim3(512), lds, stream, d, A);
+                        } else if (st.kind == 1) SPPARK_R64_LAUNCH(k_ntt6); else SPPARK_R64_LAUNCH(k_ntt12);
 #undef SPPARK_R64_LAUNCH
                         continue;
                     }
@@ -443,6 +472,7 @@ public:
         if (order == NTT_RR)
             bit_reverse(d, lg, stream);
         HIP_OK(hipGetLastError());
+        if (final_out) HIP_OK(hipMemcpyAsync(final_out, d, n * sizeof(F), hipMemcpyDeviceToDevice, stream));      // (no step stored there)
     }
 
     // in-place bit-reversal permutation (NN and RR orders; ntt/ntt.cuh:44-79)
@@ -511,14 +541,18 @@ public:
     {
         if (lg_domain + lg_blowup > F::TWO_ADICITY) HIP_OK(hipErrorInvalidValue);
         const size_t dom = (size_t)1 << lg_domain;
-        HIP_OK(hipMemcpyAsync(d_tmp, d_ext, dom * sizeof(F), hipMemcpyDeviceToDevice, stream));
-        run(gpu, d_tmp, lg_domain, NTT_NR, NTT_INVERSE, NTT_STANDARD, stream);
+        // (the inverse transform runs in the first 2^lg_domain elements of d_ext -- overwritten below anyway -- and leaves the
+        //  coefficients in d_tmp: its last step stores there, no copy in front of it)
+        const lde_input lo{nullptr, 0, 0, d_tmp};
+        run(gpu, d_ext, lg_domain, NTT_NR, NTT_INVERSE, NTT_STANDARD, stream, &lo);
         if (d_aux) {
             hipLaunchKernelGGL(k_bitrev_copy<F>, dim3((unsigned)((dom + 255) / 256)), dim3(256), 0, stream, d_aux, d_tmp, lg_domain);
             HIP_OK(hipGetLastError());
         }
-        lde_spread(gpu, d_ext, d_tmp, lg_domain, lg_blowup, true, stream);
-        run(gpu, d_ext, lg_domain + lg_blowup, NTT_RN, NTT_FORWARD, NTT_STANDARD, stream);
+        // (the spread + coset shift of LDE_launch ride in the forward transform's first step where the plan allows: 134 MB
+        //  never written and a launch less at 2^22 -> 2^24)
+        const lde_input li{d_tmp, lg_domain, lg_blowup, nullptr};
+        run(gpu, d_ext, lg_domain + lg_blowup, NTT_RN, NTT_FORWARD, NTT_STANDARD, stream, &li);
     }
 };
 

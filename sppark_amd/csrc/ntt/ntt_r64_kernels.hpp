@@ -49,6 +49,14 @@ template<class F> struct ntt_r64_args {
     // k_ntt6 (the step on the whole transform): cz[row], applied to the rows when they are loaded (DIF) / stored (DIT);
     // k_ntt12: cz[lo] = g^(rev6(lo) << (lg_n - 6)), lo = position & 63, applied when the block is stored (DIF) / loaded (DIT).
     const F* cz;
+    // k_ntt12, first step of a forward RN transform inside sppark_lde (LDE template flag): the block is read from the COMPACT
+    // 2^lde_lgd coefficients (bit-reversed order) instead of the spread array -- position p holds lde_src[p >> lde_lgb] times
+    // g^(rev(p >> lde_lgb)) when its low lde_lgb <= 3 bits are zero, and zero otherwise (k_lde_spread's output, never written)
+    F* out = nullptr;   // k_ntt12 as the LAST step (DIF): the blocks are stored here instead of in place (sppark_lde's inverse transform leaves
+                        // the coefficients in its scratch buffer without a copy before it)
+    const F* lde_src = nullptr;
+    const F* lde_glo = nullptr; const F* lde_ghi = nullptr;     // the powers of g: ntt_tables lo / hi / h of the domain's size
+    unsigned lde_gh = 0, lde_lgd = 0, lde_lgb = 0;
 };
 
 SPPARK_DEVFN unsigned wave_uniform(unsigned v)
@@ -204,15 +212,28 @@ template<class F> struct alignas(16) ntt_vec16 { F v[16 / sizeof(F)]; };
 
 // One round.  DIF runs A1, B1, A2, B2 (HBM -> ... -> HBM); DIT runs them in the opposite order with
 // the diagonal applied BEFORE the butterflies.
-template<class F, bool DIF, bool INV, int D>
-SPPARK_DEVFN void ntt12_round(F* sub, F* tile, const ntt_r64_args<F>& A, unsigned lane)
+template<class F, bool DIF, bool INV, int D, bool LDE = false>
+SPPARK_DEVFN void ntt12_round(F* sub, F* tile, const ntt_r64_args<F>& A, unsigned lane, size_t blk = 0, F* osub = nullptr)
 {
+    if (osub == nullptr) osub = sub;                                // where a round that stores to memory puts the block
     constexpr bool from_hbm = DIF ? D == R12_A1 : D == R12_B2;
     constexpr bool to_hbm   = DIF ? D == R12_B2 : D == R12_A1;
     constexpr unsigned PER = 16 / sizeof(F);                        // elements per 16-byte access
     const unsigned u = wave_uniform(lane >> 6);
     F x[8];
-    if (D == R12_B2 && from_hbm) {                                  // 8 consecutive elements: 16-byte loads
+    if (LDE && D == R12_B2 && from_hbm) {                           // the spread array as it would have been (8 consecutive positions)
+        const size_t p0 = (blk << 12) + ntt12_pos<D>(lane, 0);
+        const unsigned B = 1u << A.lde_lgb;
+        #pragma unroll
+        for (unsigned r = 0; r < 8; r++) {
+            x[r] = F();
+            if ((r & (B - 1)) == 0) {
+                const size_t idx = (p0 + r) >> A.lde_lgb;
+                const size_t e = bit_rev32((unsigned)idx, A.lde_lgd);
+                x[r] = A.lde_src[idx] * (A.lde_glo[e & (((size_t)1 << A.lde_gh) - 1)] * A.lde_ghi[e >> A.lde_gh]);
+            }
+        }
+    } else if (D == R12_B2 && from_hbm) {                           // 8 consecutive elements: 16-byte loads
         const ntt_vec16<F>* src = reinterpret_cast<const ntt_vec16<F>*>(sub + ntt12_pos<D>(lane, 0));
         #pragma unroll
         for (unsigned k = 0; k < 8 / PER; k++) {
@@ -253,7 +274,7 @@ SPPARK_DEVFN void ntt12_round(F* sub, F* tile, const ntt_r64_args<F>& A, unsigne
         for (unsigned r = 0; r < 8; r++) x[r] = x[r] * cz[r];
     }
     if (D == R12_B2 && to_hbm) {
-        ntt_vec16<F>* dst = reinterpret_cast<ntt_vec16<F>*>(sub + ntt12_pos<D>(lane, 0));
+        ntt_vec16<F>* dst = reinterpret_cast<ntt_vec16<F>*>(osub + ntt12_pos<D>(lane, 0));
         #pragma unroll
         for (unsigned k = 0; k < 8 / PER; k++) {
             ntt_vec16<F> q;
@@ -265,12 +286,12 @@ SPPARK_DEVFN void ntt12_round(F* sub, F* tile, const ntt_r64_args<F>& A, unsigne
         #pragma unroll
         for (unsigned r = 0; r < 8; r++) {
             const unsigned p = ntt12_pos<D>(lane, r);
-            if (to_hbm) sub[p] = x[r]; else tile[ntt12_phys(p)] = x[r];
+            if (to_hbm) osub[p] = x[r]; else tile[ntt12_phys(p)] = x[r];
         }
     }
 }
 
-template<class F, bool DIF, bool INV>
+template<class F, bool DIF, bool INV, bool LDE = false>
 __global__ __launch_bounds__(512)
 void k_ntt12(F* data, ntt_r64_args<F> A)
 {
@@ -278,11 +299,16 @@ void k_ntt12(F* data, ntt_r64_args<F> A)
     F* tile = reinterpret_cast<F*>(ntt_lds);
     F* sub = data + ((size_t)blockIdx.x << 12);
     const unsigned lane = threadIdx.x;
-    if (DIF) {
+    if (LDE) {                                                      // (forward DIT only: the driver's sppark_lde path)
+        ntt12_round<F, false, INV, R12_B2, true>(sub, tile, A, lane, blockIdx.x); __syncthreads();
+        ntt12_round<F, false, INV, R12_A2>(sub, tile, A, lane); __syncthreads();
+        ntt12_round<F, false, INV, R12_B1>(sub, tile, A, lane); __syncthreads();
+        ntt12_round<F, false, INV, R12_A1>(sub, tile, A, lane);
+    } else if (DIF) {
         ntt12_round<F, true, INV, R12_A1>(sub, tile, A, lane); __syncthreads();
         ntt12_round<F, true, INV, R12_B1>(sub, tile, A, lane); __syncthreads();
         ntt12_round<F, true, INV, R12_A2>(sub, tile, A, lane); __syncthreads();
-        ntt12_round<F, true, INV, R12_B2>(sub, tile, A, lane);
+        ntt12_round<F, true, INV, R12_B2>(sub, tile, A, lane, 0, A.out ? A.out + ((size_t)blockIdx.x << 12) : nullptr);
     } else {
         ntt12_round<F, false, INV, R12_B2>(sub, tile, A, lane); __syncthreads();
         ntt12_round<F, false, INV, R12_A2>(sub, tile, A, lane); __syncthreads();

@@ -67,6 +67,12 @@ static void emu_bitrev(F* d, unsigned lg)
     }
 }
 
+// ntt_engine::run()'s |lde| argument: the compact coefficients the first k_ntt12 step of sppark_lde's forward transform reads
+// (ntt_r64_args::lde_*), set by emu_lde around its emu_ntt call
+struct emu_lde_in { const void* src; const void* glo; const void* ghi; unsigned gh, lgd, lgb; };
+static const emu_lde_in* g_lde_in = nullptr;
+static void* g_final_out = nullptr;     // ntt_r64_args::out of the last k_ntt12 step (DIF), consumed (set to null) by the step that stores there
+
 // the radix-64 plan of ntt_engine::run (single-word fields, lg >= 12): k_ntt6 / k_ntt12 round by round,
 // generic passes for the other steps; tables from r64_table_item, as ntt_engine::r64_table builds them
 template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int inverse, ntt_tables<FF>& T, unsigned nt, unsigned direct_max,
@@ -128,6 +134,18 @@ template<class FF> static void emu_r64_passes(FF* d, unsigned lg, bool gs, int i
                 } else {
                     FF* sub = d + (tile_id << 12);
 #define EMU_R12(DIF, INV, D) EMU_ALL((ntt12_round<FF, DIF, INV, D>(sub, tile.data(), A, tid)))
+                    if (g_final_out && last && gs && inverse) {     // as k_ntt12<F, true, true> with ntt_r64_args::out
+                        FF* osub = (FF*)g_final_out + (tile_id << 12);
+                        EMU_R12(true, true, R12_A1) EMU_R12(true, true, R12_B1) EMU_R12(true, true, R12_A2)
+                        EMU_ALL((ntt12_round<FF, true, true, R12_B2>(sub, tile.data(), A, tid, 0, osub)))
+                        if (tile_id + 1 == (n >> 12)) g_final_out = nullptr;
+                    } else
+                    if (g_lde_in && i == 0 && !gs && !inverse) {    // as k_ntt12<F, false, false, true>
+                        A.lde_src = (const FF*)g_lde_in->src; A.lde_glo = (const FF*)g_lde_in->glo; A.lde_ghi = (const FF*)g_lde_in->ghi;
+                        A.lde_gh = g_lde_in->gh; A.lde_lgd = g_lde_in->lgd; A.lde_lgb = g_lde_in->lgb;
+                        EMU_ALL((ntt12_round<FF, false, false, R12_B2, true>(sub, tile.data(), A, tid, tile_id)))
+                        EMU_R12(false, false, R12_A2) EMU_R12(false, false, R12_B1) EMU_R12(false, false, R12_A1)
+                    } else
                     if (gs) { if (inverse) { EMU_R12(true, true, R12_A1) EMU_R12(true, true, R12_B1) EMU_R12(true, true, R12_A2) EMU_R12(true, true, R12_B2) }
                               else         { EMU_R12(true, false, R12_A1) EMU_R12(true, false, R12_B1) EMU_R12(true, false, R12_A2) EMU_R12(true, false, R12_B2) } }
                     else    { if (inverse) { EMU_R12(false, true, R12_B2) EMU_R12(false, true, R12_A2) EMU_R12(false, true, R12_B1) EMU_R12(false, true, R12_A1) }
@@ -325,8 +343,11 @@ extern "C" int emu_lde(void* inout, unsigned lg_domain, unsigned lg_blowup, void
 {
     F* ext = (F*)inout;
     const size_t dom = (size_t)1 << lg_domain, n_ext = dom << lg_blowup;
-    std::vector<F> tmp(ext, ext + dom);
-    emu_ntt(tmp.data(), lg_domain, 1, 1, 0, 64);
+    // as ntt_engine::lde(): the inverse transform in place in ext[0 .. dom), its last step (where that is k_ntt12) storing to tmp
+    std::vector<F> tmp(dom);
+    g_final_out = tmp.data();
+    emu_ntt(ext, lg_domain, 1, 1, 0, 64);
+    if (g_final_out) { memcpy((void*)tmp.data(), (const void*)ext, dom * sizeof(F)); g_final_out = nullptr; }
     if (aux) {
         for (size_t i = 0; i < dom; i++) {
             size_t r = 0;
@@ -339,7 +360,19 @@ extern "C" int emu_lde(void* inout, unsigned lg_domain, unsigned lg_blowup, void
     for (size_t k = 0; k < std::max(glo.size(), ghi.size()); k++)
         table_item(glo.data(), ghi.data(), (F*)nullptr, group_gen(), lg_domain, h, k);
     ntt_tables<F> G{glo.data(), ghi.data(), nullptr, lg_domain, h, F::one()};
+    // as ntt_engine::run(.., lde): the spread + coset shift inside the first step of the radix-64 plan (the extended buffer is
+    // then never read: filled with a pattern here), as a pass of its own otherwise
+    const unsigned lg_ext = lg_domain + lg_blowup;
+    if (sizeof(F) <= 8 && lg_ext >= 12 && lg_ext >= g_r64_min && lg_blowup >= 1 && lg_blowup <= 3
+        && make_r64_plan(lg_ext).step[make_r64_plan(lg_ext).nsteps - 1].kind == 2) {
+        memset((void*)ext, 0xA5, n_ext * sizeof(F));
+        const emu_lde_in li{tmp.data(), glo.data(), ghi.data(), h, lg_domain, lg_blowup};
+        g_lde_in = &li;
+        emu_ntt(ext, lg_ext, 2, 0, 0, 64);
+        g_lde_in = nullptr;
+        return 1;
+    }
     for (size_t o = 0; o < n_ext; o++) lde_spread_item(ext, tmp.data(), G, lg_domain, lg_blowup, 1, o);
-    emu_ntt(ext, lg_domain + lg_blowup, 2, 0, 0, 64);
+    emu_ntt(ext, lg_ext, 2, 0, 0, 64);
     return 0;
 }

@@ -123,12 +123,15 @@ def test_lde_kernels_on_host(oracle, field, feature):
     O = oracle
     L = _emu(feature)
     w = 4 if field in ("bls12_381", "bn254") else 1
-    for lg, lgb in ((1, 1), (3, 2), (6, 1), (9, 2), (11, 3) if w == 1 else (8, 3)):
+    # (single-word fields from 2^12 extended elements on, blow-up 2 / 4 / 8: the spread and the coset shift inside the first
+    #  k_ntt12 step of the forward transform -- emu_lde returns 1 --, a spread pass of its own otherwise)
+    for lg, lgb in ((1, 1), (3, 2), (6, 1), (9, 2), (11, 3), (11, 1), (10, 2), (12, 2), (9, 4), (13, 1)) if w == 1 else ((1, 1), (3, 2), (6, 1), (9, 2), (8, 3)):
         x = recipe.ntt_input(field, lg, 300 + lg)
         exp, aux_exp = O.lde(field, x, lgb, want_aux=True)
         buf = np.zeros(((1 << (lg + lgb)), w), dtype=x.dtype); buf[:1 << lg] = x.reshape(-1, w)
         aux = np.zeros((1 << lg, w), dtype=x.dtype)
-        L.emu_lde(buf.ctypes.data, lg, lgb, aux.ctypes.data)
+        fused = L.emu_lde(buf.ctypes.data, lg, lgb, aux.ctypes.data)
+        assert fused == (1 if w == 1 and lg + lgb >= 12 and lgb <= 3 else 0), (field, lg, lgb, fused)
         assert (buf.reshape(exp.shape) == exp).all(), (field, lg, lgb)
         assert (aux.reshape(aux_exp.shape) == aux_exp).all(), (field, lg, lgb)
 

@@ -273,6 +273,47 @@ void k_bucket_level1_coop(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __re
     if (live && c.role == 0) { acc.store(&A[id]); ret.store(&Wt[id]); }
 }
 
+// The first level for grids between the cooperative form and one resident round of waves (COOP_LEVEL_MAX < work items <=
+// LAT_LANES: 2^17 ... 2^21 points), its two chains on TWO WAVES: acc_j = acc_(j+1) + B_j and ret = sum_j acc_j are 2 (K - 1)
+// dependent additions for one lane (k_bucket_level1_lat: 0.27 ms of a 1.4 ms MSM at 2^18 points with 544 waves on 1024 SIMDs),
+// but ret only ever needs the acc of the step before: wave 0 of a 128-lane work-group runs the acc chain of 64 work items and
+// leaves every acc in LDS (two images, alternating), wave 1 adds the previous one to ret in the same step -- K + 1 additions deep.
+template<class FP>
+__global__ __launch_bounds__(128, 2)
+void k_bucket_level1_pipe(xyzz_mem<FP::N>* __restrict__ A, xyzz_mem<FP::N>* __restrict__ Wt,
+                          const xyzz_mem<FP::N>* __restrict__ buckets, unsigned NB, unsigned K, unsigned nwins,
+                          const u32* __restrict__ off)
+{
+    __shared__ coop_img<FP, 64> img[2];
+    const unsigned role = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned nchunks = NB / K;
+    const size_t id = (size_t)blockIdx.x * 64 + lane;
+    const bool live = id < (size_t)nwins * nchunks;
+    const unsigned w = live ? (unsigned)(id / nchunks) : 0, u = live ? (unsigned)(id % nchunks) : 0;
+    const xyzz_mem<FP::N>* row = buckets + (size_t)w * NB + (size_t)u * K;
+    const u32* o = off ? off + (size_t)w * (NB + 1) + (size_t)u * K : nullptr;
+    xyzz_dev<FP> v; v.set_inf();                                    // wave 0: acc, wave 1: ret
+    // step s: wave 0 brings acc to acc_(K-1-s) and leaves it in img[s & 1]; wave 1 takes acc_(K-s) from img[(s - 1) & 1]
+    #pragma unroll 1
+    for (unsigned s = 0; s < K; s++) {
+        if (role == 0) {
+            xyzz_dev<FP> y;
+            if (live) y = bucket_load<FP>(row, o, K - 1 - s); else y.set_inf();
+            if (s == 0) v = y; else bucket_add_fast<FP>(v, y);
+            img[s & 1].store(lane, v);
+        } else if (s >= 1) {
+            const xyzz_dev<FP> y = img[(s - 1) & 1].load(lane);
+            if (s == 1) v = y; else bucket_add_fast<FP>(v, y);
+        }
+        coop_barrier();
+    }
+    if (role == 1) {
+        const xyzz_dev<FP> y = img[(K - 1) & 1].load(lane);         // acc_0
+        if (K == 1) v = y; else bucket_add_fast<FP>(v, y);
+    }
+    if (live) v.store(role == 0 ? &A[id] : &Wt[id]);
+}
+
 template<class FP>
 __global__ __launch_bounds__(COOP_NT)
 void k_bucket_levelN_coop(xyzz_mem<FP::N>* __restrict__ A2, xyzz_mem<FP::N>* __restrict__ Wt2,

@@ -789,6 +789,10 @@ private:
                 if (lat && nthr <= COOP_LEVEL_MAX && tune.join != 4)
                     hipLaunchKernelGGL(k_bucket_level1_coop<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(COOP_NT), 0, stream,
                                        A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
+                // (between that and one resident round of waves: the two chains of a work item on two waves; tune.join 10: on one)
+                else if (lat && tune.join != 10 && tune.join != 4)
+                    hipLaunchKernelGGL(k_bucket_level1_pipe<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(128), 0, stream,
+                                       A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
                 else if (lat) hipLaunchKernelGGL(k_bucket_level1_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                                                  A1, W1, buckets, p.NB, p.K1, p.nwins, offp);
             }

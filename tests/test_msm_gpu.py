@@ -313,7 +313,7 @@ def test_msm_tunables(oracle, libs, tune):
 def test_msm_tail_variants(oracle, libs, curve, name):
     """The tail of an MSM (record list + bucket sums) in every form the driver can run it: k_join_runs on / off,
     with and without the one-launch narrow end of the tree (k_reduce_tail) and the low-latency bucket-sum kernels,
-    first-level chunks of 4 / 16 -- on inputs where the join resolves everything (many buckets, short segments), where
+    the first level's two sums on one lane instead of two waves (10), first-level chunks of 4 / 16 -- on inputs where the join resolves everything (many buckets, short segments), where
     it resolves nothing (one bucket holds all entries: the tree does the work) and in between."""
     import sppark_amd
     O = oracle
@@ -326,7 +326,7 @@ def test_msm_tail_variants(oracle, libs, curve, name):
                         (s_two, (dict(wbits=9, L=4, F=4),))):
         exp = O.msm_affine(curve, pts, scal, algo=0, param=8)
         for plan in plans:
-            for join, k1 in ((0, 0), (1, 0), (2, 0), (3, 0), (0, 4), (0, 16)):
+            for join, k1 in ((0, 0), (1, 0), (2, 0), (3, 0), (10, 0), (0, 4), (0, 16)):
                 ctx.tune(**plan); ctx.tune_tail(join, k1)
                 out = ctx.invoke(pts, scal)
                 assert (sppark_amd.to_affine(out, name) == exp).all(), (plan, join, k1)

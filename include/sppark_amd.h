@@ -199,8 +199,8 @@ SppError sppark_msm_tune_sums(sppark_msm_ctx *ctx, unsigned top_items);
  * (k_reduce_tail), 3 = without the low-latency bucket-sum kernels for small grids, 4 = without the cooperative (four waves
  * per operation) kernels, 5 = without the piece tree of the small sizes, 6 = the point conversion with one lane per point
  * instead of the coalesced form, 7 = the subset-sum top with a work-group per sum instead of per piece of a sum, 8 = every level of the piece
- * tree a launch of its own (no k_piece_tail_coop), 16 + x = that launch from the first level of at most 2^x work items, 10 = the first bucket-sum level of the medium sizes with one lane per work
- * item (k_bucket_level1_lat) instead of its two sums on two waves (k_bucket_level1_pipe).  k1: buckets per work item of the first bucket-sum level (a power of
+ * tree a launch of its own (no k_piece_tail_coop), 16 + x = that launch from the first level of at most 2^x work items, 10 = the latency-bound chunked bucket-sum levels with one lane per work
+ * item (k_bucket_level1_lat / _levelN_lat) instead of their sums on two / three waves (k_bucket_level1_pipe / _levelN_pipe).  k1: buckets per work item of the first bucket-sum level (a power of
  * two; 0 = the same as the other levels). */
 SppError sppark_msm_tune_tail(sppark_msm_ctx *ctx, unsigned join, unsigned k1);
 /* Pipeline shape.  groups: the windows are sorted and accumulated in this many groups, the digits +

@@ -23,6 +23,7 @@ extern template __global__ void k_join_runs<msm_fp_d>(bucket_m*, u32*, const u32
 extern template __global__ void k_reduce_tail<msm_fp_d>(bucket_m*, u32*, bucket_m*, u32*, bucket_m*, unsigned, unsigned, const u32*);
 extern template __global__ void k_piece_level<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,
                                                         unsigned, unsigned, unsigned, u32*);
+extern template __global__ void k_bucket_levelN_pipe<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, unsigned);
 extern template __global__ void k_bucket_level1_pipe<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 extern template __global__ void k_bucket_small_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const u32*, unsigned, unsigned);
 extern template __global__ void k_piece_level_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,

@@ -17,6 +17,7 @@ template __global__ void k_reduce_tail_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*
 template __global__ void k_bucket_level1_coop<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 template __global__ void k_bucket_levelN_coop<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*,
                                                         unsigned, unsigned, unsigned, unsigned);
+template __global__ void k_bucket_levelN_pipe<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, unsigned);
 template __global__ void k_bucket_level1_pipe<msm_fp_d>(bucket_m*, bucket_m*, const bucket_m*, unsigned, unsigned, unsigned, const u32*);
 template __global__ void k_bucket_small_bits_coop<msm_fp_d>(bucket_m*, const bucket_m*, const u32*, unsigned, unsigned);
 template __global__ void k_piece_level_coop<msm_fp_d>(bucket_m*, u32*, bucket_m*, const u32*, unsigned, unsigned, unsigned, unsigned,

@@ -853,6 +853,9 @@ private:
                     if (lat && nthr <= COOP_LEVEL_MAX && tune.join != 4)
                         hipLaunchKernelGGL(k_bucket_levelN_coop<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(COOP_NT), 0, stream,
                                            oa, ow, ia, iw, nitems, K, lgG, p.nwins);
+                    else if (lat && tune.join != 10 && tune.join != 4)      // (its three sums on three waves; tune.join 10: on one lane)
+                        hipLaunchKernelGGL(k_bucket_levelN_pipe<fp_d>, dim3((unsigned)((nthr + 63) / 64)), dim3(192), 0, stream,
+                                           oa, ow, ia, iw, nitems, K, lgG, p.nwins);
                     else if (lat) hipLaunchKernelGGL(k_bucket_levelN_lat<fp_d>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                                                      oa, ow, ia, iw, nitems, K, lgG, p.nwins);
                 }
